@@ -1,0 +1,300 @@
+"""ctypes binding of libmislam.so -- the C ABI declared in include/mi_slam.h.
+
+This module is plumbing for the Python-side callers in this repository (tests, bench.py, __graft_entry__): it passes host
+numpy buffers straight through to the C entry points and adds nothing of its own.  There is deliberately no fallback: if
+the shared library is missing, or no HIP device is usable, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmislam.so")
+
+MI_OK = 0
+DIST_CPU_ROUNDING, DIST_FMA = 0, 1
+COMPOSE_CPU_ADDITIVE, COMPOSE_EXACT = 0, 1
+STOP_RUNNING, STOP_CONVERGED, STOP_MAX_ITERATIONS, STOP_NO_PAIRS, STOP_ERROR_INCREASED, STOP_TOLERANCE, STOP_SIGMA = range(7)
+(KERNEL_NN, KERNEL_MOMENTS, KERNEL_SOLVE, KERNEL_TRANSFORM, KERNEL_FINALIZE, KERNEL_ALLREDUCE, KERNEL_CPD_DENOM,
+ KERNEL_CPD_CONTRACT, KERNEL_CPD_MSTEP) = range(9)
+KERNEL_NAMES = ["nn", "moments", "solve", "transform", "finalize", "allreduce", "cpd_denom", "cpd_contract", "cpd_mstep"]
+UNIQUE_ID_BYTES = 128
+
+# every symbol include/mi_slam.h declares (tests check that the library exports each of them)
+EXPORTS = [
+    "mi_abi_version", "mi_last_error", "mi_device_count", "mi_ctx_create", "mi_dist_unique_id", "mi_ctx_create_dist",
+    "mi_ctx_rank", "mi_shard_range", "mi_pack_key", "mi_unpack_key", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_icp_params_default", "mi_icp_params_cuda_slam",
+    "mi_icp_register", "mi_icp_load", "mi_icp_reset", "mi_icp_run", "mi_icp_result", "mi_nn_search", "mi_kabsch",
+    "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_estep",
+    "mi_cpd_mstep", "mi_profile_enable", "mi_profile_reset", "mi_profile_get",
+]
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("eps", C.c_float), ("max_iterations", C.c_int), ("max_distance_squared", C.c_float),
+                ("dist_mode", C.c_int), ("compose_mode", C.c_int), ("filter_pairs", C.c_int),
+                ("abort_on_increase", C.c_int), ("sync_every", C.c_int), ("verbose", C.c_int), ("reserved", C.c_int * 7)]
+
+
+class CpdParams(C.Structure):
+    _fields_ = [("eps", C.c_float), ("weight", C.c_float), ("const_scale", C.c_int), ("max_iterations", C.c_int),
+                ("tolerance", C.c_float), ("sigma2_init", C.c_float), ("sync_every", C.c_int), ("verbose", C.c_int),
+                ("reserved", C.c_int * 8)]
+
+
+class MiSlamError(RuntimeError):
+    pass
+
+
+_lib = None
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int)
+_u8 = C.POINTER(C.c_ubyte)
+
+
+def lib():
+    """Load libmislam.so (raises if it has not been built -- run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MiSlamError("libmislam.so not built at %s: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        _lib.mi_last_error.restype = C.c_char_p
+        _lib.mi_ctx_destroy.restype = None
+        _lib.mi_icp_params_default.restype = None
+        _lib.mi_icp_params_cuda_slam.restype = None
+        _lib.mi_cpd_params_default.restype = None
+        _lib.mi_pack_key.restype = C.c_ulonglong
+        _lib.mi_pack_key.argtypes = [C.c_float, C.c_int]
+        _lib.mi_unpack_key.restype = None
+        _lib.mi_unpack_key.argtypes = [C.c_ulonglong, _f, _i]
+    return _lib
+
+
+def _check(rc):
+    if rc != MI_OK:
+        raise MiSlamError("libmislam error %d: %s" % (rc, lib().mi_last_error().decode()))
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f)
+
+
+def _cloud(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 3:
+        raise ValueError("cloud must be [n,3] float32")
+    return a
+
+
+def device_count():
+    c = C.c_int(0)
+    _check(lib().mi_device_count(C.byref(c)))
+    return c.value
+
+
+def icp_params(cuda_slam=False, **kw):
+    p = IcpParams()
+    (lib().mi_icp_params_cuda_slam if cuda_slam else lib().mi_icp_params_default)(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def cpd_params(**kw):
+    p = CpdParams()
+    lib().mi_cpd_params_default(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def shard_range(m_total, rank, world):
+    lo, hi = C.c_int(0), C.c_int(0)
+    _check(lib().mi_shard_range(m_total, rank, world, C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+def pack_key(d2, index):
+    return int(lib().mi_pack_key(float(d2), int(index)))
+
+
+def unpack_key(key):
+    d2, idx = C.c_float(0), C.c_int(0)
+    lib().mi_unpack_key(C.c_ulonglong(key), C.byref(d2), C.byref(idx))
+    return d2.value, idx.value
+
+
+def dist_unique_id():
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    _check(lib().mi_dist_unique_id(buf))
+    return buf.raw
+
+
+def _T_to_Rt(T):
+    M = np.array(T, dtype=np.float32).reshape(4, 4).T   # column-major -> M[row, col]
+    return M[:3, :3].copy(), M[:3, 3].copy()
+
+
+class Context:
+    """mi_ctx handle.  Context(device) or Context(device, rank, world, unique_id) for the multi-GPU path."""
+
+    def __init__(self, device=0, rank=None, world=None, unique_id=None):
+        self._h = C.c_void_p()
+        if world is None:
+            _check(lib().mi_ctx_create(device, C.byref(self._h)))
+        else:
+            _check(lib().mi_ctx_create_dist(device, rank, world, unique_id, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().mi_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(lib().mi_ctx_synchronize(self._h))
+
+    def rank_world(self):
+        r, w = C.c_int(0), C.c_int(0)
+        _check(lib().mi_ctx_rank(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    # ---- ICP
+    def icp_register(self, before, after, params):
+        before, after = _cloud(before), _cloud(after)
+        T = (C.c_float * 16)()
+        it, err = C.c_int(0), C.c_float(0)
+        _check(lib().mi_icp_register(self._h, _fp(before), before.shape[0], _fp(after), after.shape[0], C.byref(params), T,
+                                     C.byref(it), C.byref(err)))
+        R, t = _T_to_Rt(T)
+        return R, t, it.value, err.value
+
+    def icp_load(self, before, after, params):
+        before, after = _cloud(before), _cloud(after)
+        _check(lib().mi_icp_load(self._h, _fp(before), before.shape[0], _fp(after), after.shape[0], C.byref(params)))
+
+    def icp_reset(self):
+        _check(lib().mi_icp_reset(self._h))
+
+    def icp_run(self, max_new_iterations):
+        done = C.c_int(0)
+        _check(lib().mi_icp_run(self._h, max_new_iterations, C.byref(done)))
+        return done.value
+
+    def icp_result(self):
+        T = (C.c_float * 16)()
+        it, err, why = C.c_int(0), C.c_float(0), C.c_int(0)
+        _check(lib().mi_icp_result(self._h, T, C.byref(it), C.byref(err), C.byref(why)))
+        R, t = _T_to_Rt(T)
+        return R, t, it.value, err.value, why.value
+
+    # ---- primitives
+    def nn_search(self, src, tgt, dist_mode=DIST_CPU_ROUNDING):
+        src, tgt = _cloud(src), _cloud(tgt)
+        n = src.shape[0]
+        idx = np.empty(n, np.int32)
+        d2 = np.empty(n, np.float32)
+        _check(lib().mi_nn_search(self._h, _fp(src), n, _fp(tgt), tgt.shape[0], dist_mode, idx.ctypes.data_as(_i), _fp(d2)))
+        return idx, d2
+
+    def kabsch(self, src, tgt, idx, keep=None):
+        src, tgt = _cloud(src), _cloud(tgt)
+        idx = np.ascontiguousarray(idx, np.int32)
+        kp = None
+        if keep is not None:
+            keep = np.ascontiguousarray(keep, np.uint8)
+            kp = keep.ctypes.data_as(_u8)
+        R9 = (C.c_float * 9)()
+        t3 = (C.c_float * 3)()
+        used = C.c_int(0)
+        _check(lib().mi_kabsch(self._h, _fp(src), src.shape[0], _fp(tgt), tgt.shape[0], idx.ctypes.data_as(_i), kp, R9, t3,
+                               C.byref(used)))
+        return np.array(R9, np.float32).reshape(3, 3).T.copy(), np.array(t3, np.float32), used.value
+
+    def transform_mse(self, src, R, t, tgt=None, idx=None, keep=None, divide_by_pairs=True, want_cloud=True):
+        src = _cloud(src)
+        n = src.shape[0]
+        R9 = np.ascontiguousarray(np.asarray(R, np.float32).T).reshape(9)
+        t3 = np.ascontiguousarray(t, np.float32)
+        out = np.empty((n, 3), np.float32) if want_cloud else None
+        mse = C.c_float(0)
+        tp, m, ip, kp = None, 0, None, None
+        if tgt is not None:
+            tgt = _cloud(tgt)
+            tp, m = _fp(tgt), tgt.shape[0]
+            idx = np.ascontiguousarray(idx, np.int32)
+            ip = idx.ctypes.data_as(_i)
+            if keep is not None:
+                keep = np.ascontiguousarray(keep, np.uint8)
+                kp = keep.ctypes.data_as(_u8)
+        _check(lib().mi_transform_mse(self._h, _fp(src), n, _fp(R9), _fp(t3), tp, m, ip, kp, 1 if divide_by_pairs else 0,
+                                      _fp(out) if want_cloud else None, C.byref(mse) if tgt is not None else None))
+        return out, (mse.value if tgt is not None else None)
+
+    # ---- CPD
+    def cpd_register(self, before, after, params):
+        before, after = _cloud(before), _cloud(after)
+        T = (C.c_float * 16)()
+        it, err, sc = C.c_int(0), C.c_float(0), C.c_float(0)
+        _check(lib().mi_cpd_register(self._h, _fp(before), before.shape[0], _fp(after), after.shape[0], C.byref(params), T,
+                                     C.byref(sc), C.byref(it), C.byref(err)))
+        sR, t = _T_to_Rt(T)
+        return sR, t, sc.value, it.value, err.value
+
+    def cpd_sigma_squared(self, before, after):
+        before, after = _cloud(before), _cloud(after)
+        s = C.c_float(0)
+        _check(lib().mi_cpd_sigma_squared(self._h, _fp(before), before.shape[0], _fp(after), after.shape[0], C.byref(s)))
+        return s.value
+
+    def cpd_estep(self, y, x, constant, sigma2):
+        y, x = _cloud(y), _cloud(x)
+        m, n = y.shape[0], x.shape[0]
+        p1 = np.empty(m, np.float32)
+        pt1 = np.empty(n, np.float32)
+        px = np.empty((m, 3), np.float32)
+        L = C.c_float(0)
+        _check(lib().mi_cpd_estep(self._h, _fp(y), m, _fp(x), n, C.c_float(constant), C.c_float(sigma2), _fp(p1), _fp(pt1),
+                                  _fp(px), C.byref(L)))
+        return p1, pt1, px, L.value
+
+    def cpd_mstep(self, before, after, p1, pt1, px, const_scale, scale=1.0, sigma2=0.0):
+        before, after = _cloud(before), _cloud(after)
+        p1 = np.ascontiguousarray(p1, np.float32)
+        pt1 = np.ascontiguousarray(pt1, np.float32)
+        px = np.ascontiguousarray(px, np.float32)
+        R9 = (C.c_float * 9)()
+        t3 = (C.c_float * 3)()
+        s, s2 = C.c_float(scale), C.c_float(sigma2)
+        _check(lib().mi_cpd_mstep(self._h, _fp(before), before.shape[0], _fp(after), after.shape[0], _fp(p1), _fp(pt1), _fp(px),
+                                  1 if const_scale else 0, R9, t3, C.byref(s), C.byref(s2)))
+        return np.array(R9, np.float32).reshape(3, 3).T.copy(), np.array(t3, np.float32), s.value, s2.value
+
+    # ---- profiling
+    def profile_enable(self, on=True):
+        _check(lib().mi_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        _check(lib().mi_profile_reset(self._h))
+
+    def profile_get(self, kernel):
+        ms, n = C.c_double(0), C.c_longlong(0)
+        _check(lib().mi_profile_get(self._h, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,137 @@
+// Context object behind the opaque mi_ctx handle: device, stream, grow-only workspace, optional RCCL communicator,
+// HIP-event profiling.  Shared by the ICP and CPD drivers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_slam.h"
+#include "kernels.h"
+
+namespace mislam {
+
+void set_error(const char* fmt, ...);
+
+#define MI_HIP(call)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) {                                                                            \
+            mislam::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);  \
+            return MI_ERR_HIP;                                                                             \
+        }                                                                                                  \
+    } while (0)
+
+#define MI_NCCL(call)                                                                                      \
+    do {                                                                                                   \
+        ncclResult_t r_ = (call);                                                                          \
+        if (r_ != ncclSuccess) {                                                                           \
+            mislam::set_error("%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+            return MI_ERR_RCCL;                                                                            \
+        }                                                                                                  \
+    } while (0)
+
+#define MI_TRY(call)             \
+    do {                         \
+        int rc_ = (call);        \
+        if (rc_ != MI_OK) return rc_; \
+    } while (0)
+
+// grow-only device buffer
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t count)
+    {
+        if (count <= cap) return MI_OK;
+        if (p) {
+            MI_HIP(hipDeviceSynchronize());   // work still reading the old buffer must drain before it is freed
+            MI_HIP(hipFree(p));
+        }
+        p = nullptr;
+        cap = 0;
+        MI_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        cap = count;
+        return MI_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct ProfileSpan {
+    int kernel;
+    hipEvent_t e0, e1;
+};
+
+struct CpdWorkspace;   // cpd_api.hip
+
+}  // namespace mislam
+
+struct mi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+    int cu_count = 256;
+
+    // ---- workspace shared by the drivers
+    mislam::DevBuf<float> staging;                       // AoS upload/download staging
+    mislam::DevBuf<float> bx, by, bz;                    // original moving cloud, SoA
+    mislam::DevBuf<float> cx, cy, cz;                    // current (transformed) moving cloud, SoA
+    mislam::DevBuf<float> tx, ty, tz;                    // this rank's fixed-cloud shard, SoA (K1 scalar streams)
+    mislam::DevBuf<float4> tgt4;                         // same shard as float4 (gathers)
+    mislam::DevBuf<unsigned long long> keys;
+    mislam::DevBuf<double> part_mom, part_err;
+    mislam::DevBuf<int> idx_tmp;
+    mislam::DevBuf<unsigned char> keep_tmp;
+    mislam::IcpState* d_state = nullptr;
+    mislam::IcpState* h_state = nullptr;                 // pinned
+
+    // ---- ICP problem currently loaded
+    bool icp_loaded = false;
+    int n = 0, n_pad = 0;
+    int m_total = 0, shard_lo = 0, shard_hi = 0;
+    mi_icp_params icp{};
+
+    // ---- CPD workspace (allocated on first use)
+    mislam::CpdWorkspace* cpd = nullptr;
+
+    // ---- profiling
+    bool profile = false;
+    std::vector<mislam::ProfileSpan> spans;
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[MI_KERNEL_COUNT] = {0};
+    long long prof_n[MI_KERNEL_COUNT] = {0};
+
+    int prof_begin(int kernel);
+    int prof_end();
+    int prof_collect();
+};
+
+namespace mislam {
+
+struct ProfScope {
+    mi_ctx* c;
+    bool on;
+    ProfScope(mi_ctx* ctx, int kernel) : c(ctx), on(ctx->profile) { if (on) (void)c->prof_begin(kernel); }
+    ~ProfScope() { if (on) (void)c->prof_end(); }
+};
+
+struct NnPlan {
+    int R, n_chunks, chunk_len;
+};
+NnPlan plan_nn(const mi_ctx* ctx, int n, int m_local);
+size_t target_alloc_len(int m_local);
+
+// Upload an AoS host cloud into SoA device arrays of n_pad entries (tail = copies of the last point).
+int upload_soa(mi_ctx* ctx, const float* host_aos, int n, int n_pad, float* x, float* y, float* z, float4* packed);
+
+}  // namespace mislam

@@ -1,0 +1,76 @@
+// Internal launch interfaces of the rigid-CPD kernels (cpd_kernels.hip).  Naming follows the reference's CPD code
+// (source/common/cpdutils.cpp:28-29): M = |before| = moving cloud y_k (index k), N = |after| = fixed cloud x (index x).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace mislam {
+
+constexpr int CPD_T = 8;              // scalar-load block of the broadcast stream
+constexpr int CPD_XSUMS = 8;          // sum log den, sum pt1*a (3), sum pt1*|a|^2, 3 spare
+constexpr int CPD_KSUMS = 16;         // Np, sum p1*b (3), sum b_r*px_c (9, row-major in r), sum p1*|b|^2, 2 spare
+constexpr int CPD_INIT_SUMS = 8;      // sum a (3), sum |a|^2, sum b (3), sum |b|^2
+constexpr int CPD_MAX_CHUNKS = 256;
+
+struct CpdState {
+    float R[9];            // rotation, column-major
+    float t[3];
+    float scale;
+    float sigma2;
+    float sigma2_init;
+    float constant;        // c of coherentpointdrift.cpp:98 (fixed from sigma2_init)
+    float L;               // Probabilities::error of the last E-step
+    float l_prev;
+    float ntol;
+    float error;
+    float Np;
+    int iterations;
+    int done;
+    int stop_reason;
+    double xs[CPD_XSUMS];
+    double ks[CPD_KSUMS];
+    double init[CPD_INIT_SUMS];
+};
+
+struct CpdRules {
+    float eps, weight, tolerance;
+    int const_scale, max_iterations;
+    int m, n;
+};
+
+struct CpdView {
+    CpdState* state;
+    // moving cloud: original b (SoA) and current y = s*R*b + t (SoA), m_pad entries each
+    const float *bx, *by, *bz;
+    float *yx, *yy, *yz;
+    int m;
+    // fixed cloud a (SoA), n_pad entries
+    const float *ax, *ay, *az;
+    int n;
+    // E-step products
+    float* den_part;       // [x_chunks_of_k][n]   partial sum_k p_xk
+    float4* xw4;           // [n]  (w*ax, w*ay, w*az, w), w = 1/den_x
+    float* pt1;            // [n]
+    float* p1_part;        // [chunks][m]
+    float* px_part;        // [chunks][3][m]  (SoA per component)
+    float* p1;             // [m]
+    float* px;             // [m][3] row-major, the reference's px.row(k)
+    int k_chunks, k_chunk_len;   // K7a: chunks over k
+    int x_chunks, x_chunk_len;   // K7b: chunks over x
+};
+
+hipError_t cpd_init_sums(const CpdView& v, double* partials, int nblocks, hipStream_t s);
+hipError_t cpd_init_state(CpdState* state, const double* partials, int nblocks, const CpdRules& rules, float sigma2_override, hipStream_t s);
+hipError_t cpd_denominators(const CpdView& v, hipStream_t s);                                  // K7a
+hipError_t cpd_post_denominators(const CpdView& v, hipStream_t s);                             //   den, w, Pt1, xw4
+hipError_t cpd_contract(const CpdView& v, int use_mfma, hipStream_t s);                        // K7b
+hipError_t cpd_post_contract(const CpdView& v, hipStream_t s);                                 //   P1, PX from chunk partials
+hipError_t cpd_xsums(const CpdView& v, double* partials, int nblocks, hipStream_t s);          // K8 part 1
+hipError_t cpd_ksums(const CpdView& v, double* partials, int nblocks, hipStream_t s);          // K8 part 2
+hipError_t cpd_reduce_sums(CpdState* state, const double* xpart, int nxb, const double* kpart, int nkb, hipStream_t s);
+hipError_t cpd_solve(CpdState* state, const double* xpart, int nxb, const double* kpart, int nkb, const CpdRules& rules,
+                     int update_loop_state, hipStream_t s);                                    // K8 solve (+ EM bookkeeping)
+hipError_t cpd_transform(const CpdView& v, int m_pad, hipStream_t s);                          // y = s*R*b + t
+
+}  // namespace mislam

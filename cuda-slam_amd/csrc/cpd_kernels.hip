@@ -1,0 +1,431 @@
+// K6-K8 -- rigid Coherent Point Drift with the exact Gaussian P, for gfx950.
+//
+// The reference's GPU E-step (ComputePMatrix, source/cuda-slam/cpdcuda.cu:80-116) walks the fixed cloud on the HOST and
+// issues three thrust launches plus two tiny memcpys PER TARGET POINT (~3N launches per EM iteration); its M-step
+// (cpdcuda.cu:172-300) is five cuBLAS calls, cuSOLVER, seven thrust passes and six memcpys.  Here one EM iteration is a
+// fixed, short sequence of kernels on one stream with no host round trip, in the streaming ("never materialise P")
+// formulation the reference's CPU code uses (source/cpu-slam/coherentpointdrift.cpp:168-221):
+//
+//   K7a cpd_denominator_kernel   lanes own fixed points x, the moving cloud y_k streams through SGPRs:
+//                                partial den_x = sum_k exp(-|x - y_k|^2 / 2 sigma^2) per k-chunk
+//       cpd_post_den_kernel      den_x (+ c), w_x = 1/den_x, Pt1[x] = 1 - c*w_x, the contraction operand (w x, w)
+//   K7b cpd_contract_kernel      lanes own moving points y_k, the fixed cloud streams through SGPRs: P~ is re-computed
+//                                (never stored: 888 MB at bunny size) and contracted with [w x | w]:
+//                                P1[k] = sum_x p_xk w_x, PX[k] = sum_x p_xk (w_x x)  -- VALU form, or with the
+//                                4x4x1 fp32 MFMA doing the 64x4 rank-1 update per fixed point on the matrix pipe
+//       cpd_post_contract_kernel fixed-order sum of the chunk partials -> P1, PX
+//   K8  cpd_xsums / cpd_ksums    the weighted moments of the M-step in fp64 (Np, mu_a, mu_b, B*PX, the two |.|^2 sums)
+//       cpd_solve_kernel         reduce + 3x3 Jacobi SVD + scale / sigma^2 / t + the EM stop rule, on one lane
+//       cpd_transform_kernel     y = s*R*b + t
+//
+// Arithmetic: fp32 pair terms as in the reference, fp64 for every long sum; compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "cpd_kernels.h"
+#include "reduce.hpp"
+#include "svd3.hpp"
+
+namespace mislam {
+
+__device__ __forceinline__ float sq_dist(float ax, float ay, float az, float bx, float by, float bz)
+{
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;   // cloudAfter[x] - cloudTransformed[k], coherentpointdrift.cpp:190
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sigma^2 initialisation: sum_ij |b_i - a_j|^2 = N sum|b|^2 + M sum|a|^2 - 2 (sum a).(sum b), O(M+N) in fp64
+// (CalculateSigmaSquared, cpdcuda.cu:65-78, is O(M*N); see mi_slam.h on why the closed form is used)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cpd_init_sums_kernel(CpdView v, double* __restrict__ partials)
+{
+    double acc[CPD_INIT_SUMS] = {0};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n; i += gridDim.x * 256) {
+        const double x = v.ax[i], y = v.ay[i], z = v.az[i];
+        acc[0] += x; acc[1] += y; acc[2] += z; acc[3] += x * x + y * y + z * z;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < v.m; i += gridDim.x * 256) {
+        const double x = v.bx[i], y = v.by[i], z = v.bz[i];
+        acc[4] += x; acc[5] += y; acc[6] += z; acc[7] += x * x + y * y + z * z;
+    }
+    block_sum_store<CPD_INIT_SUMS>(acc, partials + (size_t)blockIdx.x * CPD_INIT_SUMS);
+}
+
+__global__ __launch_bounds__(256) void cpd_init_state_kernel(CpdState* __restrict__ st, const double* __restrict__ partials, int nblocks,
+                                                             CpdRules rules, float sigma2_override)
+{
+    __shared__ double lds[256];
+    double s[CPD_INIT_SUMS];
+    reduce_partials<CPD_INIT_SUMS>(partials, nblocks, s, lds);
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < CPD_INIT_SUMS; i++) st->init[i] = s[i];
+    const double M = rules.m, N = rules.n;
+    const double total = N * s[7] + M * s[3] - 2.0 * (s[0] * s[4] + s[1] * s[5] + s[2] * s[6]);
+    float sigma2 = (float)(total / (3.0 * M * N));
+    if (sigma2_override > 0.f) sigma2 = sigma2_override;
+    for (int i = 0; i < 9; i++) st->R[i] = (i % 4 == 0) ? 1.f : 0.f;
+    st->t[0] = st->t[1] = st->t[2] = 0.f;
+    st->scale = 1.f;
+    st->sigma2 = sigma2;
+    st->sigma2_init = sigma2;
+    // constant = (pow(2*M_PI*sigma2, 1.5) * weight * |before|) / ((1 - weight) * |after|)   coherentpointdrift.cpp:98:
+    // the pow and the numerator are double, the denominator a float product, the quotient narrowed to float
+    const double num = pow(2.0 * 3.14159265358979323846 * (double)sigma2, 1.5) * (double)rules.weight * M;
+    const float den = (1.f - rules.weight) * (float)rules.n;
+    st->constant = (float)(num / (double)den);
+    st->L = 0.f;
+    st->l_prev = 0.f;
+    st->ntol = rules.tolerance + 10.0f;      // :99
+    st->error = 1e5f;                        // :86
+    st->Np = 0.f;
+    st->iterations = 0;
+    st->stop_reason = MI_STOP_RUNNING_;
+    // loop condition, evaluated before the first iteration (:106)
+    st->done = 0;
+    if (!(0 < rules.max_iterations)) { st->done = 1; st->stop_reason = MI_STOP_MAX_ITERATIONS_; }
+    else if (!(sigma2 > rules.eps)) { st->done = 1; st->stop_reason = MI_STOP_SIGMA_; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K7a: partial denominators.  grid = x_blocks * k_chunks, lane owns R fixed points, y_k broadcast from SGPRs.
+// ---------------------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void cpd_denominator_kernel(CpdView v)
+{
+    if (v.state->done != 0) return;
+    const int chunk = blockIdx.x % v.k_chunks;
+    const int xblk = blockIdx.x / v.k_chunks;
+    const int x0 = xblk * (256 * R) + threadIdx.x;
+    const float mult = -0.5f / v.state->sigma2;          // coherentpointdrift.cpp:176
+    float ax[R], ay[R], az[R], sum[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = min(x0 + r * 256, v.n - 1);
+        ax[r] = v.ax[i]; ay[r] = v.ay[i]; az[r] = v.az[i];
+        sum[r] = 0.f;
+    }
+    const int k_begin = chunk * v.k_chunk_len;
+    const int k_end = min(k_begin + v.k_chunk_len, v.m);
+    int k = k_begin;
+    for (; k + CPD_T <= k_end; k += CPD_T) {
+#pragma unroll
+        for (int u = 0; u < CPD_T; u++) {
+            const float yx = v.yx[k + u], yy = v.yy[k + u], yz = v.yz[k + u];   // wave-uniform -> scalar loads
+#pragma unroll
+            for (int r = 0; r < R; r++) sum[r] += expf(mult * sq_dist(ax[r], ay[r], az[r], yx, yy, yz));
+        }
+    }
+    for (; k < k_end; k++) {
+        const float yx = v.yx[k], yy = v.yy[k], yz = v.yz[k];
+#pragma unroll
+        for (int r = 0; r < R; r++) sum[r] += expf(mult * sq_dist(ax[r], ay[r], az[r], yx, yy, yz));
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = x0 + r * 256;
+        if (i < v.n) v.den_part[(size_t)chunk * v.n + i] = sum[r];
+    }
+}
+
+// den_x = sum of chunk partials + c; Pt1[x] = 1 - c/den (coherentpointdrift.cpp:204-206); operand of the contraction.
+__global__ __launch_bounds__(256) void cpd_post_den_kernel(CpdView v)
+{
+    if (v.state->done != 0) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= v.n) return;
+    const float c = v.state->constant;
+    float den = 0.f;
+    for (int ch = 0; ch < v.k_chunks; ch++) den += v.den_part[(size_t)ch * v.n + i];
+    den += c;
+    const float w = 1.0f / den;
+    v.pt1[i] = 1.0f - c / den;
+    v.xw4[i] = make_float4(v.ax[i] * w, v.ay[i] * w, v.az[i] * w, w);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K7b: contraction.  grid = k_blocks * x_chunks, lane owns R moving points, x (and its weights) broadcast from SGPRs.
+// VALU form: 4 fused-free multiply-adds per pair on the vector pipe.
+// ---------------------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void cpd_contract_kernel(CpdView v)
+{
+    if (v.state->done != 0) return;
+    const int chunk = blockIdx.x % v.x_chunks;
+    const int kblk = blockIdx.x / v.x_chunks;
+    const int k0 = kblk * (256 * R) + threadIdx.x;
+    const float mult = -0.5f / v.state->sigma2;
+    float yx[R], yy[R], yz[R], p1[R], pxx[R], pxy[R], pxz[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int k = min(k0 + r * 256, v.m - 1);
+        yx[r] = v.yx[k]; yy[r] = v.yy[k]; yz[r] = v.yz[k];
+        p1[r] = pxx[r] = pxy[r] = pxz[r] = 0.f;
+    }
+    const int x_begin = chunk * v.x_chunk_len;
+    const int x_end = min(x_begin + v.x_chunk_len, v.n);
+    for (int x = x_begin; x < x_end; x++) {
+        const float ax = v.ax[x], ay = v.ay[x], az = v.az[x];     // wave-uniform -> scalar loads
+        const float4 w = v.xw4[x];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float p = expf(mult * sq_dist(ax, ay, az, yx[r], yy[r], yz[r]));
+            p1[r] += p * w.w;            // p1(k) += p/den          coherentpointdrift.cpp:210-211
+            pxx[r] += p * w.x;           // px.row(k) += x * p/den  :212
+            pxy[r] += p * w.y;
+            pxz[r] += p * w.z;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int k = k0 + r * 256;
+        if (k < v.m) {
+            v.p1_part[(size_t)chunk * v.m + k] = p1[r];
+            float* px = v.px_part + (size_t)chunk * 3 * v.m;
+            px[k] = pxx[r]; px[v.m + k] = pxy[r]; px[2 * (size_t)v.m + k] = pxz[r];
+        }
+    }
+}
+
+// MFMA form of K7b: one wave = 64 moving points (lane l <-> k0 + l).  Per fixed point x the VALU computes the 64 affinities
+// p_l and ONE v_mfma_f32_4x4x1_16b_f32 applies the rank-1 update of the 64x4 accumulator [PX | P1] on the matrix pipe:
+// block b = l/4 holds rows 4b..4b+3; A[i][b] = p of lane 4b+i, B[b][j] = (w x, w y, w z, w)[j] replicated over blocks, so
+// D_b[i][j] += p_{4b+i} * wx4[j].  The result is bit-for-bit an fp32 fma chain over x (ISA: one rounding per product).
+// The B operand comes from a per-x 16-byte record expanded over lanes by a lane-indexed load (lane l reads word l&3).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void cpd_contract_mfma_kernel(CpdView v)
+{
+    if (v.state->done != 0) return;
+    const int chunk = blockIdx.x % v.x_chunks;
+    const int kblk = blockIdx.x / v.x_chunks;
+    const int k = kblk * 256 + threadIdx.x;
+    const int kc = min(k, v.m - 1);
+    const float mult = -0.5f / v.state->sigma2;
+    const float yx = v.yx[kc], yy = v.yy[kc], yz = v.yz[kc];
+    const int lane = threadIdx.x & 63;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int x_begin = chunk * v.x_chunk_len;
+    const int x_end = min(x_begin + v.x_chunk_len, v.n);
+    const float* __restrict__ wrec = reinterpret_cast<const float*>(v.xw4);
+    for (int x = x_begin; x < x_end; x++) {
+        const float ax = v.ax[x], ay = v.ay[x], az = v.az[x];
+        const float p = expf(mult * sq_dist(ax, ay, az, yx, yy, yz));
+        const float b = wrec[4 * (size_t)x + (lane & 3)];
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(p, b, acc, 0, 0, 0);
+    }
+    // D layout of the 4x4x1 form: lane l holds column j = l & 3 of block l >> 2, register i = row i of that block, i.e.
+    // acc[i] = D[k = 4*(l>>2) + i][j = l&3].  Scatter to the chunk partial arrays (j = 3 is P1, j = 0..2 is PX).
+    const int kbase = kblk * 256 + (threadIdx.x & ~63) + 4 * (lane >> 2);
+    const int j = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int kk = kbase + i;
+        if (kk < v.m) {
+            if (j == 3) v.p1_part[(size_t)chunk * v.m + kk] = acc[i];
+            else v.px_part[(size_t)chunk * 3 * v.m + (size_t)j * v.m + kk] = acc[i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cpd_post_contract_kernel(CpdView v)
+{
+    if (v.state->done != 0) return;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= v.m) return;
+    float p1 = 0.f, x = 0.f, y = 0.f, z = 0.f;
+    for (int ch = 0; ch < v.x_chunks; ch++) {
+        p1 += v.p1_part[(size_t)ch * v.m + k];
+        const float* px = v.px_part + (size_t)ch * 3 * v.m;
+        x += px[k]; y += px[v.m + k]; z += px[2 * (size_t)v.m + k];
+    }
+    v.p1[k] = p1;
+    v.px[3 * (size_t)k] = x; v.px[3 * (size_t)k + 1] = y; v.px[3 * (size_t)k + 2] = z;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K8: M-step moments (fp64) and solve
+// xs = { sum log den, sum pt1*a (3), sum pt1*|a|^2 };  den = c / (1 - pt1) is not recomputed: log den = -log w
+// ks = { Np, sum p1*b (3), sum b_r*px_c (9), sum p1*|b|^2 }
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cpd_xsums_kernel(CpdView v, double* __restrict__ partials, int with_log)
+{
+    if (v.state->done != 0) return;
+    double acc[CPD_XSUMS] = {0};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n; i += gridDim.x * 256) {
+        const float pt1 = v.pt1[i];
+        const float x = v.ax[i], y = v.ay[i], z = v.az[i];
+        if (with_log) acc[0] += (double)logf(1.0f / v.xw4[i].w);      // error -= log(denominator), :215
+        acc[1] += (double)x * pt1; acc[2] += (double)y * pt1; acc[3] += (double)z * pt1;
+        acc[4] += (double)(x * x) * pt1 + (double)(y * y) * pt1 + (double)(z * z) * pt1;     // :257
+    }
+    block_sum_store<CPD_XSUMS>(acc, partials + (size_t)blockIdx.x * CPD_XSUMS);
+}
+
+__global__ __launch_bounds__(256) void cpd_ksums_kernel(CpdView v, double* __restrict__ partials)
+{
+    if (v.state->done != 0) return;
+    double acc[CPD_KSUMS] = {0};
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < v.m; k += gridDim.x * 256) {
+        const float p1 = v.p1[k];
+        const float b[3] = {v.bx[k], v.by[k], v.bz[k]};
+        const float px[3] = {v.px[3 * (size_t)k], v.px[3 * (size_t)k + 1], v.px[3 * (size_t)k + 2]};
+        acc[0] += (double)p1;
+        for (int r = 0; r < 3; r++) {
+            acc[1 + r] += (double)b[r] * p1;
+            for (int c = 0; c < 3; c++) acc[4 + 3 * r + c] += (double)b[r] * px[c];
+            acc[13] += (double)(b[r] * b[r]) * p1;                                            // :259
+        }
+    }
+    block_sum_store<CPD_KSUMS>(acc, partials + (size_t)blockIdx.x * CPD_KSUMS);
+}
+
+__global__ __launch_bounds__(256) void cpd_solve_kernel(CpdState* __restrict__ st, const double* __restrict__ xpart, int nxb,
+                                                        const double* __restrict__ kpart, int nkb, CpdRules rules, int update_loop_state)
+{
+    if (st->done != 0) return;
+    __shared__ double lds[256];
+    double xs[CPD_XSUMS], ks[CPD_KSUMS];
+    reduce_partials<CPD_XSUMS>(xpart, nxb, xs, lds);
+    reduce_partials<CPD_KSUMS>(kpart, nkb, ks, lds);
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < CPD_XSUMS; i++) st->xs[i] = xs[i];
+    for (int i = 0; i < CPD_KSUMS; i++) st->ks[i] = ks[i];
+
+    float sigma2 = st->sigma2;
+    if (update_loop_state) {
+        // error = -sum log den + DIMENSION*N*log(sigma2)/2   coherentpointdrift.cpp:215-217
+        const float L = (float)(-xs[0]) + (float)(3 * rules.n) * logf(sigma2) / 2.0f;
+        st->ntol = fabsf((L - st->l_prev) / L);        // :114
+        st->l_prev = L;
+        st->L = L;
+    }
+    // ---- MStep, coherentpointdrift.cpp:223-277
+    const float Np = (float)ks[0];
+    const float InvertedNp = 1.0f / Np;
+    float cb[3], ca[3];
+    for (int d = 0; d < 3; d++) {
+        cb[d] = (float)((double)InvertedNp * ks[1 + d]);      // InvertedNp * EigenBefore * p1
+        ca[d] = (float)((double)InvertedNp * xs[1 + d]);      // InvertedNp * EigenAfter * pt1
+    }
+    Mat3 A;   // (EigenBefore * px)^T - Np * centerAfter * centerBefore^T
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) A.a[r][c] = (float)ks[4 + 3 * c + r] - Np * (ca[r] * cb[c]);
+    const Kabsch3 kb = kabsch_rotation(A);
+    const float scaleNumerator = (kb.S[0] + kb.S[1]) + kb.S[2] * kb.det;
+    const float sigmaSubtrahend = (float)xs[4] - Np * ((ca[0] * ca[0] + ca[1] * ca[1]) + ca[2] * ca[2]);
+    const float scaleDenominator = (float)ks[13] - Np * ((cb[0] * cb[0] + cb[1] * cb[1]) + cb[2] * cb[2]);
+    float scale = st->scale;
+    if (!rules.const_scale) {
+        scale = scaleNumerator / scaleDenominator;
+        sigma2 = (InvertedNp * fabsf(sigmaSubtrahend - scale * scaleNumerator)) / 3.f;
+    } else {
+        sigma2 = (InvertedNp * fabsf(sigmaSubtrahend + scaleDenominator - 2 * scaleNumerator)) / 3.f;
+    }
+    for (int i = 0; i < 3; i++) {
+        const float rc = ((kb.R.a[i][0] * scale) * cb[0] + (kb.R.a[i][1] * scale) * cb[1]) + (kb.R.a[i][2] * scale) * cb[2];
+        st->t[i] = ca[i] - rc;
+    }
+    for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) st->R[3 * c + r] = kb.R.a[r][c];
+    st->scale = scale;
+    st->sigma2 = sigma2;
+    st->Np = Np;
+    if (update_loop_state) {
+        st->error = sigma2;                            // :121
+        st->iterations += 1;
+        // while (iterations < maxIterations && ntol > tolerance && sigmaSquared > eps)   :106
+        if (!(st->iterations < rules.max_iterations)) { st->done = 1; st->stop_reason = MI_STOP_MAX_ITERATIONS_; }
+        else if (!(st->ntol > rules.tolerance)) { st->done = 1; st->stop_reason = MI_STOP_TOLERANCE_; }
+        else if (!(sigma2 > rules.eps)) { st->done = 1; st->stop_reason = MI_STOP_SIGMA_; }
+    }
+}
+
+// y = scale * (R * b) + t   (TransformPoint with scale, common.cpp:51-55; glm operation order).  Runs even on the
+// stopping iteration (the reference transforms before re-testing the loop condition), hence no `done` check.
+__global__ __launch_bounds__(256) void cpd_transform_kernel(CpdView v, int m_pad)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m_pad) return;
+    const CpdState* st = v.state;
+    const float s = st->scale;
+    const float x = v.bx[i], y = v.by[i], z = v.bz[i];
+    v.yx[i] = s * ((st->R[0] * x + st->R[3] * y) + st->R[6] * z) + st->t[0];
+    v.yy[i] = s * ((st->R[1] * x + st->R[4] * y) + st->R[7] * z) + st->t[1];
+    v.yz[i] = s * ((st->R[2] * x + st->R[5] * y) + st->R[8] * z) + st->t[2];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CPD_R = 2;
+
+hipError_t cpd_init_sums(const CpdView& v, double* partials, int nblocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(cpd_init_sums_kernel, dim3(nblocks), dim3(256), 0, s, v, partials);
+    return hipGetLastError();
+}
+
+hipError_t cpd_init_state(CpdState* state, const double* partials, int nblocks, const CpdRules& rules, float sigma2_override, hipStream_t s)
+{
+    hipLaunchKernelGGL(cpd_init_state_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks, rules, sigma2_override);
+    return hipGetLastError();
+}
+
+hipError_t cpd_denominators(const CpdView& v, hipStream_t s)
+{
+    const int xblocks = (v.n + 256 * CPD_R - 1) / (256 * CPD_R);
+    hipLaunchKernelGGL(cpd_denominator_kernel<CPD_R>, dim3(xblocks * v.k_chunks), dim3(256), 0, s, v);
+    return hipGetLastError();
+}
+
+hipError_t cpd_post_denominators(const CpdView& v, hipStream_t s)
+{
+    hipLaunchKernelGGL(cpd_post_den_kernel, dim3((v.n + 255) / 256), dim3(256), 0, s, v);
+    return hipGetLastError();
+}
+
+hipError_t cpd_contract(const CpdView& v, int use_mfma, hipStream_t s)
+{
+    if (use_mfma) {
+        const int kblocks = (v.m + 255) / 256;
+        hipLaunchKernelGGL(cpd_contract_mfma_kernel, dim3(kblocks * v.x_chunks), dim3(256), 0, s, v);
+    } else {
+        const int kblocks = (v.m + 256 * CPD_R - 1) / (256 * CPD_R);
+        hipLaunchKernelGGL(cpd_contract_kernel<CPD_R>, dim3(kblocks * v.x_chunks), dim3(256), 0, s, v);
+    }
+    return hipGetLastError();
+}
+
+hipError_t cpd_post_contract(const CpdView& v, hipStream_t s)
+{
+    hipLaunchKernelGGL(cpd_post_contract_kernel, dim3((v.m + 255) / 256), dim3(256), 0, s, v);
+    return hipGetLastError();
+}
+
+hipError_t cpd_xsums(const CpdView& v, double* partials, int nblocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(cpd_xsums_kernel, dim3(nblocks), dim3(256), 0, s, v, partials, v.xw4 != nullptr ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t cpd_ksums(const CpdView& v, double* partials, int nblocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(cpd_ksums_kernel, dim3(nblocks), dim3(256), 0, s, v, partials);
+    return hipGetLastError();
+}
+
+hipError_t cpd_solve(CpdState* state, const double* xpart, int nxb, const double* kpart, int nkb, const CpdRules& rules,
+                     int update_loop_state, hipStream_t s)
+{
+    hipLaunchKernelGGL(cpd_solve_kernel, dim3(1), dim3(256), 0, s, state, xpart, nxb, kpart, nkb, rules, update_loop_state);
+    return hipGetLastError();
+}
+
+hipError_t cpd_transform(const CpdView& v, int m_pad, hipStream_t s)
+{
+    hipLaunchKernelGGL(cpd_transform_kernel, dim3((m_pad + 255) / 256), dim3(256), 0, s, v, m_pad);
+    return hipGetLastError();
+}
+
+}  // namespace mislam

@@ -1,0 +1,382 @@
+// K2-K6 -- everything of an ICP iteration that is not the nearest-neighbour search, for gfx950.
+//
+// One reference iteration (source/cuda-slam/icpcuda.cu:31-54) is ~10 thrust/cuBLAS/cuSOLVER passes over N-sized arrays
+// with >= 10 host round trips.  Here it is four small kernels on one stream with NO host round trip:
+//
+//   K2  icp_moments_kernel          gather after[idx[i]] + count, sum b, sum a, sum a b^T in fp64 (one pass, nothing
+//                                   materialised: replaces CalculateCentroid x4, GetAlignedCloud x2, the permutation
+//                                   gather, GlmToCuBlas x2 and cublasSgemm of cudacommon.cu:168-201)
+//   K3  icp_solve_kernel            fixed-order reduction of the block partials, 3x3 Jacobi SVD + Kabsch on one lane,
+//                                   composition into the running transform (replaces cusolverDnSgesvd + 7 memcpys +
+//                                   host glm code, cudacommon.cu:203-253, icpcuda.cu:35)
+//   K4+K5 icp_transform_error_kernel  cur = R*before + t (TransformCloud, cudacommon.cu:132-136) fused with the squared
+//                                   error against the correspondences found BEFORE the update (GetMeanSquaredError,
+//                                   cudacommon.cu:138-148) and with re-arming the packed keys for the next search
+//   K6  icp_finalize_kernel         error reduction + the stop rules of basicicp.cpp:52-57 / icpcuda.cu:40-53, evaluated
+//                                   on the device: every kernel of later iterations returns at once when `done` is set.
+//
+// Reductions are two-stage with a fixed summation order (per-block partials, then one workgroup), so results are
+// bitwise reproducible run to run; there are no float atomics.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "reduce.hpp"
+#include "svd3.hpp"
+
+namespace mislam {
+
+__global__ __launch_bounds__(256) void fill_keys_kernel(unsigned long long* __restrict__ keys, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = KEY_INIT;
+}
+
+// AoS xyz (12 B/point, the reference's host layout) -> SoA x[], y[], z[] (+ optional float4 copy for gathers).
+// Entries [n, n_pad) replicate point n-1 (see K1's padding rule).
+__global__ __launch_bounds__(256) void aos_to_soa_kernel(const float* __restrict__ aos, int n, int n_pad, float* __restrict__ x,
+                                                         float* __restrict__ y, float* __restrict__ z, float4* __restrict__ packed)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pad) return;
+    const int s = i < n ? i : n - 1;
+    const float px = aos[3 * (size_t)s], py = aos[3 * (size_t)s + 1], pz = aos[3 * (size_t)s + 2];
+    x[i] = px; y[i] = py; z[i] = pz;
+    if (packed != nullptr) packed[i] = make_float4(px, py, pz, 0.f);
+}
+
+__global__ __launch_bounds__(256) void soa_to_aos_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ z, int n, float* __restrict__ aos)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    aos[3 * (size_t)i] = x[i]; aos[3 * (size_t)i + 1] = y[i]; aos[3 * (size_t)i + 2] = z[i];
+}
+
+// keys -> idx[], d2[] (test-grade mi_nn_search output)
+__global__ __launch_bounds__(256) void unpack_keys_kernel(const unsigned long long* __restrict__ keys, int n, int* __restrict__ idx,
+                                                          float* __restrict__ d2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    idx[i] = (int)(unsigned int)(k & 0xffffffffull);
+    if (d2 != nullptr) d2[i] = __uint_as_float((unsigned int)(k >> 32));
+}
+
+// idx[] (+ optional keep mask) -> keys with d2 = 0 for kept pairs and +inf for dropped ones, so the ICP kernels can be
+// driven from caller-supplied correspondences (mi_kabsch / mi_transform_mse).
+__global__ __launch_bounds__(256) void pack_keys_kernel(const int* __restrict__ idx, const unsigned char* __restrict__ keep, int n,
+                                                        unsigned long long* __restrict__ keys)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bool k = keep == nullptr || keep[i] != 0;
+    const unsigned int hi = k ? 0u : 0x7f800000u;
+    keys[i] = ((unsigned long long)hi << 32) | (unsigned int)idx[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2: fused moments.  acc = { count, sum b (3), sum a (3), sum a_r b_c (9, row-major in r) }
+// A pair is used when its winner lies in this device's target shard [shard_lo, shard_hi) -- so in the multi-GPU path
+// every pair is accumulated by exactly one rank, the one that owns the target's coordinates -- and, with filter_pairs,
+// when d2 < max_distance_squared (common.cpp:490).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void icp_moments_kernel(IcpView v, double* __restrict__ partials)
+{
+    if (v.state->done != 0) return;
+    double acc[ICP_MOMENTS] = {0};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n; i += gridDim.x * 256) {
+        const unsigned long long key = v.keys[i];
+        const int gidx = (int)(unsigned int)(key & 0xffffffffull);
+        const float d2 = __uint_as_float((unsigned int)(key >> 32));
+        const bool mine = gidx >= v.shard_lo && gidx < v.shard_hi;
+        const bool kept = v.filter_pairs ? (d2 < v.max_distance_squared) : true;
+        if (mine && kept) {
+            const float4 a = v.tgt4[gidx - v.shard_lo];
+            const double bx = v.cx[i], by = v.cy[i], bz = v.cz[i];
+            const double ax = a.x, ay = a.y, az = a.z;
+            acc[0] += 1.0;
+            acc[1] += bx; acc[2] += by; acc[3] += bz;
+            acc[4] += ax; acc[5] += ay; acc[6] += az;
+            acc[7] += ax * bx;  acc[8] += ax * by;  acc[9] += ax * bz;
+            acc[10] += ay * bx; acc[11] += ay * by; acc[12] += ay * bz;
+            acc[13] += az * bx; acc[14] += az * by; acc[15] += az * bz;
+        }
+    }
+    block_sum_store<ICP_MOMENTS>(acc, partials + (size_t)blockIdx.x * ICP_MOMENTS);
+}
+
+// Reduce block partials into the state (multi-GPU path: the result is then all-reduced before the solve).
+__global__ __launch_bounds__(256) void icp_reduce_moments_kernel(IcpState* __restrict__ state, const double* __restrict__ partials, int nblocks)
+{
+    if (state->done != 0) return;
+    __shared__ double lds[256];
+    double mom[ICP_MOMENTS];
+    reduce_partials<ICP_MOMENTS>(partials, nblocks, mom, lds);
+    if (threadIdx.x < ICP_MOMENTS) state->mom[threadIdx.x] = mom[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void icp_reduce_error_kernel(IcpState* __restrict__ state, const double* __restrict__ partials, int nblocks)
+{
+    if (state->done != 0) return;
+    __shared__ double lds[256];
+    double e[ICP_ERRSUMS];
+    reduce_partials<ICP_ERRSUMS>(partials, nblocks, e, lds);
+    if (threadIdx.x < ICP_ERRSUMS) state->err[threadIdx.x] = e[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K3: solve + compose (one lane).  partials == nullptr: the moments are already in state->mom (multi-GPU path).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ void solve_from_moments(const double* mom, float Ri[9], float ti[3])
+{
+    const double n = mom[0];
+    const double cbx = mom[1] / n, cby = mom[2] / n, cbz = mom[3] / n;
+    const double cax = mom[4] / n, cay = mom[5] / n, caz = mom[6] / n;
+    const double ca[3] = {cax, cay, caz}, cb[3] = {cbx, cby, cbz};
+    // H = sum (a - ca)(b - cb)^T = sum a b^T - n ca cb^T   (alignedAfter * alignedBefore^T, common.cpp:530)
+    Mat3 H;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) H.a[r][c] = (float)(mom[7 + 3 * r + c] - n * ca[r] * cb[c]);
+    const Kabsch3 k = kabsch_rotation(H);
+    // column-major like glm::mat3 (ConvertRotationMatrix, common.cpp:335-346)
+    for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) Ri[3 * c + r] = k.R.a[r][c];
+    const float fcb[3] = {(float)cbx, (float)cby, (float)cbz};
+    const float fca[3] = {(float)cax, (float)cay, (float)caz};
+    // t = centroidAfter - R * centroidBefore (common.cpp:549), glm mat3*vec3 operation order
+    for (int i = 0; i < 3; i++) ti[i] = fca[i] - ((Ri[i] * fcb[0] + Ri[3 + i] * fcb[1]) + Ri[6 + i] * fcb[2]);
+}
+
+// glm mat3 * mat3, column-major operands (include/glm/detail/type_mat3x3.inl operator*)
+__device__ void mat3_mul_cm(const float a[9], const float b[9], float out[9])
+{
+    float r[9];
+    for (int c = 0; c < 3; c++)
+        for (int rr = 0; rr < 3; rr++) r[3 * c + rr] = (a[rr] * b[3 * c] + a[3 + rr] * b[3 * c + 1]) + a[6 + rr] * b[3 * c + 2];
+    for (int i = 0; i < 9; i++) out[i] = r[i];
+}
+
+__global__ __launch_bounds__(256) void icp_solve_kernel(IcpState* __restrict__ state, const double* __restrict__ partials, int nblocks,
+                                                        int compose_mode)
+{
+    if (state->done != 0) return;
+    __shared__ double lds[256];
+    double mom[ICP_MOMENTS];
+    if (partials != nullptr) {
+        reduce_partials<ICP_MOMENTS>(partials, nblocks, mom, lds);
+    } else {
+#pragma unroll
+        for (int i = 0; i < ICP_MOMENTS; i++) mom[i] = state->mom[i];
+    }
+    if (threadIdx.x != 0) return;
+    if (partials != nullptr)
+        for (int i = 0; i < ICP_MOMENTS; i++) state->mom[i] = mom[i];
+    state->pairs = (int)mom[0];
+    if (mom[0] <= 0.0) {   // "if (correspondingPoints.size() == 0) break;"  basicicp.cpp:36
+        state->done = 1;
+        state->stop_reason = MI_STOP_NO_PAIRS_;
+        return;
+    }
+    float Ri[9], ti[3];
+    solve_from_moments(mom, Ri, ti);
+    for (int i = 0; i < 9; i++) state->Ri[i] = Ri[i];
+    for (int i = 0; i < 3; i++) state->ti[i] = ti[i];
+    float R[9], t[3];
+    for (int i = 0; i < 9; i++) R[i] = state->R[i];
+    for (int i = 0; i < 3; i++) t[i] = state->t[i];
+    if (compose_mode == 0) {
+        // rotationMatrix = Ri * rotationMatrix; translationVector = ti + translationVector  (basicicp.cpp:43-44)
+        mat3_mul_cm(Ri, R, R);
+        for (int i = 0; i < 3; i++) t[i] = ti[i] + t[i];
+    } else {
+        // transformationMatrix = Ti * transformationMatrix  (icpcuda.cu:35)
+        float nt[3];
+        for (int i = 0; i < 3; i++) nt[i] = ((Ri[i] * t[0] + Ri[3 + i] * t[1]) + Ri[6 + i] * t[2]) + ti[i];
+        mat3_mul_cm(Ri, R, R);
+        for (int i = 0; i < 3; i++) t[i] = nt[i];
+    }
+    for (int i = 0; i < 9; i++) state->R[i] = R[i];
+    for (int i = 0; i < 3; i++) state->t[i] = t[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K4+K5: cur = R*before + t for ALL n_pad entries (padding stays a copy of a real point), squared error of the kept pairs
+// against the OLD correspondences (basicicp.cpp:48, icpcuda.cu:38), keys re-armed for the next search.
+// err partial = { sum |a - cur|^2, kept pairs }
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void icp_transform_error_kernel(IcpView v, double* __restrict__ partials, int rearm)
+{
+    if (v.state->done != 0) return;
+    float R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = v.state->R[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) t[i] = v.state->t[i];
+    double acc[ICP_ERRSUMS] = {0};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n_pad; i += gridDim.x * 256) {
+        const float x = v.bx[i], y = v.by[i], z = v.bz[i];
+        // TransformPoint: (rotationMatrix * point) + translationVector  (common.cpp:45-49), glm operation order
+        const float ox = ((R[0] * x + R[3] * y) + R[6] * z) + t[0];
+        const float oy = ((R[1] * x + R[4] * y) + R[7] * z) + t[1];
+        const float oz = ((R[2] * x + R[5] * y) + R[8] * z) + t[2];
+        v.cx[i] = ox; v.cy[i] = oy; v.cz[i] = oz;
+        if (i < v.n) {
+            const unsigned long long key = v.keys[i];
+            const int gidx = (int)(unsigned int)(key & 0xffffffffull);
+            const float d2 = __uint_as_float((unsigned int)(key >> 32));
+            const bool mine = gidx >= v.shard_lo && gidx < v.shard_hi;
+            const bool kept = v.filter_pairs ? (d2 < v.max_distance_squared) : true;
+            unsigned long long next_key = KEY_INIT;
+            if (mine) {
+                const float4 a = v.tgt4[gidx - v.shard_lo];
+                const float dx = a.x - ox, dy = a.y - oy, dz = a.z - oz;
+                const float e = (dx * dx + dy * dy) + dz * dz;       // diff.LengthSquared(), common.cpp:264-265
+                if (kept) {
+                    acc[0] += (double)e;
+                    acc[1] += 1.0;
+                }
+                // The old match under the new transform is a real candidate of the next search, evaluated with the
+                // search's own arithmetic, so its key is a valid starting bound for K1.
+                const float c = v.fma ? __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) : e;
+                next_key = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned int)gidx;
+            }
+            if (rearm == 1) v.keys[i] = KEY_INIT;
+            else if (rearm == 2) v.keys[i] = next_key;
+        }
+    }
+    block_sum_store<ICP_ERRSUMS>(acc, partials + (size_t)blockIdx.x * ICP_ERRSUMS);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K6: error + stop rules.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void icp_finalize_kernel(IcpState* __restrict__ state, const double* __restrict__ partials, int nblocks,
+                                                           IcpRules rules)
+{
+    if (state->done != 0) return;
+    __shared__ double lds[256];
+    double e[ICP_ERRSUMS];
+    if (partials != nullptr) {
+        reduce_partials<ICP_ERRSUMS>(partials, nblocks, e, lds);
+    } else {
+        e[0] = state->err[0];
+        e[1] = state->err[1];
+    }
+    if (threadIdx.x != 0) return;
+    state->err[0] = e[0];
+    state->err[1] = e[1];
+    // cpu-slam: mean over the surviving pairs (common.cpp:267); cuda-slam: sum / after.size() (cudacommon.cu:147)
+    const double denom = rules.filter_pairs ? e[1] : (double)rules.m_total;
+    const float error = (float)(e[0] / denom);
+    state->error = error;
+    state->passes += 1;
+    if (error < rules.eps) {                                       // basicicp.cpp:52 / icpcuda.cu:40
+        state->done = 1;
+        state->stop_reason = MI_STOP_CONVERGED_;
+        return;
+    }
+    if (rules.abort_on_increase && error > state->prev_error) {    // icpcuda.cu:43-49
+        for (int i = 0; i < 9; i++) state->R[i] = state->prevR[i];
+        for (int i = 0; i < 3; i++) state->t[i] = state->prevT[i];
+        state->error = state->prev_error;
+        state->done = 1;
+        state->stop_reason = MI_STOP_ERROR_INCREASED_;
+        return;
+    }
+    for (int i = 0; i < 9; i++) state->prevR[i] = state->R[i];
+    for (int i = 0; i < 3; i++) state->prevT[i] = state->t[i];
+    state->prev_error = error;
+    state->iterations += 1;                                        // basicicp.cpp:57
+    if (rules.max_iterations != -1 && state->iterations >= rules.max_iterations) {
+        state->done = 1;
+        state->stop_reason = MI_STOP_MAX_ITERATIONS_;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------------------------
+static inline int blocks_for(int n, int cap)
+{
+    int b = (n + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return b;
+}
+
+hipError_t fill_keys(unsigned long long* keys, int n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, keys, n);
+    return hipGetLastError();
+}
+
+hipError_t aos_to_soa(const float* aos, int n, int n_pad, float* x, float* y, float* z, float4* packed, hipStream_t s)
+{
+    if (n_pad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aos_to_soa_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, s, aos, n, n_pad, x, y, z, packed);
+    return hipGetLastError();
+}
+
+hipError_t soa_to_aos(const float* x, const float* y, const float* z, int n, float* aos, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(soa_to_aos_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, aos);
+    return hipGetLastError();
+}
+
+hipError_t unpack_keys(const unsigned long long* keys, int n, int* idx, float* d2, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, idx, d2);
+    return hipGetLastError();
+}
+
+hipError_t pack_keys(const int* idx, const unsigned char* keep, int n, unsigned long long* keys, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, idx, keep, n, keys);
+    return hipGetLastError();
+}
+
+int icp_reduce_blocks(int n) { return blocks_for(n, ICP_MAX_PARTIAL_BLOCKS); }
+
+hipError_t icp_moments(const IcpView& v, double* partials, int nblocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(icp_moments_kernel, dim3(nblocks), dim3(256), 0, s, v, partials);
+    return hipGetLastError();
+}
+
+hipError_t icp_reduce_moments(IcpState* state, const double* partials, int nblocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(icp_reduce_moments_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks);
+    return hipGetLastError();
+}
+
+hipError_t icp_reduce_error(IcpState* state, const double* partials, int nblocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(icp_reduce_error_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks);
+    return hipGetLastError();
+}
+
+hipError_t icp_solve(IcpState* state, const double* partials, int nblocks, int compose_mode, hipStream_t s)
+{
+    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks, compose_mode);
+    return hipGetLastError();
+}
+
+hipError_t icp_transform_error(const IcpView& v, double* partials, int nblocks, int rearm, hipStream_t s)
+{
+    hipLaunchKernelGGL(icp_transform_error_kernel, dim3(nblocks), dim3(256), 0, s, v, partials, rearm);
+    return hipGetLastError();
+}
+
+hipError_t icp_finalize(IcpState* state, const double* partials, int nblocks, const IcpRules& rules, hipStream_t s)
+{
+    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks, rules);
+    return hipGetLastError();
+}
+
+}  // namespace mislam

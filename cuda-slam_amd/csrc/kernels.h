@@ -1,0 +1,97 @@
+// Internal launch interfaces between the C-ABI/driver layer (mislam_api.cpp) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mislam {
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1 nearest-neighbour search (nn_kernel.hip)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int NN_TARGET_BLOCK = 16;       // T: targets per min-only block of K1 (chunk_len and target padding granule)
+constexpr int NN_MAX_R = 8;               // sources per lane
+constexpr int NN_SRC_PAD = 256 * NN_MAX_R;  // source arrays are padded to a multiple of this
+constexpr unsigned long long KEY_INIT = 0xFFFFFFFFFFFFFFFFull;
+
+struct NnLaunch {
+    const float *sx, *sy, *sz;            // sources, SoA, n_pad floats each (n_pad % (256*R) == 0)
+    int n, n_pad;
+    const float *tx, *ty, *tz;            // targets, SoA, >= n_chunks*chunk_len floats each
+    int chunk_len, n_chunks;              // chunk_len % NN_TARGET_BLOCK == 0
+    int index_base;                       // global index of target 0 of this device's shard
+    unsigned long long* keys;             // n packed (d2 bits << 32 | index) keys: KEY_INIT or a REAL candidate's key
+    const int* done_flag;                 // device-side stop flag (may be null)
+    int R;                                // 1, 2, 4 or 8
+    int fma;
+};
+hipError_t nn_launch(const NnLaunch& a, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------------------
+// ICP iteration kernels (icp_kernels.hip)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int ICP_MOMENTS = 16;              // count, sum b (3), sum a (3), sum a b^T (9)
+constexpr int ICP_ERRSUMS = 2;               // sum |a - b'|^2, kept pairs
+constexpr int ICP_MAX_PARTIAL_BLOCKS = 1024;
+
+// mirror of the public MI_STOP_* values (mi_slam.h) for device code
+enum { MI_STOP_RUNNING_ = 0, MI_STOP_CONVERGED_ = 1, MI_STOP_MAX_ITERATIONS_ = 2, MI_STOP_NO_PAIRS_ = 3,
+       MI_STOP_ERROR_INCREASED_ = 4, MI_STOP_TOLERANCE_ = 5, MI_STOP_SIGMA_ = 6 };
+
+// Device-resident loop state.  The host only ever copies it back; every decision is taken on the device.
+struct IcpState {
+    float R[9];              // running rotation, column-major (glm::mat3)
+    float t[3];              // running translation
+    float prevR[9];
+    float prevT[3];
+    float Ri[9];             // last per-iteration solve
+    float ti[3];
+    float error;             // *error of the reference drivers
+    float prev_error;
+    int iterations;          // *iterations of the reference drivers
+    int passes;              // loop bodies executed
+    int done;
+    int stop_reason;
+    int pairs;               // correspondences kept in the last solve (this rank's share in the multi-GPU path)
+    int pad_;
+    double mom[ICP_MOMENTS];
+    double err[ICP_ERRSUMS];
+};
+
+struct IcpView {
+    IcpState* state;
+    const float *bx, *by, *bz;       // original `before`, SoA, n_pad
+    float *cx, *cy, *cz;             // current (transformed) cloud, SoA, n_pad
+    const float4* tgt4;              // this rank's target shard as float4 (gather-friendly), local index
+    unsigned long long* keys;        // n packed keys
+    int n, n_pad;
+    int shard_lo, shard_hi;          // global target index range owned by this rank
+    int filter_pairs;
+    float max_distance_squared;
+    int fma;                         // distance arithmetic used when re-arming keys with the previous match
+};
+
+struct IcpRules {
+    float eps;
+    int max_iterations;
+    int filter_pairs;
+    int abort_on_increase;
+    int m_total;                     // |after| over all ranks
+};
+
+hipError_t fill_keys(unsigned long long* keys, int n, hipStream_t s);
+hipError_t aos_to_soa(const float* aos, int n, int n_pad, float* x, float* y, float* z, float4* packed, hipStream_t s);
+hipError_t soa_to_aos(const float* x, const float* y, const float* z, int n, float* aos, hipStream_t s);
+hipError_t unpack_keys(const unsigned long long* keys, int n, int* idx, float* d2, hipStream_t s);
+hipError_t pack_keys(const int* idx, const unsigned char* keep, int n, unsigned long long* keys, hipStream_t s);
+
+int icp_reduce_blocks(int n);
+hipError_t icp_moments(const IcpView& v, double* partials, int nblocks, hipStream_t s);
+hipError_t icp_reduce_moments(IcpState* state, const double* partials, int nblocks, hipStream_t s);
+hipError_t icp_reduce_error(IcpState* state, const double* partials, int nblocks, hipStream_t s);
+hipError_t icp_solve(IcpState* state, const double* partials, int nblocks, int compose_mode, hipStream_t s);
+// rearm: 0 = leave keys, 1 = KEY_INIT, 2 = the previous match's key under the NEW transform (a real candidate: K1 then
+// starts from a tight bound and hardly ever takes its re-scan path)
+hipError_t icp_transform_error(const IcpView& v, double* partials, int nblocks, int rearm, hipStream_t s);
+hipError_t icp_finalize(IcpState* state, const double* partials, int nblocks, const IcpRules& rules, hipStream_t s);
+
+}  // namespace mislam

@@ -1,0 +1,663 @@
+// C ABI (include/mi_slam.h): context, ICP driver and the test-grade ICP primitives.
+//
+// The ICP driver is the MI355X-native counterpart of CudaICP (source/cuda-slam/icpcuda.cu:8-58): the same loop, but the
+// whole iteration -- search, (all-reduce), moments, solve, transform, error, stop rule -- is enqueued on one HIP stream
+// without a single host round trip; the host only reads the 256-byte state block back every `sync_every` iterations.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "context.h"
+
+using namespace mislam;
+
+// ---------------------------------------------------------------------------------------------------------------
+// error reporting
+// ---------------------------------------------------------------------------------------------------------------
+namespace mislam {
+static thread_local char g_error[512] = "";
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+}
+}  // namespace mislam
+
+extern "C" const char* mi_last_error(void) { return g_error; }
+extern "C" int mi_abi_version(void) { return MI_SLAM_ABI_VERSION; }
+
+extern "C" int mi_device_count(int* count)
+{
+    if (!count) { set_error("mi_device_count: null argument"); return MI_ERR_INVALID_ARG; }
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess || c <= 0) {
+        *count = 0;
+        set_error("no usable HIP device (%s); this library has no CPU fallback", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return MI_ERR_NO_DEVICE;
+    }
+    *count = c;
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------------------
+static int ctx_create_common(int device, mi_ctx** out)
+{
+    if (!out) { set_error("mi_ctx_create: null out pointer"); return MI_ERR_INVALID_ARG; }
+    *out = nullptr;
+    int count = 0;
+    MI_TRY(mi_device_count(&count));
+    if (device < 0 || device >= count) { set_error("mi_ctx_create: device %d out of range [0,%d)", device, count); return MI_ERR_INVALID_ARG; }
+    MI_HIP(hipSetDevice(device));
+    mi_ctx* c = new mi_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    MI_HIP(hipGetDeviceProperties(&prop, device));
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    MI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    MI_HIP(hipMalloc((void**)&c->d_state, sizeof(IcpState)));
+    MI_HIP(hipHostMalloc((void**)&c->h_state, sizeof(IcpState), hipHostMallocDefault));
+    memset(c->h_state, 0, sizeof(IcpState));
+    *out = c;
+    return MI_OK;
+}
+
+extern "C" int mi_ctx_create(int device, mi_ctx** out) { return ctx_create_common(device, out); }
+
+extern "C" int mi_dist_unique_id(void* out_unique_id)
+{
+    if (!out_unique_id) { set_error("mi_dist_unique_id: null argument"); return MI_ERR_INVALID_ARG; }
+    static_assert(sizeof(ncclUniqueId) == MI_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    MI_NCCL(ncclGetUniqueId(&id));
+    memcpy(out_unique_id, &id, sizeof id);
+    return MI_OK;
+}
+
+extern "C" int mi_ctx_create_dist(int device, int rank, int world, const void* unique_id, mi_ctx** out)
+{
+    if (world < 1 || rank < 0 || rank >= world || !unique_id) { set_error("mi_ctx_create_dist: bad rank/world/id"); return MI_ERR_INVALID_ARG; }
+    MI_TRY(ctx_create_common(device, out));
+    mi_ctx* c = *out;
+    c->rank = rank;
+    c->world = world;
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, ncclGetErrorString(r));
+        mi_ctx_destroy(c);
+        *out = nullptr;
+        return MI_ERR_RCCL;
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_ctx_rank(const mi_ctx* ctx, int* rank, int* world)
+{
+    if (!ctx) { set_error("mi_ctx_rank: null context"); return MI_ERR_INVALID_ARG; }
+    if (rank) *rank = ctx->rank;
+    if (world) *world = ctx->world;
+    return MI_OK;
+}
+
+extern "C" int mi_shard_range(int m_total, int rank, int world, int* lo, int* hi)
+{
+    if (m_total < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) { set_error("mi_shard_range: bad arguments"); return MI_ERR_INVALID_ARG; }
+    *lo = (int)((long long)m_total * rank / world);
+    *hi = (int)((long long)m_total * (rank + 1) / world);
+    return MI_OK;
+}
+
+extern "C" unsigned long long mi_pack_key(float d2, int global_index)
+{
+    unsigned int bits;
+    memcpy(&bits, &d2, sizeof bits);
+    return ((unsigned long long)bits << 32) | (unsigned int)global_index;
+}
+
+extern "C" void mi_unpack_key(unsigned long long key, float* d2, int* global_index)
+{
+    const unsigned int bits = (unsigned int)(key >> 32);
+    if (d2) memcpy(d2, &bits, sizeof bits);
+    if (global_index) *global_index = (int)(unsigned int)(key & 0xffffffffull);
+}
+
+namespace mislam { void cpd_workspace_destroy(mi_ctx* ctx); }
+
+extern "C" void mi_ctx_destroy(mi_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    cpd_workspace_destroy(c);
+    c->staging.release();
+    c->bx.release(); c->by.release(); c->bz.release();
+    c->cx.release(); c->cy.release(); c->cz.release();
+    c->tx.release(); c->ty.release(); c->tz.release();
+    c->tgt4.release(); c->keys.release(); c->part_mom.release(); c->part_err.release();
+    c->idx_tmp.release(); c->keep_tmp.release();
+    for (auto& s : c->spans) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->d_state) (void)hipFree(c->d_state);
+    if (c->h_state) (void)hipHostFree(c->h_state);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mi_ctx_synchronize(mi_ctx* c)
+{
+    if (!c) { set_error("mi_ctx_synchronize: null context"); return MI_ERR_INVALID_ARG; }
+    MI_HIP(hipSetDevice(c->device));
+    MI_HIP(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// profiling: HIP events on the context's own stream around each kernel launch
+// ---------------------------------------------------------------------------------------------------------------
+int mi_ctx::prof_begin(int kernel)
+{
+    ProfileSpan s{};
+    s.kernel = kernel;
+    for (hipEvent_t* e : {&s.e0, &s.e1}) {
+        if (!event_pool.empty()) { *e = event_pool.back(); event_pool.pop_back(); }
+        else MI_HIP(hipEventCreate(e));
+    }
+    MI_HIP(hipEventRecord(s.e0, stream));
+    spans.push_back(s);
+    return MI_OK;
+}
+
+int mi_ctx::prof_end()
+{
+    MI_HIP(hipEventRecord(spans.back().e1, stream));
+    return MI_OK;
+}
+
+int mi_ctx::prof_collect()
+{
+    if (spans.empty()) return MI_OK;
+    MI_HIP(hipStreamSynchronize(stream));
+    for (auto& s : spans) {
+        float ms = 0.f;
+        MI_HIP(hipEventElapsedTime(&ms, s.e0, s.e1));
+        prof_ms[s.kernel] += ms;
+        prof_n[s.kernel] += 1;
+        event_pool.push_back(s.e0);
+        event_pool.push_back(s.e1);
+    }
+    spans.clear();
+    return MI_OK;
+}
+
+extern "C" int mi_profile_enable(mi_ctx* c, int enable)
+{
+    if (!c) { set_error("mi_profile_enable: null context"); return MI_ERR_INVALID_ARG; }
+    MI_HIP(hipSetDevice(c->device));
+    MI_TRY(c->prof_collect());
+    c->profile = enable != 0;
+    return MI_OK;
+}
+
+extern "C" int mi_profile_reset(mi_ctx* c)
+{
+    if (!c) { set_error("mi_profile_reset: null context"); return MI_ERR_INVALID_ARG; }
+    MI_HIP(hipSetDevice(c->device));
+    MI_TRY(c->prof_collect());
+    for (int k = 0; k < MI_KERNEL_COUNT; k++) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    return MI_OK;
+}
+
+extern "C" int mi_profile_get(mi_ctx* c, int kernel, double* total_ms, long long* launches)
+{
+    if (!c || kernel < 0 || kernel >= MI_KERNEL_COUNT) { set_error("mi_profile_get: bad argument"); return MI_ERR_INVALID_ARG; }
+    MI_HIP(hipSetDevice(c->device));
+    MI_TRY(c->prof_collect());
+    if (total_ms) *total_ms = c->prof_ms[kernel];
+    if (launches) *launches = c->prof_n[kernel];
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// shared helpers
+// ---------------------------------------------------------------------------------------------------------------
+namespace mislam {
+
+static int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+static inline int round_up(int v, int g) { return (v + g - 1) / g * g; }
+
+constexpr int NN_MAX_CHUNKS = 1024;
+
+size_t target_alloc_len(int m_local)
+{
+    // any chunking with <= NN_MAX_CHUNKS chunks of T-aligned length stays inside this allocation
+    return (size_t)round_up(std::max(m_local, 1), NN_TARGET_BLOCK) + (size_t)NN_TARGET_BLOCK * NN_MAX_CHUNKS;
+}
+
+// 2-D decomposition of the (source, target) pair space for K1.  Few chunks = few re-scan restarts and few atomics;
+// enough workgroups = every CU busy with a short tail.  Measured on MI355X (profiles/r01_nn_microbench.log): R = 2 with
+// the smallest chunk count that still yields >= ~8 workgroups per CU is the fastest configuration at every size.
+NnPlan plan_nn(const mi_ctx* ctx, int n, int m_local)
+{
+    NnPlan p;
+    p.R = env_int("MISLAM_NN_R", 2);
+    if (p.R != 1 && p.R != 2 && p.R != 4 && p.R != 8) p.R = 2;
+    const int n_src_blocks = round_up(std::max(n, 1), 256 * p.R) / (256 * p.R);
+    const int target_wgs = env_int("MISLAM_NN_WGS", ctx->cu_count * 8);
+    int chunks = (target_wgs + n_src_blocks - 1) / n_src_blocks;
+    const int max_chunks = std::max(1, std::min(NN_MAX_CHUNKS, m_local / (NN_TARGET_BLOCK * 4)));
+    chunks = std::max(1, std::min(chunks, max_chunks));
+    if (chunks > 8) chunks = std::min(round_up(chunks, 8), std::max(8, max_chunks / 8 * 8));
+    const int forced = env_int("MISLAM_NN_CHUNKS", 0);
+    if (forced > 0) chunks = std::min(forced, NN_MAX_CHUNKS);
+    p.chunk_len = round_up((std::max(m_local, 1) + chunks - 1) / chunks, NN_TARGET_BLOCK);
+    p.n_chunks = (std::max(m_local, 1) + p.chunk_len - 1) / p.chunk_len;
+    return p;
+}
+
+int upload_soa(mi_ctx* c, const float* host_aos, int n, int n_pad, float* x, float* y, float* z, float4* packed)
+{
+    MI_TRY(c->staging.reserve((size_t)3 * n));
+    MI_HIP(hipMemcpyAsync(c->staging.p, host_aos, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    MI_HIP(aos_to_soa(c->staging.p, n, n_pad, x, y, z, packed, c->stream));
+    // the staging buffer is reused by the next upload: keep stream order, and a pageable-memory copy is already
+    // synchronous with respect to the host buffer
+    return MI_OK;
+}
+
+static int launch_nn(mi_ctx* c, const float* sx, const float* sy, const float* sz, int n, int m_local, int index_base, int fma,
+                     const int* done_flag)
+{
+    const NnPlan p = plan_nn(c, n, m_local);
+    NnLaunch a{};
+    a.sx = sx; a.sy = sy; a.sz = sz;
+    a.n = n; a.n_pad = round_up(n, 256 * p.R);
+    a.tx = c->tx.p; a.ty = c->ty.p; a.tz = c->tz.p;
+    a.chunk_len = p.chunk_len; a.n_chunks = p.n_chunks;
+    a.index_base = index_base;
+    a.keys = c->keys.p;
+    a.done_flag = done_flag;
+    a.R = p.R;
+    a.fma = fma;
+    // host-side shape checks before a hand-written kernel runs (a fault can reset the whole node)
+    if ((size_t)a.n_pad > c->cx.cap && sx == c->cx.p) { set_error("internal: source padding exceeds allocation"); return MI_ERR_STATE; }
+    if ((size_t)a.n_chunks * a.chunk_len > c->tx.cap) { set_error("internal: target chunking exceeds allocation"); return MI_ERR_STATE; }
+    if (a.chunk_len % NN_TARGET_BLOCK != 0) { set_error("internal: chunk_len not a multiple of the target block"); return MI_ERR_STATE; }
+    ProfScope ps(c, MI_KERNEL_NN);
+    MI_HIP(nn_launch(a, c->stream));
+    return MI_OK;
+}
+
+static int allreduce_keys(mi_ctx* c, int n)
+{
+    if (!c->comm) return MI_OK;
+    ProfScope ps(c, MI_KERNEL_ALLREDUCE);
+    MI_NCCL(ncclAllReduce(c->keys.p, c->keys.p, (size_t)n, ncclUint64, ncclMin, c->comm, c->stream));
+    return MI_OK;
+}
+
+static int allreduce_doubles(mi_ctx* c, double* dev_ptr, int count)
+{
+    if (!c->comm) return MI_OK;
+    MI_NCCL(ncclAllReduce(dev_ptr, dev_ptr, (size_t)count, ncclDouble, ncclSum, c->comm, c->stream));
+    return MI_OK;
+}
+
+static void shard_range(int m_total, int rank, int world, int* lo, int* hi) { (void)mi_shard_range(m_total, rank, world, lo, hi); }
+
+// Uploads this rank's shard of the fixed cloud (SoA streams for K1 + float4 for gathers).
+static int upload_target_shard(mi_ctx* c, const float* after_xyz, int m_total)
+{
+    c->m_total = m_total;
+    shard_range(m_total, c->rank, c->world, &c->shard_lo, &c->shard_hi);
+    const int m_local = c->shard_hi - c->shard_lo;
+    const size_t len = target_alloc_len(m_local);
+    MI_TRY(c->tx.reserve(len)); MI_TRY(c->ty.reserve(len)); MI_TRY(c->tz.reserve(len));
+    MI_TRY(c->tgt4.reserve(len));
+    if (m_local > 0)
+        MI_TRY(upload_soa(c, after_xyz + 3 * (size_t)c->shard_lo, m_local, (int)len, c->tx.p, c->ty.p, c->tz.p, c->tgt4.p));
+    return MI_OK;
+}
+
+static IcpView make_view(mi_ctx* c)
+{
+    IcpView v{};
+    v.state = c->d_state;
+    v.bx = c->bx.p; v.by = c->by.p; v.bz = c->bz.p;
+    v.cx = c->cx.p; v.cy = c->cy.p; v.cz = c->cz.p;
+    v.tgt4 = c->tgt4.p;
+    v.keys = c->keys.p;
+    v.n = c->n; v.n_pad = c->n_pad;
+    v.shard_lo = c->shard_lo; v.shard_hi = c->shard_hi;
+    v.filter_pairs = c->icp.filter_pairs;
+    v.max_distance_squared = c->icp.max_distance_squared;
+    v.fma = c->icp.dist_mode == MI_DIST_FMA;
+    return v;
+}
+
+static void state_identity(IcpState* s)
+{
+    memset(s, 0, sizeof *s);
+    s->R[0] = s->R[4] = s->R[8] = 1.f;
+    s->prevR[0] = s->prevR[4] = s->prevR[8] = 1.f;
+    s->error = 1e5f;                 // "*error = 1e5"  basicicp.cpp:26
+    s->prev_error = 3.402823466e38f; // numeric_limits<float>::max()  icpcuda.cu:10
+}
+
+}  // namespace mislam
+
+// ---------------------------------------------------------------------------------------------------------------
+// ICP
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" void mi_icp_params_default(mi_icp_params* p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->eps = 1e-3f;
+    p->max_iterations = -1;
+    p->max_distance_squared = 1000.f;
+    p->dist_mode = MI_DIST_CPU_ROUNDING;
+    p->compose_mode = MI_COMPOSE_CPU_ADDITIVE;
+    p->filter_pairs = 1;
+    p->abort_on_increase = 0;
+    p->sync_every = 0;
+    p->verbose = 0;
+}
+
+extern "C" void mi_icp_params_cuda_slam(mi_icp_params* p)
+{
+    if (!p) return;
+    mi_icp_params_default(p);
+    p->dist_mode = MI_DIST_FMA;
+    p->compose_mode = MI_COMPOSE_EXACT;
+    p->filter_pairs = 0;
+    p->abort_on_increase = 1;
+}
+
+static int icp_check_params(const mi_icp_params* p)
+{
+    if (!p) { set_error("ICP: null params"); return MI_ERR_INVALID_ARG; }
+    if (p->dist_mode != MI_DIST_CPU_ROUNDING && p->dist_mode != MI_DIST_FMA) { set_error("ICP: bad dist_mode %d", p->dist_mode); return MI_ERR_INVALID_ARG; }
+    if (p->compose_mode != MI_COMPOSE_CPU_ADDITIVE && p->compose_mode != MI_COMPOSE_EXACT) { set_error("ICP: bad compose_mode %d", p->compose_mode); return MI_ERR_INVALID_ARG; }
+    if (p->max_iterations < -1) { set_error("ICP: max_iterations %d (use -1 for unbounded)", p->max_iterations); return MI_ERR_INVALID_ARG; }
+    return MI_OK;
+}
+
+extern "C" int mi_icp_reset(mi_ctx* c)
+{
+    if (!c || !c->icp_loaded) { set_error("mi_icp_reset: no problem loaded"); return MI_ERR_STATE; }
+    MI_HIP(hipSetDevice(c->device));
+    state_identity(c->h_state);
+    if (c->icp.max_iterations == 0) {   // "while (iterations < maxIterations)" never enters
+        c->h_state->done = 1;
+        c->h_state->stop_reason = MI_STOP_MAX_ITERATIONS;
+    }
+    MI_HIP(hipMemcpyAsync(c->d_state, c->h_state, sizeof(IcpState), hipMemcpyHostToDevice, c->stream));
+    const size_t bytes = sizeof(float) * (size_t)c->n_pad;
+    MI_HIP(hipMemcpyAsync(c->cx.p, c->bx.p, bytes, hipMemcpyDeviceToDevice, c->stream));   // transformedCloud = cloudBefore, basicicp.cpp:30
+    MI_HIP(hipMemcpyAsync(c->cy.p, c->by.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    MI_HIP(hipMemcpyAsync(c->cz.p, c->bz.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    MI_HIP(fill_keys(c->keys.p, c->n, c->stream));
+    MI_HIP(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, const float* after_xyz, int n_after,
+                           const mi_icp_params* params)
+{
+    if (!c) { set_error("mi_icp_load: null context"); return MI_ERR_INVALID_ARG; }
+    if (!before_xyz || !after_xyz || n_before <= 0 || n_after <= 0) { set_error("mi_icp_load: empty or null cloud (n_before=%d, n_after=%d)", n_before, n_after); return MI_ERR_INVALID_ARG; }
+    if (n_after < c->world) { set_error("mi_icp_load: fewer target points (%d) than ranks (%d)", n_after, c->world); return MI_ERR_INVALID_ARG; }
+    MI_TRY(icp_check_params(params));
+    MI_HIP(hipSetDevice(c->device));
+    c->icp_loaded = false;
+    c->icp = *params;
+    c->n = n_before;
+    c->n_pad = round_up(n_before, NN_SRC_PAD);
+    const size_t np = (size_t)c->n_pad;
+    MI_TRY(c->bx.reserve(np)); MI_TRY(c->by.reserve(np)); MI_TRY(c->bz.reserve(np));
+    MI_TRY(c->cx.reserve(np)); MI_TRY(c->cy.reserve(np)); MI_TRY(c->cz.reserve(np));
+    MI_TRY(c->keys.reserve(np));
+    MI_TRY(c->part_mom.reserve((size_t)ICP_MAX_PARTIAL_BLOCKS * ICP_MOMENTS));
+    MI_TRY(c->part_err.reserve((size_t)ICP_MAX_PARTIAL_BLOCKS * ICP_ERRSUMS));
+    MI_TRY(upload_soa(c, before_xyz, n_before, c->n_pad, c->bx.p, c->by.p, c->bz.p, nullptr));
+    MI_TRY(upload_target_shard(c, after_xyz, n_after));
+    c->icp_loaded = true;
+    return mi_icp_reset(c);
+}
+
+// One loop body of basicicp.cpp:32-57 / icpcuda.cu:31-54, enqueued without host synchronisation.
+static int icp_enqueue_iteration(mi_ctx* c)
+{
+    const IcpView v = make_view(c);
+    const int m_local = c->shard_hi - c->shard_lo;
+    const int nb = icp_reduce_blocks(c->n);
+    const int nbp = icp_reduce_blocks(c->n_pad);
+    // K1 (+ C1)
+    MI_TRY(launch_nn(c, c->cx.p, c->cy.p, c->cz.p, c->n, m_local, c->shard_lo, v.fma, &c->d_state->done));
+    MI_TRY(allreduce_keys(c, c->n));
+    // K2, K3
+    { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_moments(v, c->part_mom.p, nb, c->stream)); }
+    if (c->comm) {
+        ProfScope ps(c, MI_KERNEL_SOLVE);
+        MI_HIP(icp_reduce_moments(c->d_state, c->part_mom.p, nb, c->stream));
+        MI_TRY(allreduce_doubles(c, c->d_state->mom, ICP_MOMENTS));
+        MI_HIP(icp_solve(c->d_state, nullptr, 0, c->icp.compose_mode, c->stream));
+    } else {
+        ProfScope ps(c, MI_KERNEL_SOLVE);
+        MI_HIP(icp_solve(c->d_state, c->part_mom.p, nb, c->icp.compose_mode, c->stream));
+    }
+    // K4+K5, K6
+    { ProfScope ps(c, MI_KERNEL_TRANSFORM); MI_HIP(icp_transform_error(v, c->part_err.p, nbp, 2, c->stream)); }
+    IcpRules rules{};
+    rules.eps = c->icp.eps;
+    rules.max_iterations = c->icp.max_iterations;
+    rules.filter_pairs = c->icp.filter_pairs;
+    rules.abort_on_increase = c->icp.abort_on_increase;
+    rules.m_total = c->m_total;
+    if (c->comm) {
+        ProfScope ps(c, MI_KERNEL_FINALIZE);
+        MI_HIP(icp_reduce_error(c->d_state, c->part_err.p, nbp, c->stream));
+        MI_TRY(allreduce_doubles(c, c->d_state->err, ICP_ERRSUMS));
+        MI_HIP(icp_finalize(c->d_state, nullptr, 0, rules, c->stream));
+    } else {
+        ProfScope ps(c, MI_KERNEL_FINALIZE);
+        MI_HIP(icp_finalize(c->d_state, c->part_err.p, nbp, rules, c->stream));
+    }
+    return MI_OK;
+}
+
+static int icp_fetch_state(mi_ctx* c)
+{
+    MI_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
+    MI_HIP(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+extern "C" int mi_icp_run(mi_ctx* c, int max_new_iterations, int* iterations_done)
+{
+    if (!c || !c->icp_loaded) { set_error("mi_icp_run: no problem loaded"); return MI_ERR_STATE; }
+    MI_HIP(hipSetDevice(c->device));
+    MI_TRY(icp_fetch_state(c));
+    const int passes_before = c->h_state->passes;
+    int batch = c->icp.sync_every;
+    if (batch <= 0) {
+        // auto: large searches dwarf a host round trip (sync each iteration); small ones are launch-bound (batch them)
+        const double pairs = (double)c->n * (double)(c->shard_hi - c->shard_lo);
+        batch = pairs >= 2e9 ? 1 : (pairs >= 2e8 ? 4 : 8);
+    }
+    int enqueued = 0;
+    while (!c->h_state->done && (max_new_iterations < 0 || enqueued < max_new_iterations)) {
+        int todo = batch;
+        if (max_new_iterations >= 0) todo = std::min(todo, max_new_iterations - enqueued);
+        for (int b = 0; b < todo; b++) MI_TRY(icp_enqueue_iteration(c));
+        enqueued += todo;
+        const int shown = c->h_state->passes;
+        MI_TRY(icp_fetch_state(c));
+        if (c->icp.verbose && c->rank == 0 && c->h_state->passes > shown)
+            printf("loop_nr %d, error: %f, correspondencesSize: %d\n", c->h_state->passes - 1, c->h_state->error, c->h_state->pairs);
+    }
+    if (iterations_done) *iterations_done = c->h_state->passes - passes_before;
+    return MI_OK;
+}
+
+extern "C" int mi_icp_result(mi_ctx* c, float out_T[16], int* iterations, float* error, int* stop_reason)
+{
+    if (!c || !c->icp_loaded) { set_error("mi_icp_result: no problem loaded"); return MI_ERR_STATE; }
+    MI_HIP(hipSetDevice(c->device));
+    MI_TRY(icp_fetch_state(c));
+    const IcpState* s = c->h_state;
+    if (out_T) {
+        // column-major 4x4, t in column 3 (ConvertToTransformationMatrix, common.cpp:353-358)
+        for (int col = 0; col < 3; col++) {
+            for (int row = 0; row < 3; row++) out_T[4 * col + row] = s->R[3 * col + row];
+            out_T[4 * col + 3] = 0.f;
+        }
+        out_T[12] = s->t[0]; out_T[13] = s->t[1]; out_T[14] = s->t[2]; out_T[15] = 1.f;
+    }
+    if (iterations) *iterations = s->iterations;
+    if (error) *error = s->error;
+    if (stop_reason) *stop_reason = s->done ? s->stop_reason : MI_STOP_RUNNING;
+    return MI_OK;
+}
+
+extern "C" int mi_icp_register(mi_ctx* c, const float* before_xyz, int n_before, const float* after_xyz, int n_after,
+                               const mi_icp_params* params, float out_T[16], int* iterations, float* error)
+{
+    if (!iterations || !error || !out_T) { set_error("mi_icp_register: out_T, iterations and error must be non-null"); return MI_ERR_INVALID_ARG; }
+    MI_TRY(mi_icp_load(c, before_xyz, n_before, after_xyz, n_after, params));
+    MI_TRY(mi_icp_run(c, -1, nullptr));
+    return mi_icp_result(c, out_T, iterations, error, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// test-grade primitives
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int mi_nn_search(mi_ctx* c, const float* src_xyz, int n, const float* tgt_xyz, int m, int dist_mode, int* idx, float* d2)
+{
+    if (!c) { set_error("mi_nn_search: null context"); return MI_ERR_INVALID_ARG; }
+    if (n < 0 || m < 0 || (n > 0 && (!src_xyz || !idx)) || (m > 0 && !tgt_xyz)) { set_error("mi_nn_search: bad arguments"); return MI_ERR_INVALID_ARG; }
+    if (dist_mode != MI_DIST_CPU_ROUNDING && dist_mode != MI_DIST_FMA) { set_error("mi_nn_search: bad dist_mode"); return MI_ERR_INVALID_ARG; }
+    if (n == 0) return MI_OK;
+    if (m == 0) { set_error("mi_nn_search: empty target cloud"); return MI_ERR_INVALID_ARG; }
+    if (m < c->world) { set_error("mi_nn_search: fewer targets than ranks"); return MI_ERR_INVALID_ARG; }
+    MI_HIP(hipSetDevice(c->device));
+    c->icp_loaded = false;   // the workspace is being reused
+    const int n_pad = round_up(n, NN_SRC_PAD);
+    MI_TRY(c->cx.reserve((size_t)n_pad)); MI_TRY(c->cy.reserve((size_t)n_pad)); MI_TRY(c->cz.reserve((size_t)n_pad));
+    MI_TRY(c->keys.reserve((size_t)n_pad));
+    MI_TRY(upload_soa(c, src_xyz, n, n_pad, c->cx.p, c->cy.p, c->cz.p, nullptr));
+    MI_TRY(upload_target_shard(c, tgt_xyz, m));
+    MI_HIP(fill_keys(c->keys.p, n, c->stream));
+    MI_TRY(launch_nn(c, c->cx.p, c->cy.p, c->cz.p, n, c->shard_hi - c->shard_lo, c->shard_lo, dist_mode == MI_DIST_FMA, nullptr));
+    MI_TRY(allreduce_keys(c, n));
+    MI_TRY(c->idx_tmp.reserve((size_t)n));
+    MI_TRY(c->staging.reserve((size_t)n));
+    MI_HIP(unpack_keys(c->keys.p, n, c->idx_tmp.p, d2 ? c->staging.p : nullptr, c->stream));
+    MI_HIP(hipMemcpyAsync(idx, c->idx_tmp.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (d2) MI_HIP(hipMemcpyAsync(d2, c->staging.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+// Shared set-up of mi_kabsch / mi_transform_mse: source -> (b, c), target -> tgt4, caller's correspondences -> keys.
+static int load_pairs(mi_ctx* c, const float* src_xyz, int n, const float* tgt_xyz, int m, const int* idx, const unsigned char* keep)
+{
+    MI_HIP(hipSetDevice(c->device));
+    c->icp_loaded = false;
+    if (c->world != 1) { set_error("this primitive is single-GPU only"); return MI_ERR_STATE; }
+    for (int i = 0; idx && i < n; i++)
+        if (idx[i] < 0 || idx[i] >= m) { set_error("correspondence idx[%d] = %d outside [0,%d)", i, idx[i], m); return MI_ERR_INVALID_ARG; }
+    c->n = n;
+    c->n_pad = round_up(n, NN_SRC_PAD);
+    const size_t np = (size_t)c->n_pad;
+    MI_TRY(c->bx.reserve(np)); MI_TRY(c->by.reserve(np)); MI_TRY(c->bz.reserve(np));
+    MI_TRY(c->cx.reserve(np)); MI_TRY(c->cy.reserve(np)); MI_TRY(c->cz.reserve(np));
+    MI_TRY(c->keys.reserve(np));
+    MI_TRY(c->part_mom.reserve((size_t)ICP_MAX_PARTIAL_BLOCKS * ICP_MOMENTS));
+    MI_TRY(c->part_err.reserve((size_t)ICP_MAX_PARTIAL_BLOCKS * ICP_ERRSUMS));
+    MI_TRY(upload_soa(c, src_xyz, n, c->n_pad, c->bx.p, c->by.p, c->bz.p, nullptr));
+    const size_t bytes = sizeof(float) * np;
+    MI_HIP(hipMemcpyAsync(c->cx.p, c->bx.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    MI_HIP(hipMemcpyAsync(c->cy.p, c->by.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    MI_HIP(hipMemcpyAsync(c->cz.p, c->bz.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    if (tgt_xyz && m > 0) MI_TRY(upload_target_shard(c, tgt_xyz, m));
+    else { c->m_total = 0; c->shard_lo = c->shard_hi = 0; MI_TRY(c->tgt4.reserve(1)); }
+    if (idx) {
+        MI_TRY(c->idx_tmp.reserve((size_t)n));
+        MI_HIP(hipMemcpyAsync(c->idx_tmp.p, idx, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        if (keep) {
+            MI_TRY(c->keep_tmp.reserve((size_t)n));
+            MI_HIP(hipMemcpyAsync(c->keep_tmp.p, keep, (size_t)n, hipMemcpyHostToDevice, c->stream));
+        }
+        MI_HIP(pack_keys(c->idx_tmp.p, keep ? c->keep_tmp.p : nullptr, n, c->keys.p, c->stream));
+    } else {
+        MI_HIP(fill_keys(c->keys.p, n, c->stream));   // index 0xFFFFFFFF is outside every shard: no pair is used
+    }
+    mi_icp_params_default(&c->icp);
+    c->icp.filter_pairs = 1;                       // keys carry d2 = 0 (kept) or +inf (dropped)
+    c->icp.max_distance_squared = 1.f;
+    state_identity(c->h_state);
+    return MI_OK;
+}
+
+extern "C" int mi_kabsch(mi_ctx* c, const float* src_xyz, int n, const float* tgt_xyz, int m, const int* idx,
+                         const unsigned char* keep, float out_R9[9], float out_t3[3], int* pairs_used)
+{
+    if (!c || !src_xyz || !tgt_xyz || !idx || n <= 0 || m <= 0 || !out_R9 || !out_t3) { set_error("mi_kabsch: bad arguments"); return MI_ERR_INVALID_ARG; }
+    MI_TRY(load_pairs(c, src_xyz, n, tgt_xyz, m, idx, keep));
+    MI_HIP(hipMemcpyAsync(c->d_state, c->h_state, sizeof(IcpState), hipMemcpyHostToDevice, c->stream));
+    const IcpView v = make_view(c);
+    const int nb = icp_reduce_blocks(n);
+    { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_moments(v, c->part_mom.p, nb, c->stream)); }
+    { ProfScope ps(c, MI_KERNEL_SOLVE); MI_HIP(icp_solve(c->d_state, c->part_mom.p, nb, MI_COMPOSE_EXACT, c->stream)); }
+    MI_TRY(icp_fetch_state(c));
+    if (pairs_used) *pairs_used = c->h_state->pairs;
+    if (c->h_state->pairs <= 0) { set_error("mi_kabsch: no pair kept"); return MI_ERR_INVALID_ARG; }
+    memcpy(out_R9, c->h_state->Ri, sizeof(float) * 9);
+    memcpy(out_t3, c->h_state->ti, sizeof(float) * 3);
+    return MI_OK;
+}
+
+extern "C" int mi_transform_mse(mi_ctx* c, const float* src_xyz, int n, const float R9[9], const float t3[3],
+                                const float* tgt_xyz, int m, const int* idx, const unsigned char* keep, int divide_by_pairs,
+                                float* out_xyz, float* mse)
+{
+    if (!c || !src_xyz || n <= 0 || !R9 || !t3) { set_error("mi_transform_mse: bad arguments"); return MI_ERR_INVALID_ARG; }
+    if (mse && (!tgt_xyz || !idx || m <= 0)) { set_error("mi_transform_mse: mse needs target cloud and idx"); return MI_ERR_INVALID_ARG; }
+    MI_TRY(load_pairs(c, src_xyz, n, tgt_xyz, m, mse ? idx : nullptr, keep));
+    memcpy(c->h_state->R, R9, sizeof(float) * 9);
+    memcpy(c->h_state->t, t3, sizeof(float) * 3);
+    MI_HIP(hipMemcpyAsync(c->d_state, c->h_state, sizeof(IcpState), hipMemcpyHostToDevice, c->stream));
+    const IcpView v = make_view(c);
+    const int nbp = icp_reduce_blocks(c->n_pad);
+    { ProfScope ps(c, MI_KERNEL_TRANSFORM); MI_HIP(icp_transform_error(v, c->part_err.p, nbp, 0, c->stream)); }
+    MI_HIP(icp_reduce_error(c->d_state, c->part_err.p, nbp, c->stream));
+    if (out_xyz) {
+        MI_TRY(c->staging.reserve((size_t)3 * n));
+        MI_HIP(soa_to_aos(c->cx.p, c->cy.p, c->cz.p, n, c->staging.p, c->stream));
+        MI_HIP(hipMemcpyAsync(out_xyz, c->staging.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    }
+    MI_TRY(icp_fetch_state(c));
+    if (mse) {
+        const double denom = divide_by_pairs ? c->h_state->err[1] : (double)m;
+        *mse = (float)(c->h_state->err[0] / denom);
+    }
+    return MI_OK;
+}

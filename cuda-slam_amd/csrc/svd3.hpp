@@ -1,0 +1,179 @@
+// K3 building block: 3x3 singular value decomposition + Kabsch rotation, usable from one GPU lane (and from host code).
+//
+// The reference solves the 3x3 problem with cusolverDnSgesvd plus five blocking memcpys per iteration
+// (source/cuda-slam/cudacommon.cu:203-224) on the GPU and with Eigen::JacobiSVD on the CPU (source/common/common.cpp:531).
+// Here it is a two-sided Jacobi iteration in registers, the scheme Eigen's JacobiSVD documents for square input
+// (scale by the largest |a_ij|; sweep the pairs (1,0), (2,0), (2,1); symmetrise each 2x2 block with a left rotation, then
+// diagonalise it with a Jacobi rotation; stop when a sweep rotates nothing; flip signs so the diagonal is positive; sort
+// descending), so the result tracks the CPU oracle to rounding.  R = U diag(1,1,det(U V^T)) V^T as in
+// common.cpp:541-545 / cudacommon.cu:236-238.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+
+namespace mislam {
+
+struct Mat3 {
+    float a[3][3];   // a[row][col]
+};
+
+struct Rot2 {
+    float c, s;
+    __host__ __device__ bool identity() const { return c == 1.f && s == 0.f; }
+};
+
+// rows p,q of m:  (x,y) <- (c x + s y, -s x + c y)
+__host__ __device__ inline void rotate_rows(Mat3& m, int p, int q, Rot2 j)
+{
+    if (j.identity()) return;
+    for (int k = 0; k < 3; k++) {
+        const float x = m.a[p][k], y = m.a[q][k];
+        m.a[p][k] = j.c * x + j.s * y;
+        m.a[q][k] = -j.s * x + j.c * y;
+    }
+}
+
+// columns p,q of m with the same 2x2 action on (x,y)
+__host__ __device__ inline void rotate_cols(Mat3& m, int p, int q, Rot2 j)
+{
+    if (j.identity()) return;
+    for (int k = 0; k < 3; k++) {
+        const float x = m.a[k][p], y = m.a[k][q];
+        m.a[k][p] = j.c * x + j.s * y;
+        m.a[k][q] = -j.s * x + j.c * y;
+    }
+}
+
+// Jacobi rotation diagonalising the symmetric 2x2 [[x, y], [y, z]]
+__host__ __device__ inline Rot2 symmetric_jacobi(float x, float y, float z)
+{
+    const float deno = 2.f * fabsf(y);
+    if (deno < FLT_MIN) return Rot2{1.f, 0.f};
+    const float tau = (x - z) / deno;
+    const float w = sqrtf(tau * tau + 1.f);
+    const float t = (tau > 0.f) ? 1.f / (tau + w) : 1.f / (tau - w);
+    const float sign_t = t > 0.f ? 1.f : -1.f;
+    const float n = 1.f / sqrtf(t * t + 1.f);
+    return Rot2{n, -sign_t * (y / fabsf(y)) * fabsf(t) * n};
+}
+
+struct Svd3 {
+    Mat3 U, V;
+    float S[3];
+};
+
+__host__ __device__ inline Svd3 svd3(const Mat3& A)
+{
+    const float precision = 2.f * FLT_EPSILON;
+    float scale = 0.f;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) scale = fmaxf(scale, fabsf(A.a[r][c]));
+    if (scale == 0.f) scale = 1.f;
+
+    Mat3 W;
+    Svd3 out;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            W.a[r][c] = A.a[r][c] / scale;
+            out.U.a[r][c] = out.V.a[r][c] = (r == c) ? 1.f : 0.f;
+        }
+    float max_diag = fmaxf(fabsf(W.a[0][0]), fmaxf(fabsf(W.a[1][1]), fabsf(W.a[2][2])));
+
+    // A 3x3 Jacobi SVD converges in a handful of sweeps; the cap only guards against NaN input spinning forever.
+    for (int sweep = 0; sweep < 64; sweep++) {
+        bool rotated = false;
+        for (int p = 1; p < 3; p++) {
+            for (int q = 0; q < p; q++) {
+                const float threshold = fmaxf(FLT_MIN, precision * max_diag);
+                if (!(fabsf(W.a[p][q]) > threshold || fabsf(W.a[q][p]) > threshold)) continue;
+                rotated = true;
+                // 2x2 block [[pp, pq], [qp, qq]]: left rotation making it symmetric ...
+                float m00 = W.a[p][p], m01 = W.a[p][q], m10 = W.a[q][p], m11 = W.a[q][q];
+                Rot2 sym;
+                const float tr = m00 + m11, d = m10 - m01;
+                if (fabsf(d) < FLT_MIN) sym = Rot2{1.f, 0.f};
+                else {
+                    const float u = tr / d;
+                    const float h = sqrtf(1.f + u * u);
+                    sym = Rot2{u / h, 1.f / h};
+                }
+                if (!sym.identity()) {
+                    const float a0 = m00, a1 = m01, b0 = m10, b1 = m11;
+                    m00 = sym.c * a0 + sym.s * b0;  m01 = sym.c * a1 + sym.s * b1;
+                    m10 = -sym.s * a0 + sym.c * b0; m11 = -sym.s * a1 + sym.c * b1;
+                }
+                // ... then the Jacobi rotation of the symmetric block; left = sym * right^T
+                const Rot2 right = symmetric_jacobi(m00, m01, m11);
+                const Rot2 left{sym.c * right.c + sym.s * right.s, sym.s * right.c - sym.c * right.s};
+                const Rot2 right_t{right.c, -right.s};
+                rotate_rows(W, p, q, left);
+                rotate_cols(out.U, p, q, left);
+                rotate_cols(W, p, q, right_t);
+                rotate_cols(out.V, p, q, right_t);
+                max_diag = fmaxf(max_diag, fmaxf(fabsf(W.a[p][p]), fabsf(W.a[q][q])));
+            }
+        }
+        if (!rotated) break;
+    }
+
+    for (int i = 0; i < 3; i++) {
+        const float d = W.a[i][i];
+        out.S[i] = fabsf(d) * scale;
+        if (d < 0.f)
+            for (int r = 0; r < 3; r++) out.U.a[r][i] = -out.U.a[r][i];
+    }
+    // selection sort, descending, swapping the matching columns of U and V
+    for (int i = 0; i < 2; i++) {
+        int pos = i;
+        for (int k = i + 1; k < 3; k++)
+            if (out.S[k] > out.S[pos]) pos = k;
+        if (out.S[pos] == 0.f) break;
+        if (pos != i) {
+            float tmp = out.S[i]; out.S[i] = out.S[pos]; out.S[pos] = tmp;
+            for (int r = 0; r < 3; r++) {
+                tmp = out.U.a[r][i]; out.U.a[r][i] = out.U.a[r][pos]; out.U.a[r][pos] = tmp;
+                tmp = out.V.a[r][i]; out.V.a[r][i] = out.V.a[r][pos]; out.V.a[r][pos] = tmp;
+            }
+        }
+    }
+    return out;
+}
+
+__host__ __device__ inline Mat3 mul_abt(const Mat3& A, const Mat3& B)   // A * B^T
+{
+    Mat3 C;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) C.a[r][c] = (A.a[r][0] * B.a[c][0] + A.a[r][1] * B.a[c][1]) + A.a[r][2] * B.a[c][2];
+    return C;
+}
+
+__host__ __device__ inline float det3(const Mat3& M)
+{
+    return M.a[0][0] * (M.a[1][1] * M.a[2][2] - M.a[1][2] * M.a[2][1]) -
+           M.a[0][1] * (M.a[1][0] * M.a[2][2] - M.a[1][2] * M.a[2][0]) +
+           M.a[0][2] * (M.a[1][0] * M.a[2][1] - M.a[1][1] * M.a[2][0]);
+}
+
+// Kabsch rotation from the cross-covariance H = sum (a - ca)(b - cb)^T (a = fixed/after, b = moving/before):
+// R = U diag(1, 1, det(U V^T)) V^T.  Also returns det and the singular values (the CPD M-step needs both).
+struct Kabsch3 {
+    Mat3 R;
+    float S[3];
+    float det;
+};
+
+__host__ __device__ inline Kabsch3 kabsch_rotation(const Mat3& H)
+{
+    const Svd3 s = svd3(H);
+    Kabsch3 k;
+    k.det = det3(mul_abt(s.U, s.V));
+    Mat3 Ud = s.U;
+    for (int r = 0; r < 3; r++) Ud.a[r][2] = s.U.a[r][2] * k.det;
+    k.R = mul_abt(Ud, s.V);
+    for (int i = 0; i < 3; i++) k.S[i] = s.S[i];
+    return k;
+}
+
+}  // namespace mislam

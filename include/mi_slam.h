@@ -1,0 +1,229 @@
+/* mi_slam.h -- C ABI of the MI355X-native point-set-registration core (libmislam.so).
+ *
+ * This is the drop-in boundary for the reference's GPU registration path.  A thin C++ adapter with the shape of the
+ * reference's Common::SlamFunc (source/common/testrunner.h:7-8) binds these entry points; INTEGRATION.md shows the
+ * adapter a maintainer would put where source/cuda-slam/gpumain.cpp:12-38 dispatches today.
+ *
+ * Conventions (all taken from the reference's own boundary):
+ *   - clouds are contiguous AoS float xyz, 12 B per point, no padding: Common::Point<float>
+ *     (source/common/point.h:6-64), the layout the reference memcpy's to the device as glm::vec3
+ *     (source/cuda-slam/icpcuda.cu:71-72);
+ *   - `before` is the moving cloud, `after` the fixed one; the result maps before onto after;
+ *   - 4x4 results are COLUMN-MAJOR with the translation in column 3, byte-identical to glm::mat4 as built by
+ *     Common::ConvertToTransformationMatrix (source/common/common.cpp:353-358) and to a default Eigen::Matrix4f;
+ *   - host pointers in, host pointers out; the library owns every device allocation (context workspace);
+ *   - every function returns MI_OK (0) or a negative error code instead of the reference's print-and-exit(1)
+ *     (include/helper_cuda.h:567-573); mi_last_error() returns the message; nothing is printed unless verbose != 0.
+ *
+ * The hot path behind it is hand-written HIP for gfx950; there is no CPU fallback: if no HIP device is usable the
+ * calls fail with MI_ERR_NO_DEVICE.
+ */
+#ifndef MI_SLAM_H
+#define MI_SLAM_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_SLAM_ABI_VERSION 1
+
+enum {
+    MI_OK = 0,
+    MI_ERR_INVALID_ARG = -1,
+    MI_ERR_NO_DEVICE = -2,
+    MI_ERR_HIP = -3,
+    MI_ERR_RCCL = -4,
+    MI_ERR_STATE = -5
+};
+
+/* Distance arithmetic of the nearest-neighbour search.  Both are IEEE fp32 on (dx,dy,dz) = target - source. */
+enum {
+    MI_DIST_CPU_ROUNDING = 0,   /* ((dx*dx + dy*dy) + dz*dz), every product and sum rounded: bit-identical to the x86-64
+                                   cpu-slam build (source/common/point.h:48-50 via common.cpp:452) */
+    MI_DIST_FMA = 1             /* fma(dz,dz, fma(dy,dy, dx*dx)): what nvcc's default contraction makes of
+                                   GetDistanceSquared (source/cuda-slam/cudacommon.cu:51-55) */
+};
+
+/* How the per-iteration solve (Ri, ti) is accumulated into the running transform. */
+enum {
+    MI_COMPOSE_CPU_ADDITIVE = 0,  /* R <- Ri*R ; t <- ti + t   -- source/cpu-slam/basicicp.cpp:43-44 (the oracle's rule) */
+    MI_COMPOSE_EXACT = 1          /* T <- Ti*T (4x4)           -- source/cuda-slam/icpcuda.cu:35 */
+};
+
+/* Why a registration loop stopped. */
+enum {
+    MI_STOP_RUNNING = 0,
+    MI_STOP_CONVERGED = 1,        /* error < eps                      basicicp.cpp:52 / icpcuda.cu:40 */
+    MI_STOP_MAX_ITERATIONS = 2,   /* iterations reached the cap        basicicp.cpp:32 / icpcuda.cu:31 */
+    MI_STOP_NO_PAIRS = 3,         /* no correspondence survived filter basicicp.cpp:36 */
+    MI_STOP_ERROR_INCREASED = 4,  /* rollback rule                     icpcuda.cu:43-49 */
+    MI_STOP_TOLERANCE = 5,        /* CPD: ntol <= tolerance            coherentpointdrift.cpp:106 */
+    MI_STOP_SIGMA = 6             /* CPD: sigma^2 <= eps               coherentpointdrift.cpp:106 */
+};
+
+typedef struct mi_ctx mi_ctx;   /* opaque: device, stream, workspace, optional RCCL communicator */
+
+/* ----------------------------------------------------------------------------------------------------------------
+ * Context.  Hoists device selection, stream/event creation, workspace allocation and (multi-GPU) the communicator out
+ * of the registration calls -- the reference allocates and frees everything per call (icpcuda.cu:21-29,56).
+ * -------------------------------------------------------------------------------------------------------------- */
+int mi_abi_version(void);
+const char* mi_last_error(void);
+int mi_device_count(int* count);
+
+int mi_ctx_create(int device, mi_ctx** out);
+
+/* Multi-GPU, one process per GPU.  Rank r of `world` ranks owns targets [r*M/world, (r+1)*M/world) of the fixed cloud
+ * and all source points; per ICP iteration the per-point packed (min-dist, argmin) keys are combined with ONE
+ * ncclAllReduce(ncclUint64, ncclMin) over xGMI (no reference counterpart: the reference is single-GPU).
+ * unique_id is the 128-byte ncclUniqueId produced by mi_dist_unique_id() on rank 0 and shipped to the other ranks by
+ * the caller's bootstrap (torch.distributed store, MPI, a socket ...). */
+#define MI_UNIQUE_ID_BYTES 128
+int mi_dist_unique_id(void* out_unique_id);
+int mi_ctx_create_dist(int device, int rank, int world, const void* unique_id, mi_ctx** out);
+int mi_ctx_rank(const mi_ctx* ctx, int* rank, int* world);
+
+/* Host-side pieces of the multi-GPU protocol (pure functions, usable without a device; the CPU tests drive them over gloo):
+ *   mi_shard_range  the contiguous target range [lo, hi) rank `rank` of `world` owns: lo = M*rank/world, hi = M*(rank+1)/world;
+ *   mi_pack_key     the 64-bit key the search emits per source point: IEEE bits of d2 (d2 >= 0, so they order like the
+ *                   value) in the high word, the GLOBAL target index in the low word -- an unsigned min over keys is the
+ *                   (min distance, lowest index) rule of cudacommon.cu:68 / common.cpp:454, across chunks and across GPUs. */
+int mi_shard_range(int m_total, int rank, int world, int* lo, int* hi);
+unsigned long long mi_pack_key(float d2, int global_index);
+void mi_unpack_key(unsigned long long key, float* d2, int* global_index);
+void mi_ctx_destroy(mi_ctx* ctx);
+int mi_ctx_synchronize(mi_ctx* ctx);
+
+/* ----------------------------------------------------------------------------------------------------------------
+ * ICP -- replaces GetCudaIcpTransformationMatrix(before, after, eps, maxIterations, iterations, error)
+ *        (source/cuda-slam/icpcuda.cuh:5-11, icpcuda.cu:60-76) and, through its modes, reproduces
+ *        BasicICP::GetBasicICPTransformationMatrix (source/cpu-slam/basicicp.cpp:23-61), the parity oracle.
+ * -------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    float eps;                   /* "convergence-epsilon"                (configparser.cpp:244, default 1e-3) */
+    int   max_iterations;        /* "max-iterations", -1 = unbounded     (gpumain.cpp:14) */
+    float max_distance_squared;  /* "max-distance-squared" (default 1000, configparser.cpp:207); used when filter_pairs */
+    int   dist_mode;             /* MI_DIST_* */
+    int   compose_mode;          /* MI_COMPOSE_* */
+    int   filter_pairs;          /* 1: drop pairs with d2 >= max_distance_squared and average the error over the survivors
+                                       (common.cpp:486-499, :267); 0: keep all and divide the error sum by |after|
+                                       (cudacommon.cu:138-148) */
+    int   abort_on_increase;     /* 1: stop and roll back when the error rises (icpcuda.cu:43-49); 0: cpu-slam never does */
+    int   sync_every;            /* iterations enqueued between host checks of the device-side stop flag; 0 = auto.
+                                    The stop rule itself is evaluated on the device after EVERY iteration, so the result
+                                    does not depend on this value. */
+    int   verbose;               /* 1: print "loop_nr %d, error: %f" lines like basicicp.cpp:50 at every host check */
+    int   reserved[7];
+} mi_icp_params;
+
+/* Defaults = cpu-slam semantics (the parity oracle): CPU rounding, additive translation, filtered pairs, no abort. */
+void mi_icp_params_default(mi_icp_params* p);
+/* The GPU reference's own driver rules (icpcuda.cu:8-58): FMA distance, exact composition, no filter, abort+rollback. */
+void mi_icp_params_cuda_slam(mi_icp_params* p);
+
+/* One-call registration.  out_T: 16 floats column-major; iterations/error as the reference's out-params (non-null). */
+int mi_icp_register(mi_ctx* ctx, const float* before_xyz, int n_before, const float* after_xyz, int n_after,
+                    const mi_icp_params* params, float out_T[16], int* iterations, float* error);
+
+/* Resident-data form of the same loop (what bench.py times: inputs already in HBM when the clock starts).
+ *   mi_icp_load   uploads both clouds (AoS -> SoA on device), sizes the workspace, resets the state to identity;
+ *   mi_icp_reset  resets the running transform / counters without re-uploading;
+ *   mi_icp_run    enqueues up to `max_new_iterations` more iterations of the loop (fewer if a stop rule fires),
+ *                 returns after they finished;
+ *   mi_icp_result reads the current (T, iterations, error, stop reason). */
+int mi_icp_load(mi_ctx* ctx, const float* before_xyz, int n_before, const float* after_xyz, int n_after,
+                const mi_icp_params* params);
+int mi_icp_reset(mi_ctx* ctx);
+int mi_icp_run(mi_ctx* ctx, int max_new_iterations, int* iterations_done);
+int mi_icp_result(mi_ctx* ctx, float out_T[16], int* iterations, float* error, int* stop_reason);
+
+/* ----------------------------------------------------------------------------------------------------------------
+ * Test-grade primitives (one per reference primitive on the path; host in / host out).
+ * -------------------------------------------------------------------------------------------------------------- */
+
+/* CUDACommon::GetCorrespondingPoints + FindCorrespondences (cudacommon.cu:272-289, :57-77) /
+ * Common::GetCorrespondingPoints search part (common.cpp:441-478):
+ * idx[i] = argmin_j |tgt[j] - src[i]|^2, strict '<', lowest index wins ties; d2[i] = that minimum (may be NULL). */
+int mi_nn_search(mi_ctx* ctx, const float* src_xyz, int n, const float* tgt_xyz, int m, int dist_mode,
+                 int* idx, float* d2);
+
+/* CUDACommon::LeastSquaresSVD (cudacommon.cu:168-253) / Common::LeastSquaresSVD (common.cpp:517-552) on the pairs
+ * (src[i], tgt[idx[i]]), i = 0..n-1, keeping pair i only if keep == NULL or keep[i] != 0.
+ * out_R9 column-major (glm::mat3), out_t3 = centroid_tgt - R * centroid_src.  pairs_used may be NULL. */
+int mi_kabsch(mi_ctx* ctx, const float* src_xyz, int n, const float* tgt_xyz, int m, const int* idx,
+              const unsigned char* keep, float out_R9[9], float out_t3[3], int* pairs_used);
+
+/* CUDACommon::TransformCloud + GetMeanSquaredError (cudacommon.cu:132-148) / common.cpp:219-224, :259-268:
+ * out[i] = R*src[i] + t (glm operation order, no contraction); *mse = sum_i |tgt[idx[i]] - out[i]|^2 / denom over the
+ * kept pairs, denom = number of kept pairs if divide_by_pairs else m.  out_xyz, idx, mse may be NULL. */
+int mi_transform_mse(mi_ctx* ctx, const float* src_xyz, int n, const float R9[9], const float t3[3],
+                     const float* tgt_xyz, int m, const int* idx, const unsigned char* keep, int divide_by_pairs,
+                     float* out_xyz, float* mse);
+
+/* ----------------------------------------------------------------------------------------------------------------
+ * Rigid CPD with the exact Gaussian P ("approximation-type": "none") -- replaces GetCudaCpdTransformationMatrix
+ * (source/cuda-slam/cpdcuda.cuh:5-17, cpdcuda.cu:302-386); oracle CoherentPointDrift::GetRigidCPDTransformationMatrix
+ * (source/cpu-slam/coherentpointdrift.cpp:69-124).  CPD naming follows the reference: M = |before| (index k),
+ * N = |after| (index x).
+ * -------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    float eps;             /* "convergence-epsilon": loop runs while sigma^2 > eps      (coherentpointdrift.cpp:106) */
+    float weight;          /* "cpd-weight" (default .3), clamped to [1e-6, 1-1e-6]      (:93-96) */
+    int   const_scale;     /* "cpd-const-scale" (parser default false, configparser.cpp:240) */
+    int   max_iterations;  /* loop runs while iterations < max_iterations; NB -1 therefore runs NO iteration (:106) */
+    float tolerance;       /* "cpd-tolerance" (default 1e-3) */
+    float sigma2_init;     /* > 0: use this initial sigma^2.  <= 0: computed on the device as the exact
+                              sum_ij |b_i - a_j|^2 / (3MN) in fp64.  cpu-slam's own value is a single sequential fp32
+                              running sum (coherentpointdrift.cpp:126-139) that saturates for M*N >~ 1e7
+                              (3.604 instead of 12.943 on the bunny clouds); pass that number here to retrace cpu-slam. */
+    int   sync_every;      /* as in mi_icp_params */
+    int   verbose;
+    int   reserved[8];
+} mi_cpd_params;
+
+void mi_cpd_params_default(mi_cpd_params* p);
+
+/* out_sR_t: column-major 4x4 holding scale*R (cpdcuda.cu:360) and t; out_scale may be NULL. */
+int mi_cpd_register(mi_ctx* ctx, const float* before_xyz, int m_before, const float* after_xyz, int n_after,
+                    const mi_cpd_params* params, float out_sR_t[16], float* out_scale, int* iterations, float* error);
+
+/* CalculateSigmaSquared (cpdcuda.cu:65-78 / coherentpointdrift.cpp:126-139), exact value (see sigma2_init above). */
+int mi_cpd_sigma_squared(mi_ctx* ctx, const float* before_xyz, int m, const float* after_xyz, int n, float* sigma2);
+
+/* ComputePMatrix, no truncation (cpdcuda.cu:80-116 / coherentpointdrift.cpp:168-221):
+ * p_xk = exp(-|x - y_k|^2 / (2 sigma^2)); den_x = sum_k p_xk + c; Pt1[x] = 1 - c/den_x; P1[k] = sum_x p_xk/den_x;
+ * PX[k] = sum_x x * p_xk/den_x (row-major M x 3); *L = -sum_x log den_x + 1.5*N*log sigma^2. */
+int mi_cpd_estep(mi_ctx* ctx, const float* y_xyz, int m, const float* x_xyz, int n, float constant, float sigma2,
+                 float* p1, float* pt1, float* px, float* L);
+
+/* MStep (cpdcuda.cu:172-300 / coherentpointdrift.cpp:223-277).  scale, sigma2 are in/out as in the reference. */
+int mi_cpd_mstep(mi_ctx* ctx, const float* before_xyz, int m, const float* after_xyz, int n, const float* p1,
+                 const float* pt1, const float* px, int const_scale, float out_R9[9], float out_t3[3], float* scale,
+                 float* sigma2);
+
+/* ----------------------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py): per-kernel HIP-event timing on the context's own stream.
+ * -------------------------------------------------------------------------------------------------------------- */
+enum {
+    MI_KERNEL_NN = 0,          /* K1 brute-force nearest-neighbour search */
+    MI_KERNEL_MOMENTS = 1,     /* K2 fused gather + centroid/cross-covariance partial sums */
+    MI_KERNEL_SOLVE = 2,       /* K3 reduce + 3x3 SVD + compose */
+    MI_KERNEL_TRANSFORM = 3,   /* K4/K5 transform + error partial sums + key reset */
+    MI_KERNEL_FINALIZE = 4,    /* K6 error reduce + stop rule */
+    MI_KERNEL_ALLREDUCE = 5,   /* C1 RCCL packed-min all-reduce (multi-GPU) */
+    MI_KERNEL_CPD_DENOM = 6,   /* K7a column sums (den, Pt1, L) */
+    MI_KERNEL_CPD_CONTRACT = 7,/* K7b P~.[X|1] contraction (MFMA) */
+    MI_KERNEL_CPD_MSTEP = 8,   /* K8 weighted moments + solve */
+    MI_KERNEL_COUNT = 9
+};
+int mi_profile_enable(mi_ctx* ctx, int enable);
+int mi_profile_reset(mi_ctx* ctx);
+/* total_ms = sum of event-timed durations of that kernel since the last reset; launches = how many. */
+int mi_profile_get(mi_ctx* ctx, int kernel, double* total_ms, long long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_SLAM_H */

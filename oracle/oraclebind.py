@@ -1,0 +1,192 @@
+"""TEST INFRASTRUCTURE ONLY.  ctypes binding of oracle/liboracle.so (the plain-C restatement, oracle/slam_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+DIST_CPU, DIST_FMA = 0, 1
+COMPOSE_CPU_ADDITIVE, COMPOSE_EXACT = 0, 1
+
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int)
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("eps", C.c_float), ("max_distance_squared", C.c_float), ("max_iterations", C.c_int),
+                ("threads", C.c_int), ("dist_mode", C.c_int), ("compose_mode", C.c_int),
+                ("abort_on_increase", C.c_int), ("filter_pairs", C.c_int)]
+
+
+class CpdParams(C.Structure):
+    _fields_ = [("eps", C.c_float), ("weight", C.c_float), ("const_scale", C.c_int), ("max_iterations", C.c_int),
+                ("tolerance", C.c_float)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.oracle_mse_indexed.restype = C.c_float
+        _lib.oracle_cpd_sigma_squared.restype = C.c_float
+        _lib.oracle_cpd_constant.restype = C.c_float
+        _lib.oracle_filter_pairs.restype = C.c_int
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_i)
+
+
+def _cloud(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] == 3
+    return a
+
+
+def _col9(R):
+    return np.ascontiguousarray(np.asarray(R, np.float32).T).reshape(9)
+
+
+def _from_col9(r):
+    return r.reshape(3, 3).T.copy()
+
+
+def nn_search(before, after, threads=0, dist_mode=DIST_CPU):
+    before, after = _cloud(before), _cloud(after)
+    n, m = before.shape[0], after.shape[0]
+    idx = np.empty(n, np.int32)
+    d2 = np.empty(n, np.float32)
+    lib().oracle_nn_search(_fp(before), n, _fp(after), m, threads, dist_mode, _ip(idx), _fp(d2))
+    return idx, d2
+
+
+def filter_pairs(d2, max_distance_squared):
+    d2 = np.ascontiguousarray(d2, np.float32)
+    ib = np.empty(len(d2), np.int32)
+    k = lib().oracle_filter_pairs(_fp(d2), len(d2), C.c_float(max_distance_squared), _ip(ib))
+    return ib[:k].copy()
+
+
+def jacobi_svd3(A):
+    a = np.ascontiguousarray(A, np.float32).reshape(9)
+    u = np.empty(9, np.float32)
+    s = np.empty(3, np.float32)
+    v = np.empty(9, np.float32)
+    lib().oracle_jacobi_svd3(_fp(a), _fp(u), _fp(s), _fp(v))
+    return u.reshape(3, 3), s, v.reshape(3, 3)
+
+
+def least_squares_svd(before_pts, after_pts):
+    before_pts, after_pts = _cloud(before_pts), _cloud(after_pts)
+    r = np.empty(9, np.float32)
+    t = np.empty(3, np.float32)
+    lib().oracle_least_squares_svd(_fp(before_pts), _fp(after_pts), before_pts.shape[0], _fp(r), _fp(t))
+    return _from_col9(r), t
+
+
+def transform_cloud(cloud, R, t, scale=None):
+    cloud = _cloud(cloud)
+    out = np.empty_like(cloud)
+    r = _col9(R)
+    tt = np.ascontiguousarray(t, np.float32)
+    lib().oracle_transform_cloud(_fp(cloud), cloud.shape[0], _fp(r), _fp(tt), C.c_float(1.0 if scale is None else scale),
+                                 0 if scale is None else 1, _fp(out))
+    return out
+
+
+def mse_indexed(before, after, ib, ia):
+    before, after = _cloud(before), _cloud(after)
+    ib = np.ascontiguousarray(ib, np.int32)
+    ia = np.ascontiguousarray(ia, np.int32)
+    return float(lib().oracle_mse_indexed(_fp(before), _fp(after), _ip(ib), _ip(ia), len(ib)))
+
+
+def icp(before, after, eps=1e-3, max_distance_squared=1000.0, max_iterations=-1, threads=0, dist_mode=DIST_CPU,
+        compose_mode=COMPOSE_CPU_ADDITIVE, abort_on_increase=False, filter_pairs=True, trace_cap=0):
+    before, after = _cloud(before), _cloud(after)
+    p = IcpParams(eps, max_distance_squared, max_iterations, threads, dist_mode, compose_mode,
+                  1 if abort_on_increase else 0, 1 if filter_pairs else 0)
+    r = np.empty(9, np.float32)
+    t = np.empty(3, np.float32)
+    it = C.c_int(0)
+    err = C.c_float(0)
+    trace = np.zeros((max(trace_cap, 1), 14), np.float32)
+    tl = C.c_int(0)
+    lib().oracle_icp(_fp(before), before.shape[0], _fp(after), after.shape[0], C.byref(p), _fp(r), _fp(t),
+                     C.byref(it), C.byref(err), _fp(trace) if trace_cap else None, trace_cap, C.byref(tl))
+    out = (_from_col9(r), t, it.value, err.value)
+    if trace_cap:
+        return out + (trace[:min(tl.value, trace_cap)].copy(),)
+    return out
+
+
+def cpd_sigma_squared(before, after):
+    before, after = _cloud(before), _cloud(after)
+    return float(lib().oracle_cpd_sigma_squared(_fp(before), before.shape[0], _fp(after), after.shape[0]))
+
+
+def cpd_constant(sigma_squared, weight, m_before, n_after):
+    return float(lib().oracle_cpd_constant(C.c_float(sigma_squared), C.c_float(weight), m_before, n_after))
+
+
+def cpd_estep(transformed, after, constant, sigma_squared):
+    transformed, after = _cloud(transformed), _cloud(after)
+    m, n = transformed.shape[0], after.shape[0]
+    p1 = np.empty(m, np.float32)
+    pt1 = np.empty(n, np.float32)
+    px = np.empty((m, 3), np.float32)
+    L = C.c_float(0)
+    lib().oracle_cpd_estep(_fp(transformed), m, _fp(after), n, C.c_float(constant), C.c_float(sigma_squared),
+                           _fp(p1), _fp(pt1), _fp(px), C.byref(L))
+    return p1, pt1, px, L.value
+
+
+def cpd_mstep(before, after, p1, pt1, px, const_scale, scale=1.0, sigma_squared=0.0):
+    before, after = _cloud(before), _cloud(after)
+    p1 = np.ascontiguousarray(p1, np.float32)
+    pt1 = np.ascontiguousarray(pt1, np.float32)
+    px = np.ascontiguousarray(px, np.float32)
+    r = np.eye(3, dtype=np.float32).reshape(9).copy()
+    t = np.zeros(3, np.float32)
+    s = C.c_float(scale)
+    s2 = C.c_float(sigma_squared)
+    lib().oracle_cpd_mstep(_fp(before), before.shape[0], _fp(after), after.shape[0], _fp(p1), _fp(pt1), _fp(px),
+                           1 if const_scale else 0, _fp(r), _fp(t), C.byref(s), C.byref(s2))
+    return _from_col9(r), t, s.value, s2.value
+
+
+def cpd(before, after, eps=1e-3, weight=0.3, const_scale=False, max_iterations=50, tolerance=1e-3, trace_cap=0):
+    before, after = _cloud(before), _cloud(after)
+    p = CpdParams(eps, weight, 1 if const_scale else 0, max_iterations, tolerance)
+    r = np.empty(9, np.float32)
+    t = np.empty(3, np.float32)
+    it = C.c_int(0)
+    err = C.c_float(0)
+    trace = np.zeros((max(trace_cap, 1), 16), np.float32)
+    tl = C.c_int(0)
+    lib().oracle_cpd(_fp(before), before.shape[0], _fp(after), after.shape[0], C.byref(p), _fp(r), _fp(t),
+                     C.byref(it), C.byref(err), _fp(trace) if trace_cap else None, trace_cap, C.byref(tl))
+    out = (_from_col9(r), t, it.value, err.value)
+    if trace_cap:
+        return out + (trace[:min(tl.value, trace_cap)].copy(),)
+    return out

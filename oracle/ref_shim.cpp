@@ -1,0 +1,192 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into, imported by or shipped with the product path.
+//
+// extern "C" entry points over the reference's own CPU implementation (source/cpu-slam + source/common),
+// compiled by oracle/Makefile from the sources where they lie under /root/reference into
+// oracle/_ref/libref_cpuslam.so.  Nothing here re-implements the algorithm: every function forwards to the
+// reference function named in its comment.  The only code of our own is the float-array <-> std::vector<Point_f>
+// marshalling and the clouds-from-config sequence, which calls the reference's own NormalizeCloud / std::shuffle on
+// Common::mtRandom / GetTransformedCloud in the order source/common/common.cpp:134-190 does (the assimp loader the
+// reference's LoadCloud needs ships only as a Windows .lib, so the raw points come in from our OBJ reader instead).
+#include <cstring>
+#include <vector>
+#include <random>
+#include <algorithm>
+
+#include "common.h"
+#include "basicicp.h"
+#include "coherentpointdrift.h"
+#include "cpdutils.h"
+
+using Common::Point_f;
+
+namespace Common {
+extern std::mt19937 mtRandom;      // source/common/common.cpp:14
+extern unsigned int randomSeed;    // source/common/common.cpp:13
+}
+
+namespace CoherentPointDrift {
+// external-linkage helpers declared at the top of source/cpu-slam/coherentpointdrift.cpp:14-42
+float CalculateSigmaSquared(const std::vector<Point_f>& cloudBefore, const std::vector<Point_f>& cloudAfter);
+Probabilities ComputePMatrix(const std::vector<Point_f>& cloudTransformed, const std::vector<Point_f>& cloudAfter,
+                             const float& constant, const float& sigmaSquared, const bool& doTruncate, float truncate);
+void MStep(const std::vector<Point_f>& cloudBefore, const std::vector<Point_f>& cloudAfter,
+           const Probabilities& probabilities, bool const_scale, glm::mat3* rotationMatrix,
+           glm::vec3* translationVector, float* scale, float* sigmaSquared);
+}
+
+namespace {
+std::vector<Point_f> to_cloud(const float* xyz, int n)
+{
+    std::vector<Point_f> c(n);
+    for (int i = 0; i < n; i++) c[i] = Point_f(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    return c;
+}
+void from_cloud(const std::vector<Point_f>& c, float* xyz)
+{
+    for (size_t i = 0; i < c.size(); i++) { xyz[3 * i] = c[i].x; xyz[3 * i + 1] = c[i].y; xyz[3 * i + 2] = c[i].z; }
+}
+// glm::mat3 is column-major m[col][row]; out9 is column-major too (out9[3*col+row]).
+void from_mat3(const glm::mat3& m, float* out9)
+{
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) out9[3 * c + r] = m[c][r];
+}
+glm::mat3 to_mat3(const float* in9)
+{
+    glm::mat3 m;
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) m[c][r] = in9[3 * c + r];
+    return m;
+}
+}
+
+#define REF_API extern "C" __attribute__((visibility("default")))
+
+// Clouds-from-config for the "same file, explicit transformation" case: common.cpp:134-190.
+// rot9_rowmajor is the JSON "rotation" array as written in the config file (configparser.cpp:139-141 stores
+// rotationMatrix[y][x] = rotation[x*3+y], i.e. the JSON is row-major), scale multiplies it (configparser.cpp:147).
+REF_API void ref_clouds_from_config(const float* raw_xyz, int n, int has_spread, float spread, unsigned seed,
+                                    const float* rot9_rowmajor, const float* trans3, float scale,
+                                    float* before_xyz, float* after_xyz)
+{
+    Common::randomSeed = seed;                                   // common.cpp:136
+    Common::mtRandom = std::mt19937{ seed };                     // common.cpp:137
+    auto before = to_cloud(raw_xyz, n);
+    auto after = before;                                         // common.cpp:142 (sameClouds)
+    if (has_spread) {                                            // common.cpp:158-163
+        before = Common::NormalizeCloud(before, spread);
+        after = Common::NormalizeCloud(after, spread);
+    }
+    std::shuffle(before.begin(), before.end(), Common::mtRandom); // common.cpp:166
+    std::shuffle(after.begin(), after.end(), Common::mtRandom);   // common.cpp:167
+    glm::mat3 R;
+    for (int x = 0; x < 3; x++) for (int y = 0; y < 3; y++) R[y][x] = rot9_rowmajor[x * 3 + y];
+    R = scale * R;
+    glm::vec3 t(trans3[0], trans3[1], trans3[2]);
+    after = Common::GetTransformedCloud(after, R, t);            // common.cpp:187-190
+    from_cloud(before, before_xyz);
+    from_cloud(after, after_xyz);
+}
+
+// Common::GetCorrespondingPoints  common.cpp:509-515 (sequential :399-439, parallel :441-507).
+// Returns the number of kept pairs; idx_before/idx_after hold the kept pair indices.
+REF_API int ref_corresponding_points(const float* before_xyz, int n, const float* after_xyz, int m,
+                                     float max_distance_squared, int parallel, int* idx_before, int* idx_after)
+{
+    auto t = Common::GetCorrespondingPoints(to_cloud(before_xyz, n), to_cloud(after_xyz, m),
+                                            max_distance_squared, parallel != 0);
+    const auto& ib = std::get<2>(t);
+    const auto& ia = std::get<3>(t);
+    std::memcpy(idx_before, ib.data(), ib.size() * sizeof(int));
+    std::memcpy(idx_after, ia.data(), ia.size() * sizeof(int));
+    return static_cast<int>(ib.size());
+}
+
+// Common::LeastSquaresSVD  common.cpp:517-552 on two clouds already in corresponding order.
+REF_API void ref_least_squares_svd(const float* before_xyz, const float* after_xyz, int n, float* rot9_colmajor, float* trans3)
+{
+    auto r = Common::LeastSquaresSVD(to_cloud(before_xyz, n), to_cloud(after_xyz, n));
+    from_mat3(r.first, rot9_colmajor);
+    trans3[0] = r.second.x; trans3[1] = r.second.y; trans3[2] = r.second.z;
+}
+
+// Common::GetTransformedCloud (R, t)  common.cpp:219-224
+REF_API void ref_transform_cloud(const float* xyz, int n, const float* rot9_colmajor, const float* trans3, float* out_xyz)
+{
+    auto c = Common::GetTransformedCloud(to_cloud(xyz, n), to_mat3(rot9_colmajor), glm::vec3(trans3[0], trans3[1], trans3[2]));
+    from_cloud(c, out_xyz);
+}
+
+// Common::GetMeanSquaredError (indexed)  common.cpp:259-268
+REF_API float ref_mse_indexed(const float* before_xyz, int n, const float* after_xyz, int m,
+                              const int* idx_before, const int* idx_after, int k)
+{
+    std::vector<int> ib(idx_before, idx_before + k), ia(idx_after, idx_after + k);
+    return Common::GetMeanSquaredError(to_cloud(before_xyz, n), to_cloud(after_xyz, m), ib, ia);
+}
+
+// BasicICP::GetBasicICPTransformationMatrix  cpu-slam/basicicp.cpp:23-61
+REF_API void ref_icp(const float* before_xyz, int n, const float* after_xyz, int m, float eps,
+                     float max_distance_squared, int max_iterations, int parallel,
+                     float* rot9_colmajor, float* trans3, int* iterations, float* error)
+{
+    auto r = BasicICP::GetBasicICPTransformationMatrix(to_cloud(before_xyz, n), to_cloud(after_xyz, m), iterations, error,
+                                                       eps, max_distance_squared, max_iterations, parallel != 0);
+    from_mat3(r.first, rot9_colmajor);
+    trans3[0] = r.second.x; trans3[1] = r.second.y; trans3[2] = r.second.z;
+}
+
+// CoherentPointDrift::CalculateSigmaSquared  cpu-slam/coherentpointdrift.cpp:126-139
+REF_API float ref_cpd_sigma_squared(const float* before_xyz, int m, const float* after_xyz, int n)
+{
+    return CoherentPointDrift::CalculateSigmaSquared(to_cloud(before_xyz, m), to_cloud(after_xyz, n));
+}
+
+// CoherentPointDrift::ComputePMatrix (exact Gaussian E-step, no truncation)  cpu-slam/coherentpointdrift.cpp:168-221
+// p1[m], pt1[n], px[m*3] row-major (px.row(k) = (x,y,z)), *L = Probabilities::error.
+REF_API void ref_cpd_estep(const float* transformed_xyz, int m, const float* after_xyz, int n, float constant,
+                           float sigma_squared, float* p1, float* pt1, float* px, float* L)
+{
+    auto p = CoherentPointDrift::ComputePMatrix(to_cloud(transformed_xyz, m), to_cloud(after_xyz, n), constant,
+                                                sigma_squared, false, -1.0f);
+    for (int k = 0; k < m; k++) {
+        p1[k] = p.p1(k);
+        for (int d = 0; d < 3; d++) px[3 * k + d] = p.px(k, d);
+    }
+    for (int x = 0; x < n; x++) pt1[x] = p.pt1(x);
+    *L = p.error;
+}
+
+// CoherentPointDrift::MStep  cpu-slam/coherentpointdrift.cpp:223-277
+// scale and sigma_squared are in/out exactly as in the reference (scale is left untouched when const_scale).
+REF_API void ref_cpd_mstep(const float* before_xyz, int m, const float* after_xyz, int n, const float* p1,
+                           const float* pt1, const float* px, int const_scale, float* rot9_colmajor, float* trans3,
+                           float* scale, float* sigma_squared)
+{
+    CoherentPointDrift::Probabilities p;
+    p.p1 = Eigen::VectorXf(m);
+    p.pt1 = Eigen::VectorXf(n);
+    p.px = Eigen::MatrixXf(m, 3);
+    for (int k = 0; k < m; k++) {
+        p.p1(k) = p1[k];
+        for (int d = 0; d < 3; d++) p.px(k, d) = px[3 * k + d];
+    }
+    for (int x = 0; x < n; x++) p.pt1(x) = pt1[x];
+    p.error = 0.f;
+    glm::mat3 R = to_mat3(rot9_colmajor);
+    glm::vec3 t(trans3[0], trans3[1], trans3[2]);
+    CoherentPointDrift::MStep(to_cloud(before_xyz, m), to_cloud(after_xyz, n), p, const_scale != 0, &R, &t, scale, sigma_squared);
+    from_mat3(R, rot9_colmajor);
+    trans3[0] = t.x; trans3[1] = t.y; trans3[2] = t.z;
+}
+
+// CoherentPointDrift::GetRigidCPDTransformationMatrix  cpu-slam/coherentpointdrift.cpp:69-124
+// fgt: 0 = None, 1 = Full, 2 = Hybrid (enumerators.h:18-23). Returns scale*R in rot9 (coherentpointdrift.cpp:123).
+REF_API void ref_cpd(const float* before_xyz, int m, const float* after_xyz, int n, float eps, float weight,
+                     int const_scale, int max_iterations, float tolerance, int fgt, float ratio_of_far_field,
+                     float order_of_truncation, float* rot9_colmajor, float* trans3, int* iterations, float* error)
+{
+    auto r = CoherentPointDrift::GetRigidCPDTransformationMatrix(
+        to_cloud(before_xyz, m), to_cloud(after_xyz, n), iterations, error, eps, weight, const_scale != 0,
+        max_iterations, tolerance, static_cast<Common::ApproximationType>(fgt), ratio_of_far_field, order_of_truncation);
+    from_mat3(r.first, rot9_colmajor);
+    trans3[0] = r.second.x; trans3[1] = r.second.y; trans3[2] = r.second.z;
+}

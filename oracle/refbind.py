@@ -1,0 +1,149 @@
+"""TEST INFRASTRUCTURE ONLY.  ctypes binding of oracle/_ref/libref_cpuslam.so -- the reference's own cpu-slam code
+compiled by oracle/Makefile (see oracle/ref_shim.cpp for the reference function behind each call).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_ref", "libref_cpuslam.so")
+
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int)
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ref_mse_indexed.restype = C.c_float
+        _lib.ref_cpd_sigma_squared.restype = C.c_float
+        _lib.ref_corresponding_points.restype = C.c_int
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_i)
+
+
+def _cloud(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] == 3
+    return a
+
+
+def clouds_from_config(raw, spread, seed, rot9_rowmajor, trans3, scale=1.0):
+    raw = _cloud(raw)
+    n = raw.shape[0]
+    before = np.empty((n, 3), np.float32)
+    after = np.empty((n, 3), np.float32)
+    rot = np.ascontiguousarray(rot9_rowmajor, dtype=np.float32)
+    tr = np.ascontiguousarray(trans3, dtype=np.float32)
+    lib().ref_clouds_from_config(_fp(raw), n, 0 if spread is None else 1, C.c_float(spread or 0.0), C.c_uint(seed),
+                                 _fp(rot), _fp(tr), C.c_float(scale), _fp(before), _fp(after))
+    return before, after
+
+
+def corresponding_points(before, after, max_distance_squared, parallel=True):
+    before, after = _cloud(before), _cloud(after)
+    n, m = before.shape[0], after.shape[0]
+    ib = np.empty(n, np.int32)
+    ia = np.empty(n, np.int32)
+    k = lib().ref_corresponding_points(_fp(before), n, _fp(after), m, C.c_float(max_distance_squared),
+                                       1 if parallel else 0, _ip(ib), _ip(ia))
+    return ib[:k].copy(), ia[:k].copy()
+
+
+def least_squares_svd(before, after):
+    before, after = _cloud(before), _cloud(after)
+    assert before.shape == after.shape
+    r = np.empty(9, np.float32)
+    t = np.empty(3, np.float32)
+    lib().ref_least_squares_svd(_fp(before), _fp(after), before.shape[0], _fp(r), _fp(t))
+    return r.reshape(3, 3).T.copy(), t  # column-major -> R[row, col]
+
+
+def transform_cloud(cloud, R, t):
+    cloud = _cloud(cloud)
+    r = np.ascontiguousarray(np.asarray(R, np.float32).T).reshape(9)  # to column-major
+    tt = np.ascontiguousarray(t, dtype=np.float32)
+    out = np.empty_like(cloud)
+    lib().ref_transform_cloud(_fp(cloud), cloud.shape[0], _fp(r), _fp(tt), _fp(out))
+    return out
+
+
+def mse_indexed(before, after, ib, ia):
+    before, after = _cloud(before), _cloud(after)
+    ib = np.ascontiguousarray(ib, np.int32)
+    ia = np.ascontiguousarray(ia, np.int32)
+    return float(lib().ref_mse_indexed(_fp(before), before.shape[0], _fp(after), after.shape[0], _ip(ib), _ip(ia), len(ib)))
+
+
+def icp(before, after, eps=1e-3, max_distance_squared=1000.0, max_iterations=-1, parallel=True):
+    before, after = _cloud(before), _cloud(after)
+    r = np.empty(9, np.float32)
+    t = np.empty(3, np.float32)
+    it = C.c_int(0)
+    err = C.c_float(0)
+    lib().ref_icp(_fp(before), before.shape[0], _fp(after), after.shape[0], C.c_float(eps),
+                  C.c_float(max_distance_squared), max_iterations, 1 if parallel else 0, _fp(r), _fp(t),
+                  C.byref(it), C.byref(err))
+    return r.reshape(3, 3).T.copy(), t, it.value, err.value
+
+
+def cpd_sigma_squared(before, after):
+    before, after = _cloud(before), _cloud(after)
+    return float(lib().ref_cpd_sigma_squared(_fp(before), before.shape[0], _fp(after), after.shape[0]))
+
+
+def cpd_estep(transformed, after, constant, sigma_squared):
+    transformed, after = _cloud(transformed), _cloud(after)
+    m, n = transformed.shape[0], after.shape[0]
+    p1 = np.empty(m, np.float32)
+    pt1 = np.empty(n, np.float32)
+    px = np.empty((m, 3), np.float32)
+    L = C.c_float(0)
+    lib().ref_cpd_estep(_fp(transformed), m, _fp(after), n, C.c_float(constant), C.c_float(sigma_squared),
+                        _fp(p1), _fp(pt1), _fp(px), C.byref(L))
+    return p1, pt1, px, L.value
+
+
+def cpd_mstep(before, after, p1, pt1, px, const_scale, scale=1.0, sigma_squared=0.0):
+    before, after = _cloud(before), _cloud(after)
+    p1 = np.ascontiguousarray(p1, np.float32)
+    pt1 = np.ascontiguousarray(pt1, np.float32)
+    px = np.ascontiguousarray(px, np.float32)
+    r = np.eye(3, dtype=np.float32).reshape(9).copy()
+    t = np.zeros(3, np.float32)
+    s = C.c_float(scale)
+    s2 = C.c_float(sigma_squared)
+    lib().ref_cpd_mstep(_fp(before), before.shape[0], _fp(after), after.shape[0], _fp(p1), _fp(pt1), _fp(px),
+                        1 if const_scale else 0, _fp(r), _fp(t), C.byref(s), C.byref(s2))
+    return r.reshape(3, 3).T.copy(), t, s.value, s2.value
+
+
+def cpd(before, after, eps=1e-3, weight=0.3, const_scale=False, max_iterations=50, tolerance=1e-3, fgt=0,
+        ratio_of_far_field=10.0, order_of_truncation=8.0):
+    before, after = _cloud(before), _cloud(after)
+    r = np.empty(9, np.float32)
+    t = np.empty(3, np.float32)
+    it = C.c_int(0)
+    err = C.c_float(0)
+    lib().ref_cpd(_fp(before), before.shape[0], _fp(after), after.shape[0], C.c_float(eps), C.c_float(weight),
+                  1 if const_scale else 0, max_iterations, C.c_float(tolerance), fgt, C.c_float(ratio_of_far_field),
+                  C.c_float(order_of_truncation), _fp(r), _fp(t), C.byref(it), C.byref(err))
+    return r.reshape(3, 3).T.copy(), t, it.value, err.value

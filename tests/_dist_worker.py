@@ -1,0 +1,80 @@
+"""Worker of tests/test_dist_protocol.py: one rank of the target-sharded correspondence search, on CPU over gloo.
+
+Per-shard compute is the oracle (test infrastructure); what is under test is the PROTOCOL the HIP path uses across GPUs --
+the product's own shard ranges (mi_shard_range) and key packing (mi_pack_key), a MIN all-reduce of the packed keys, and the
+owner-accumulates rule for the moments and error sums followed by a SUM all-reduce -- checked against the unsharded result.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import load_package  # noqa: E402
+
+from oracle import oraclebind as O  # noqa: E402
+
+
+def moments(src, tgt, idx, mask):
+    b = src[mask].astype(np.float64)
+    a = tgt[idx[mask]].astype(np.float64)
+    return np.concatenate([[mask.sum()], b.sum(0), a.sum(0), (a[:, :, None] * b[:, None, :]).sum(0).reshape(9)])
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    capi = load_package().capi
+
+    rng = np.random.default_rng(1234)          # same data on every rank
+    n, m = 700, 1003
+    src = rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+    tgt = rng.uniform(-5, 5, (m, 3)).astype(np.float32)
+    tgt[600:900] = tgt[100:400]                # duplicates straddling the shard boundaries: lowest GLOBAL index must win
+    src[:50] = tgt[100:150]
+
+    lo, hi = capi.shard_range(m, rank, world)
+    lidx, ld2 = O.nn_search(src, tgt[lo:hi], threads=1)
+    keys = np.array([capi.pack_key(d, i + lo) for d, i in zip(ld2, lidx)], dtype=np.uint64)
+    assert np.all(keys < (1 << 63))            # d2 >= 0: sign bit clear, so int64 MIN orders like uint64 MIN
+    t = torch.from_numpy(keys.astype(np.int64))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    merged = t.numpy().astype(np.uint64)
+    gidx = (merged & np.uint64(0xFFFFFFFF)).astype(np.int32)
+    gd2 = (merged >> np.uint64(32)).astype(np.uint32).view(np.float32)
+
+    ridx, rd2 = O.nn_search(src, tgt, threads=1)
+    assert np.array_equal(gidx, ridx), "merged argmin differs from the unsharded search"
+    assert np.array_equal(gd2.view(np.uint32), rd2.view(np.uint32))
+
+    # owner-accumulates: the rank whose shard holds the winner adds the pair
+    kept = gd2 < np.float32(30.0)
+    mine = (gidx >= lo) & (gidx < hi)
+    local = moments(src, tgt, gidx, kept & mine)
+    tm = torch.from_numpy(local.copy())
+    dist.all_reduce(tm, op=dist.ReduceOp.SUM)
+    full = moments(src, tgt, ridx, kept)
+    assert tm[0].item() == full[0] == kept.sum()          # every kept pair counted exactly once
+    assert np.allclose(tm.numpy(), full, rtol=1e-12, atol=1e-9)
+
+    # error sums of the kept pairs against a transformed source
+    R = np.array([[0.36, 0.47, -0.8], [-0.8, 0.6, 0.0], [0.48, 0.64, 0.6]], np.float32)
+    cur = O.transform_cloud(src, R, np.array([0.1, 0.2, 0.3], np.float32))
+    sel = kept & mine
+    diff = tgt[gidx[sel]].astype(np.float64) - cur[sel]
+    te = torch.tensor([float((diff ** 2).sum()), float(sel.sum())], dtype=torch.float64)
+    dist.all_reduce(te, op=dist.ReduceOp.SUM)
+    dfull = tgt[ridx[kept]].astype(np.float64) - cur[kept]
+    assert abs(te[0].item() - (dfull ** 2).sum()) < 1e-9 * max(1.0, (dfull ** 2).sum())
+    assert te[1].item() == kept.sum()
+
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print("DIST_PROTOCOL_OK world=%d" % world)
+
+
+if __name__ == "__main__":
+    main()

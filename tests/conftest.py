@@ -1,0 +1,100 @@
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def load_package():
+    """The product package lives in `cuda-slam_amd/` (hyphen), so it is imported by path as `cuda_slam_amd`."""
+    if "cuda_slam_amd" in sys.modules:
+        return sys.modules["cuda_slam_amd"]
+    root = os.path.join(ROOT, "cuda-slam_amd")
+    spec = importlib.util.spec_from_file_location("cuda_slam_amd", os.path.join(root, "__init__.py"),
+                                                  submodule_search_locations=[root])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["cuda_slam_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def capi():
+    return load_package().capi
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oraclebind
+    oraclebind.lib()
+    return oraclebind
+
+
+@pytest.fixture(scope="session")
+def ref():
+    """The reference's own cpu-slam code (oracle/_ref, built in the build container and shipped prebuilt)."""
+    from oracle import refbind
+    if not refbind.available():
+        pytest.skip("oracle/_ref/libref_cpuslam.so not built (needs /root/reference: make -C oracle ref)")
+    refbind.lib()
+    return refbind
+
+
+@pytest.fixture(scope="session")
+def ctx(capi):
+    """One device context for the whole GPU session (the HIP path; there is no fallback -- this raises without a GPU)."""
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+class Golden:
+    def npz(self, name):
+        return np.load(os.path.join(GOLD, name))   # allow_pickle stays False
+
+    def json(self, name):
+        with open(os.path.join(GOLD, name)) as f:
+            return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return Golden()
+
+
+@pytest.fixture(scope="session")
+def bunny(golden):
+    z = golden.npz("bunny_clouds.npz")
+    return z["before"], z["after"]
+
+
+def synth_cloud(n, seed=666, m=None):
+    """SURVEY 8d synthetic recipe (same as oracle/make_golden.py): uniform [-5,5]^3, 0.2 rad about (1,2,3)/sqrt14,
+    translation 10*(1,1,1)/sqrt3, independently permuted target."""
+    rng = np.random.default_rng(seed)
+    before = rng.uniform(-5.0, 5.0, size=(n, 3)).astype(np.float32)
+    axis = np.array([1.0, 2.0, 3.0]) / np.sqrt(14.0)
+    ang = 0.2
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    Rm = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+    t = 10.0 * np.ones(3) / np.sqrt(3.0)
+    perm = rng.permutation(n)
+    after = (before[perm].astype(np.float64) @ Rm.T + t).astype(np.float32)
+    if m is not None:
+        after = after[:m]
+    return before, after, Rm.astype(np.float32), t.astype(np.float32)
+
+
+def frob(R1, t1, R2, t2):
+    return float(np.sqrt(((np.asarray(R1, np.float64) - R2) ** 2).sum() + ((np.asarray(t1, np.float64) - t2) ** 2).sum()))

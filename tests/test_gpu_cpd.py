@@ -1,0 +1,101 @@
+"""GPU suite: rigid CPD (exact Gaussian P) through the C ABI against the oracle and the reference's golden vectors.
+
+Tolerances (floating point, written per quantity):
+  E-step  P1, Pt1, PX: 2e-5 relative to the array's max -- fp32 sums in a different order (chunked / MFMA fma chain vs the
+          reference's sequential fp32 loop) and exp() within ~2 ulp of glibc's expf;
+  M-step  R 1e-5, t 1e-4, scale 1e-4 rel; sigma^2 1e-3 rel + 5e-5 abs (a cancelling difference, see test_oracle_golden);
+  run     iteration count exact, s*R|t within 1e-4 Frobenius of cpu-slam (north_star) when started from cpu-slam's sigma^2.
+"""
+import numpy as np
+import pytest
+
+from conftest import frob
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def test_sigma_squared_is_the_exact_value(ctx, capi, bunny):
+    before, after = bunny
+    s2 = ctx.cpd_sigma_squared(before, after)
+    bd, ad = before.astype(np.float64), after.astype(np.float64)
+    n, m = len(ad), len(bd)
+    exact = (m * (ad ** 2).sum() + n * (bd ** 2).sum() - 2 * (ad.sum(0) * bd.sum(0)).sum()) / (3.0 * n * m)
+    assert abs(s2 - exact) < 1e-6 * exact
+    assert abs(exact - 12.943) < 1e-2          # NOT cpu-slam's saturated 3.604 (see mi_slam.h, sigma2_init)
+
+
+@pytest.mark.parametrize("mfma", ["0", "1"])
+def test_estep_matches_golden(ctx, capi, golden, bunny, monkeypatch, mfma):
+    monkeypatch.setenv("MISLAM_CPD_MFMA", mfma)
+    before, after = bunny
+    g = golden.json("bunny_cpd.json")
+    e = golden.npz("bunny_cpd_estep0.npz")
+    p1, pt1, px, L = ctx.cpd_estep(before, after, g["constant"], g["sigma2_init"])
+    assert rel(p1, e["p1"]) < 2e-5
+    assert rel(pt1, e["pt1"]) < 2e-5
+    assert rel(px, e["px"]) < 2e-5
+    assert abs(L - g["L0"]) < 1e-5 * abs(g["L0"])
+
+
+@pytest.mark.parametrize("mfma", ["0", "1"])
+@pytest.mark.parametrize("m,n,sigma2", [(300, 350, 8.0), (1000, 17, 0.5), (65, 1300, 0.01), (1, 1, 1.0), (4097, 4099, 0.05)])
+def test_estep_random_matches_oracle(ctx, capi, oracle, monkeypatch, mfma, m, n, sigma2):
+    monkeypatch.setenv("MISLAM_CPD_MFMA", mfma)
+    rng = np.random.default_rng(m * 31 + n)
+    y = rng.uniform(-5, 5, (m, 3)).astype(np.float32)
+    x = (y[rng.integers(0, m, n)] + rng.normal(scale=0.2, size=(n, 3))).astype(np.float32)
+    c = oracle.cpd_constant(sigma2, 0.3, m, n)
+    p1, pt1, px, L = ctx.cpd_estep(y, x, c, sigma2)
+    o1, ot1, ox, oL = oracle.cpd_estep(y, x, c, sigma2)
+    assert rel(p1, o1) < 2e-5 and rel(pt1, ot1) < 2e-5 and rel(px, ox) < 2e-5
+    assert abs(L - oL) < 1e-5 * abs(oL) + 1e-4
+
+
+@pytest.mark.parametrize("const_scale,key", [(False, "mstep0_scale_free"), (True, "mstep0_const_scale")])
+def test_mstep_matches_golden(ctx, capi, golden, bunny, const_scale, key):
+    before, after = bunny
+    g = golden.json("bunny_cpd.json")[key]
+    e = golden.npz("bunny_cpd_estep0.npz")
+    R, t, s, s2 = ctx.cpd_mstep(before, after, e["p1"], e["pt1"], e["px"], const_scale)
+    assert np.abs(R - np.array(g["R"])).max() < 1e-5
+    assert np.abs(t - np.array(g["t"])).max() < 1e-4
+    assert abs(s - g["scale"]) < 1e-4 * g["scale"]
+    assert abs(s2 - g["sigma2"]) < 1e-3 * g["sigma2"] + 5e-5
+
+
+@pytest.mark.parametrize("const_scale,key", [(False, "final_scale_free"), (True, "final_const_scale")])
+def test_bunny_cpd_matches_cpu_slam(ctx, capi, golden, bunny, const_scale, key):
+    # cfg 4, started from cpu-slam's own sigma^2 so the EM trajectory is cpu-slam's
+    before, after = bunny
+    g = golden.json("bunny_cpd.json")
+    f = g[key]
+    p = capi.cpd_params(max_iterations=50, const_scale=1 if const_scale else 0, sigma2_init=g["sigma2_init"])
+    sR, t, scale, it, err = ctx.cpd_register(before, after, p)
+    assert it == f["iterations"]
+    assert frob(sR, t, f["sR"], f["t"]) < 1e-4
+    assert abs(err - f["error"]) < 1e-4
+
+
+def test_bunny_cpd_with_device_sigma(ctx, capi, bunny):
+    # the library's own (exact) sigma^2 start: converges to the known transform of config/default.json
+    before, after = bunny
+    sR, t, scale, it, err = ctx.cpd_register(before, after, capi.cpd_params(max_iterations=60))
+    Rcfg = np.array([[0.36, 0.47, -0.8], [-0.8, 0.6, 0.0], [0.48, 0.64, 0.6]])
+    assert 0 < it <= 60 and err < 1e-3
+    assert np.abs(sR - Rcfg).max() < 2e-2 and np.abs(t - 1.0).max() < 2e-2
+
+
+def test_cpd_loop_quirks(ctx, capi, bunny):
+    before, after = bunny
+    # max_iterations = -1 (the parser default path, gpumain.cpp:14) runs NO iteration: coherentpointdrift.cpp:106
+    sR, t, scale, it, err = ctx.cpd_register(before[:500], after[:500], capi.cpd_params())
+    assert it == 0 and err == pytest.approx(1e5) and np.array_equal(sR, np.eye(3)) and np.all(t == 0)
+    # identical clouds: sigma^2 collapses, the loop stops on the sigma rule
+    sR, t, scale, it, err = ctx.cpd_register(before[:2000], before[:2000], capi.cpd_params(max_iterations=30, const_scale=1))
+    assert it >= 1 and np.abs(sR - np.eye(3)).max() < 1e-2 and np.abs(t).max() < 1e-2
+    with pytest.raises(capi.MiSlamError):
+        ctx.cpd_register(before[:0], after, capi.cpd_params(max_iterations=3))
