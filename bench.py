@@ -42,6 +42,20 @@ def synth_cloud(np, n, seed=666):
     return before, after
 
 
+def committed_traffic(workload):
+    """HBM bytes per NN launch from the committed rocprofv3 --pmc summary of this same command (profiles/), if there is one
+    for this workload: bench.py cannot run the counter passes itself (they need their own rocprofv3 runs)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_counters.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload") == workload and "nn_bruteforce_kernel" in d:
+            return d["nn_bruteforce_kernel"].get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
+    return None, None
+
+
 def cpu_baseline(np, before, after, budget_pairs=4.0e10):
     """The reference's cpu-slam correspondence search (>99 % of its iteration) on a bounded row sample."""
     from oracle import refbind, oraclebind
@@ -141,6 +155,8 @@ def main():
         nn_ms, nn_n = prof["nn"]
         nn_avg_s = nn_ms / max(nn_n, 1) * 1e-3
         alg_bytes = 20.0 * n + 12.0 * m_local          # 12N source xyz + 8N packed key out + 12 M_local target xyz
+        traffic, traffic_src = (committed_traffic("icp_synthetic_uniform_n%d" % n) if world == 1 and args.dist_mode == 0
+                                else (None, None))
         achieved_gbs = alg_bytes / nn_avg_s / 1e9
         pairs_per_s = n * float(m_local) / nn_avg_s
         lane_ops = pairs_per_s * OPS_PER_PAIR[args.dist_mode]
@@ -153,7 +169,8 @@ def main():
                        "compose": "cpu_additive", "parallelism": "target-shard x%d, RCCL u64-min all-reduce" % world,
                        "error_after_steps": err},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "nn_bruteforce_kernel",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "nn_bruteforce_kernel",
                          "avg_launch_ms": nn_avg_s * 1e3, "launches": nn_n, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "brute force is fp32-VALU-bound, see 'valu'; compulsory HBM bytes are ~4 us of bandwidth"},
             "valu": {"bound": "fp32-valu-issue", "achieved": lane_ops, "peak": VALU_LANE_OPS_PEAK, "unit": "lane-ops/s",

@@ -261,9 +261,13 @@ NnPlan plan_nn(const mi_ctx* ctx, int n, int m_local)
     const int n_src_blocks = round_up(std::max(n, 1), 256 * p.R) / (256 * p.R);
     const int target_wgs = env_int("MISLAM_NN_WGS", ctx->cu_count * 8);
     int chunks = (target_wgs + n_src_blocks - 1) / n_src_blocks;
+    // a chunk should fit an XCD's L2 next to everything else it holds: <= 2 MB of target xyz (12 B/point)
+    const int l2_chunks = (int)(((long long)std::max(m_local, 1) * 12 + (2 << 20) - 1) / (2 << 20));
+    chunks = std::max(chunks, l2_chunks);
     const int max_chunks = std::max(1, std::min(NN_MAX_CHUNKS, m_local / (NN_TARGET_BLOCK * 4)));
     chunks = std::max(1, std::min(chunks, max_chunks));
-    if (chunks > 8) chunks = std::min(round_up(chunks, 8), std::max(8, max_chunks / 8 * 8));
+    // multiples of 8 get the XCD-pinned block mapping of K1
+    if (chunks > 1 && max_chunks >= 8) chunks = std::min(round_up(chunks, 8), max_chunks / 8 * 8);
     const int forced = env_int("MISLAM_NN_CHUNKS", 0);
     if (forced > 0) chunks = std::min(forced, NN_MAX_CHUNKS);
     p.chunk_len = round_up((std::max(m_local, 1) + chunks - 1) / chunks, NN_TARGET_BLOCK);

@@ -66,11 +66,21 @@ __global__ __launch_bounds__(256) void nn_bruteforce_kernel(
 {
     if (done_flag != nullptr && *done_flag != 0) return;
 
-    // XCD-aware decomposition: consecutive block ids round-robin over the 8 XCDs, so "chunk = id % n_chunks" with
-    // n_chunks a multiple of 8 keeps every XCD on its own 1/8 of the target stream (private L2 stays hot); the source
-    // block is the slow index.  Any other n_chunks is merely not XCD-aligned (speed only).
-    const int chunk = blockIdx.x % n_chunks;
-    const int sblk = blockIdx.x / n_chunks;
+    // XCD-aware decomposition.  Consecutive block ids are dealt round-robin over the 8 XCDs, each with a private 4 MiB L2.
+    // With n_chunks a multiple of 8, XCD x = id % 8 owns the chunks {x, x+8, ...} and walks them ONE AT A TIME: all source
+    // blocks pass over chunk x before any block touches chunk x+8, so the target bytes an XCD is streaming (<= ~2 MB, see
+    // plan_nn) stay resident in its L2 and are fetched from HBM/MALL once instead of once per source block.
+    // Placement only affects speed/traffic, never the result; other chunk counts use the plain mapping.
+    int chunk, sblk;
+    if ((n_chunks & 7) == 0) {
+        const int n_sblk = gridDim.x / n_chunks;
+        const int local = blockIdx.x >> 3;
+        chunk = ((local / n_sblk) << 3) + (blockIdx.x & 7);
+        sblk = local % n_sblk;
+    } else {
+        chunk = blockIdx.x % n_chunks;
+        sblk = blockIdx.x / n_chunks;
+    }
     const int src0 = sblk * (256 * R) + threadIdx.x;
 
     f32x2 px[R], py[R], pz[R];

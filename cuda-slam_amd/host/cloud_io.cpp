@@ -1,0 +1,200 @@
+#include "cloud_io.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
+#include <fstream>
+#include <numeric>
+#include <random>
+#include <sstream>
+
+namespace Common {
+namespace {
+
+std::mt19937 g_rng{0};
+
+Point_f add(const Point_f& a, const Point_f& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+Point_f sub(const Point_f& a, const Point_f& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+Point_f mul(const Point_f& a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+
+// sequential fp32 accumulate, then divide (common.cpp:281-284)
+Point_f center_of_mass(const CpuCloud& c)
+{
+    Point_f s;
+    for (const auto& p : c) s = add(s, p);
+    const float n = (float)c.size();
+    return {s.x / n, s.y / n, s.z / n};
+}
+
+float spread_of(const CpuCloud& c)   // largest axis-aligned extent (common.cpp:57-79)
+{
+    if (c.empty()) return 0.f;
+    Point_f lo = c[0], hi = c[0];
+    for (const auto& p : c) {
+        lo = {std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z)};
+        hi = {std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z)};
+    }
+    return std::max({hi.x - lo.x, hi.y - lo.y, hi.z - lo.z});
+}
+
+std::pair<Point_f, Point_f> bounds_of(const CpuCloud& c)
+{
+    Point_f lo = c.empty() ? Point_f{} : c[0], hi = lo;
+    for (const auto& p : c) {
+        lo = {std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z)};
+        hi = {std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z)};
+    }
+    return {lo, hi};
+}
+
+std::vector<int> random_permutation(int n)
+{
+    std::vector<int> p((size_t)n);
+    std::iota(p.begin(), p.end(), 0);
+    std::shuffle(p.begin(), p.end(), g_rng);
+    return p;
+}
+
+float rand_float(float lo, float hi) { return static_cast<float>(rand()) / RAND_MAX * (hi - lo) + lo; }   // testutils.cpp:7-11
+Point_f rand_point(const Point_f& lo, const Point_f& hi) { return {rand_float(lo.x, hi.x), rand_float(lo.y, hi.y), rand_float(lo.z, hi.z)}; }
+
+CpuCloud subcloud(const CpuCloud& c, int size)   // common.cpp:25-37
+{
+    if (size >= (int)c.size()) return c;
+    auto perm = random_permutation((int)c.size());
+    perm.resize((size_t)size);
+    CpuCloud out;
+    out.reserve((size_t)size);
+    for (int i : perm) out.push_back(c[(size_t)i]);
+    return out;
+}
+
+CpuCloud add_noise(const CpuCloud& c, float share, float intensity)   // common.cpp:97-119
+{
+    CpuCloud out = c;
+    const int n = (int)c.size();
+    const int affected = std::clamp((int)std::round(share * n), 0, n);
+    std::vector<char> flag((size_t)n, 0);
+    std::fill(flag.begin(), flag.begin() + affected, 1);
+    const auto perm = random_permutation(n);
+    std::vector<char> mask((size_t)n);
+    for (int i = 0; i < n; i++) mask[(size_t)i] = flag[(size_t)perm[(size_t)i]];
+    const float reach = spread_of(c) * intensity;
+    for (int i = 0; i < n; i++)
+        if (mask[(size_t)i]) out[(size_t)i] = add(out[(size_t)i], rand_point({-reach, -reach, -reach}, {reach, reach, reach}));
+    return out;
+}
+
+CpuCloud add_outliers(const CpuCloud& c, int count)   // common.cpp:121-132
+{
+    CpuCloud out = c;
+    const auto [lo, hi] = bounds_of(c);
+    for (int i = 0; i < count; i++) out.push_back(rand_point(lo, hi));
+    return out;
+}
+
+Mat3 rotation_about(const Vec3& axis_in, float angle)   // glm::rotate(mat4(1), angle, normalize(axis)) as a 3x3
+{
+    const float len = std::sqrt(axis_in.x * axis_in.x + axis_in.y * axis_in.y + axis_in.z * axis_in.z);
+    const Vec3 a{axis_in.x / len, axis_in.y / len, axis_in.z / len};
+    const float c = std::cos(angle), s = std::sin(angle), k = 1.f - c;
+    Mat3 R;
+    R[0][0] = c + k * a.x * a.x;       R[0][1] = k * a.x * a.y + s * a.z; R[0][2] = k * a.x * a.z - s * a.y;
+    R[1][0] = k * a.y * a.x - s * a.z; R[1][1] = c + k * a.y * a.y;       R[1][2] = k * a.y * a.z + s * a.x;
+    R[2][0] = k * a.z * a.x + s * a.y; R[2][1] = k * a.z * a.y - s * a.x; R[2][2] = c + k * a.z * a.z;
+    return R;
+}
+
+}  // namespace
+
+CpuCloud LoadCloud(const std::string& path)
+{
+    std::ifstream f(path);
+    CpuCloud verts, corners;
+    std::string line;
+    while (std::getline(f, line)) {
+        if (line.size() > 2 && line[0] == 'v' && line[1] == ' ') {
+            std::istringstream ss(line.substr(2));
+            Point_f p;
+            ss >> p.x >> p.y >> p.z;
+            verts.push_back(p);
+        } else if (line.size() > 2 && line[0] == 'f' && line[1] == ' ') {
+            std::istringstream ss(line.substr(2));
+            std::vector<long> ids;
+            std::string tok;
+            while (ss >> tok) {
+                const long i = std::strtol(tok.c_str(), nullptr, 10);   // "v", "v/vt", "v//vn", "v/vt/vn"
+                ids.push_back(i > 0 ? i - 1 : (long)verts.size() + i);
+            }
+            for (size_t k = 1; k + 1 < ids.size(); k++)
+                for (long id : {ids[0], ids[k], ids[k + 1]})
+                    if (id >= 0 && id < (long)verts.size()) corners.push_back(verts[(size_t)id]);
+        }
+    }
+    return corners.empty() ? verts : corners;
+}
+
+CpuCloud NormalizeCloud(const CpuCloud& cloud, float size)
+{
+    const Point_f center = center_of_mass(cloud);
+    CpuCloud aligned(cloud.size());
+    std::transform(cloud.begin(), cloud.end(), aligned.begin(), [&](const Point_f& p) { return sub(p, center); });
+    const float extent = spread_of(aligned);
+    if (std::abs(extent) < 1e-15) return cloud;
+    const float scale = size / extent;
+    const Point_f back = mul(center, -1.f);
+    for (auto& p : aligned) p = sub(mul(p, scale), back);
+    return aligned;
+}
+
+CpuCloud GetTransformedCloud(const CpuCloud& cloud, const Mat3& R, const Vec3& t)
+{
+    CpuCloud out(cloud.size());
+    for (size_t i = 0; i < cloud.size(); i++) {
+        const Vec3 r = R * Vec3{cloud[i].x, cloud[i].y, cloud[i].z};
+        out[i] = {r.x + t.x, r.y + t.y, r.z + t.z};
+    }
+    return out;
+}
+
+std::pair<CpuCloud, CpuCloud> GetCloudsFromConfig(const Configuration& config)
+{
+    const unsigned seed = config.RandomSeed ? (unsigned)*config.RandomSeed : std::random_device{}();
+    g_rng = std::mt19937{seed};
+
+    const bool same = config.BeforePath == config.AfterPath;
+    CpuCloud before = LoadCloud(config.BeforePath);
+    CpuCloud after = same ? before : LoadCloud(config.AfterPath);
+
+    if (config.CloudBeforeResize) before = subcloud(before, *config.CloudBeforeResize);
+    if (config.CloudAfterResize) after = subcloud(after, *config.CloudAfterResize);
+    if (config.CloudSpread) {
+        before = NormalizeCloud(before, *config.CloudSpread);
+        after = NormalizeCloud(after, *config.CloudSpread);
+    }
+    std::shuffle(before.begin(), before.end(), g_rng);
+    std::shuffle(after.begin(), after.end(), g_rng);
+    if (config.NoiseAffectedPointsBefore) before = add_noise(before, *config.NoiseAffectedPointsBefore, config.NoiseIntensityBefore);
+    if (config.NoiseAffectedPointsAfter) after = add_noise(after, *config.NoiseAffectedPointsAfter, config.NoiseIntensityAfter);
+    before = add_outliers(before, config.AdditionalOutliersBefore);
+    after = add_outliers(after, config.AdditionalOutliersAfter);
+
+    if (config.Transformation) {
+        return {before, GetTransformedCloud(after, config.Transformation->first, config.Transformation->second)};
+    }
+    if (config.TransformationParameters) {
+        // Tests::GetRandomRotationMatrix / GetRandomTranslationVector (source/common/testutils.cpp:43-55)
+        const auto [rot_range, trans_range] = *config.TransformationParameters;
+        const Point_f ax = rand_point({0, 0, 0}, {1, 1, 1});
+        const Mat3 R = rotation_about({ax.x, ax.y, ax.z}, rot_range);
+        const Point_f d = rand_point({-1, -1, -1}, {1, 1, 1});
+        const float len = std::sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+        const Vec3 t{d.x / len * trans_range, d.y / len * trans_range, d.z / len * trans_range};
+        return {before, GetTransformedCloud(after, R, t)};
+    }
+    return {before, after};
+}
+
+}  // namespace Common

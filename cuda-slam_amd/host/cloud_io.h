@@ -1,0 +1,24 @@
+// Input side of the registration program: OBJ point reader and the clouds-from-configuration stage that feeds the
+// registration call (the reference's LoadCloud / GetCloudsFromConfig, source/common/common.cpp:16-23, :134-210).
+#pragma once
+#include <string>
+#include <utility>
+
+#include "configuration.h"
+#include "slam_types.h"
+
+namespace Common {
+
+// One point per FACE CORNER in face order, polygons fan-triangulated; a file without faces yields its vertices.
+// This is what the reference's assimp loader produces (aiProcess_Triangulate, no JoinIdenticalVertices:
+// source/common/loader.cpp:30-67) -- bunny.obj (2 503 v, 4 968 f) -> 14 904 points (source/common/testset.cpp:22).
+CpuCloud LoadCloud(const std::string& path);
+
+CpuCloud NormalizeCloud(const CpuCloud& cloud, float size);                       // common.cpp:81-95
+CpuCloud GetTransformedCloud(const CpuCloud& cloud, const Mat3& R, const Vec3& t);   // common.cpp:219-224
+
+// Load, optional resize, normalise to "cloud-spread", shuffle with mt19937("random-seed"), optional noise / outliers,
+// apply the configured transform to `after` (common.cpp:134-210).  Returns (before, after).
+std::pair<CpuCloud, CpuCloud> GetCloudsFromConfig(const Configuration& config);
+
+}  // namespace Common

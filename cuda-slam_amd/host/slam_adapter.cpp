@@ -1,0 +1,113 @@
+#include "slam_adapter.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/mi_slam.h"
+
+using namespace Common;
+
+namespace {
+
+SlamRules g_rules = SlamRules::CudaSlam;
+float g_max_distance_squared = 1000.f;
+int g_device = 0;
+mi_ctx* g_ctx = nullptr;
+
+// checkCudaErrors behaviour (include/helper_cuda.h:567-573): report and leave
+void check(int rc, const char* what)
+{
+    if (rc == MI_OK) return;
+    fprintf(stderr, "MI355X device error at %s: code=%d \"%s\"\n", what, rc, mi_last_error());
+    exit(EXIT_FAILURE);
+}
+
+mi_ctx* context()
+{
+    // created once per process (the reference creates and destroys its cuBLAS/cuSOLVER handles and every buffer per call)
+    if (!g_ctx) {
+        check(mi_ctx_create(g_device, &g_ctx), "mi_ctx_create");
+        atexit([] { mi_ctx_destroy(g_ctx); g_ctx = nullptr; });
+    }
+    return g_ctx;
+}
+
+std::pair<Mat3, Vec3> split(const float T[16])   // ConvertToRotationTranslationPair, common.cpp:360-365
+{
+    Mat3 R;
+    for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) R[c][r] = T[4 * c + r];
+    return {R, Vec3{T[12], T[13], T[14]}};
+}
+
+}  // namespace
+
+void SetSlamRules(SlamRules rules, float max_distance_squared)
+{
+    g_rules = rules;
+    g_max_distance_squared = max_distance_squared;
+}
+
+void SetSlamDevice(int device) { g_device = device; }
+
+std::pair<Mat3, Vec3> GetCudaIcpTransformationMatrix(const std::vector<Point_f>& cloudBefore, const std::vector<Point_f>& cloudAfter,
+                                                    float eps, int maxIterations, int* iterations, float* error)
+{
+    mi_icp_params p;
+    if (g_rules == SlamRules::CudaSlam) mi_icp_params_cuda_slam(&p);
+    else mi_icp_params_default(&p);
+    p.eps = eps;
+    p.max_iterations = maxIterations;
+    p.max_distance_squared = g_max_distance_squared;
+    p.verbose = 1;   // the reference prints one line per iteration (icpcuda.cu:39)
+    float T[16];
+    // Point_f is the 12-byte xyz triple the C ABI expects: the vectors are passed as they are
+    check(mi_icp_register(context(), reinterpret_cast<const float*>(cloudBefore.data()), (int)cloudBefore.size(),
+                          reinterpret_cast<const float*>(cloudAfter.data()), (int)cloudAfter.size(), &p, T, iterations, error),
+          "mi_icp_register");
+    return split(T);
+}
+
+std::pair<Mat3, Vec3> GetCudaCpdTransformationMatrix(const std::vector<Point_f>& cloudBefore, const std::vector<Point_f>& cloudAfter,
+                                                    float eps, float weight, bool const_scale, int maxIterations, float tolerance,
+                                                    ApproximationType fgt, int* iterations, float* error, const float& ratioOfFarField,
+                                                    const float& orderOfTruncation)
+{
+    (void)ratioOfFarField;
+    (void)orderOfTruncation;
+    if (fgt != ApproximationType::None)
+        printf("approximation-type full/hybrid (Fast Gauss Transform) is not part of the accelerated path: using the exact Gaussian P\n");
+    mi_cpd_params p;
+    mi_cpd_params_default(&p);
+    p.eps = eps;
+    p.weight = weight;
+    p.const_scale = const_scale ? 1 : 0;
+    p.max_iterations = maxIterations;
+    p.tolerance = tolerance;
+    p.verbose = 1;   // cpdcuda.cu:357
+    float T[16];
+    check(mi_cpd_register(context(), reinterpret_cast<const float*>(cloudBefore.data()), (int)cloudBefore.size(),
+                          reinterpret_cast<const float*>(cloudAfter.data()), (int)cloudAfter.size(), &p, T, nullptr, iterations, error),
+          "mi_cpd_register");
+    return split(T);
+}
+
+std::pair<Mat3, Vec3> GetGpuSlamResult(const CpuCloud& before, const CpuCloud& after, Configuration configuration, int* iterations,
+                                      float* error)
+{
+    const int maxIterations = configuration.MaxIterations.has_value() ? configuration.MaxIterations.value() : -1;   // gpumain.cpp:14
+    switch (configuration.ComputationMethod_) {
+    case ComputationMethod::Cpd:
+        return GetCudaCpdTransformationMatrix(before, after, configuration.ConvergenceEpsilon, configuration.CpdWeight,
+                                              configuration.CpdConstScale, maxIterations, configuration.CpdTolerance,
+                                              configuration.ApproximationType_, iterations, error, configuration.RatioOfFarField,
+                                              (float)configuration.OrderOfTruncation);
+    case ComputationMethod::NoniterativeIcp:
+        fprintf(stderr, "method nicp is outside the accelerated path of this build (icp and cpd are)\n");
+        exit(EXIT_FAILURE);
+    case ComputationMethod::Icp:
+    default:
+        return GetCudaIcpTransformationMatrix(before, after, configuration.ConvergenceEpsilon, maxIterations, iterations, error);
+    }
+}

@@ -1,0 +1,97 @@
+"""CPU suite: the C++ host side (cuda-slam_amd/host -> cuda-slam_amd/mi-slam): configuration reader quirks and the
+clouds-from-configuration stage.  No GPU call is made (MISLAM_DUMP_ONLY stops the program before the registration)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+EXE = os.path.join(ROOT, "cuda-slam_amd", "mi-slam")
+REF_BUNNY = "/root/reference/data/bunny.obj"
+
+BASE = {"before-path": "a.obj", "after-path": "a.obj", "method": "icp", "translation": [1.0, 1.0, 1.0],
+        "rotation": [0.36, 0.47, -0.8, -0.8, 0.6, 0, 0.48, 0.64, 0.6]}
+
+
+def run(cfg, tmp_path, *extra, dump=False):
+    if not os.path.exists(EXE):
+        pytest.skip("mi-slam not built (run __graft_entry__.build())")
+    p = tmp_path / "cfg.json"
+    p.write_text(json.dumps(cfg) if isinstance(cfg, dict) else cfg)
+    args = [EXE, str(p)] + list(extra)
+    if dump:
+        args += ["--dump-clouds", str(tmp_path / "clouds.bin")]
+    env = dict(os.environ, MISLAM_DUMP_ONLY="1")
+    return subprocess.run(args, capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=120)
+
+
+def write_obj(path, verts, faces):
+    with open(path, "w") as f:
+        for v in verts:
+            f.write("v %r %r %r\n" % tuple(float(x) for x in v))
+        for fc in faces:
+            f.write("f " + " ".join(str(i) for i in fc) + "\n")
+
+
+def read_dump(path):
+    n, m = np.fromfile(path, dtype=np.int32, count=2)
+    d = np.fromfile(path, dtype=np.float32, offset=8)
+    return d[:3 * n].reshape(n, 3), d[3 * n:].reshape(m, 3)
+
+
+def test_parser_defaults_and_quirks(tmp_path):
+    write_obj(tmp_path / "a.obj", [(0, 0, 0), (1, 0, 0), (0, 1, 0)], [(1, 2, 3)])
+    r = run(BASE, tmp_path, dump=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    assert "Approximation type: hybrid" in out            # configparser.cpp:217
+    assert "const scale: 0" in out                        # parsed default false (configparser.cpp:240), not the struct's true
+    assert "Max distance squared: 1000.0" in out and "Convergence epsilon: 0.001" in out
+    cfg = dict(BASE, **{"approximation-type": "banana", "cpd-const-scale": True, "max-distance-squared": 400})
+    out = run(cfg, tmp_path, dump=True).stdout
+    assert "Approximation type: hybrid" in out and "const scale: 1" in out and "Max distance squared: 400.0" in out
+
+
+def test_parser_rejects_like_the_reference(tmp_path):
+    write_obj(tmp_path / "a.obj", [(0, 0, 0), (1, 0, 0), (0, 1, 0)], [(1, 2, 3)])
+    no_transform = {k: v for k, v in BASE.items() if k not in ("translation", "rotation")}
+    r = run(no_transform, tmp_path)
+    assert r.returncode != 0 and "transformation or transformation parameters have to be provided" in r.stdout and "Aborting" in r.stdout
+    # the parser reads "rotation-range", not the schema's "angle-range" (configparser.cpp:170 vs config/schema.json:42)
+    assert run(dict(no_transform, **{"translation-range": 1.0, "angle-range": 0.2}), tmp_path).returncode != 0
+    assert run(dict(no_transform, **{"translation-range": 1.0, "rotation-range": 0.2, "random-seed": 3}), tmp_path, dump=True).returncode == 0
+    assert "not supported" in run(dict(BASE, method="ransac"), tmp_path).stdout
+    assert "Wrong translation or rotation size" in run(dict(BASE, rotation=[1, 0, 0]), tmp_path).stdout
+    assert run("{ this is not json", tmp_path).returncode != 0
+
+
+def test_obj_face_corner_expansion_and_transform(tmp_path):
+    # 4 vertices, one triangle + one quad (fan-triangulated): 3 + 6 = 9 points, duplicates kept (loader.cpp:58-66)
+    verts = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)]
+    write_obj(tmp_path / "a.obj", verts, [(1, 2, 3), (1, 2, 3, 4)])
+    r = run(dict(BASE, **{"random-seed": 5}), tmp_path, dump=True)
+    assert r.returncode == 0
+    before, after = read_dump(tmp_path / "clouds.bin")
+    assert before.shape == (9, 3) and after.shape == (9, 3)
+    v = np.array(verts, np.float32)
+    expect = np.concatenate([v[[0, 1, 2]], v[[0, 1, 2]], v[[0, 2, 3]]])
+    assert sorted(map(tuple, before)) == sorted(map(tuple, expect))
+    R = np.array(BASE["rotation"], np.float32).reshape(3, 3)
+    want = sorted(map(tuple, np.round(expect @ R.T + 1.0, 5)))
+    assert np.allclose(sorted(map(tuple, np.round(after, 5))), want, atol=2e-5)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BUNNY), reason="reference data absent (build container only)")
+def test_bunny_input_stage_reproduces_the_golden_clouds(tmp_path, golden):
+    # config/default.json + random-seed 666: same OBJ expansion, normalisation, shuffles and transform as the clouds the
+    # reference's own preprocessing produced (tests/golden/bunny_clouds.npz) -- bit for bit
+    cfg = dict(BASE, **{"before-path": REF_BUNNY, "after-path": REF_BUNNY, "cloud-spread": 10.0, "random-seed": 666,
+                        "max-distance-squared": 400, "max-iterations": 50, "policy": "parallel"})
+    r = run(cfg, tmp_path, dump=True)
+    assert r.returncode == 0
+    before, after = read_dump(tmp_path / "clouds.bin")
+    z = golden.npz("bunny_clouds.npz")
+    assert np.array_equal(before, z["before"]) and np.array_equal(after, z["after"])
