@@ -88,6 +88,10 @@ def main():
     ap.add_argument("--points", type=int, default=1000000, help="N = M, BASELINE.json: 10^6")
     ap.add_argument("--dist-mode", type=int, default=0, help="0 = cpu-slam rounding (parity default), 1 = fma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--brute-ref-steps", type=int, default=2,
+                    help="untimed every-pair steps measured after the timed region when the box hierarchy was used (0 = skip)")
+    ap.add_argument("--nn", choices=["auto", "brute", "tree"], default="auto",
+                    help="search strategy (identical results): auto = the library default (box hierarchy at this size)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,7 +131,8 @@ def main():
         ctx.synchronize()
 
     # eps = 0: the device-side stop rule is evaluated every step and never fires -> every step is a full iteration
-    params = capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode)
+    nn_mode = {"auto": capi.NN_AUTO, "brute": capi.NN_BRUTEFORCE, "tree": capi.NN_TREE}[args.nn]
+    params = capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=nn_mode)
     ctx.icp_load(before, after, params)            # H2D upload + SoA conversion: outside the timed region
     if args.warmup > 0:
         ctx.icp_run(args.warmup)
@@ -146,38 +151,58 @@ def main():
         elapsed = float(tt.item())
 
     prof = {capi.KERNEL_NAMES[k]: ctx.profile_get(k) for k in range(len(capi.KERNEL_NAMES))}
-    ctx.profile_enable(False)
     R, t, iters, err, why = ctx.icp_result()
     lo, hi = capi.shard_range(m, rank, world)
     m_local = hi - lo
+    used_tree = args.nn == "tree" or (args.nn == "auto" and m_local >= 2048)
 
-    if rank == 0:
-        nn_ms, nn_n = prof["nn"]
+    # Outside the timed region: the same steps with the every-pair search (K1), for the brute-force roofline figures the
+    # north star asks for.  Same keys, same registration -- only the number of evaluated pairs differs.
+    brute_prof = None
+    if used_tree and args.brute_ref_steps > 0:
+        ctx.icp_load(before, after, capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=capi.NN_BRUTEFORCE))
+        ctx.icp_run(1)
+        ctx.profile_reset()
+        ctx.icp_run(args.brute_ref_steps)
+        brute_prof = ctx.profile_get(capi.KERNEL_NN)
+    ctx.profile_enable(False)
+
+    def nn_figures(nn_ms, nn_n, brute):
         nn_avg_s = nn_ms / max(nn_n, 1) * 1e-3
         alg_bytes = 20.0 * n + 12.0 * m_local          # 12N source xyz + 8N packed key out + 12 M_local target xyz
-        traffic, traffic_src = (committed_traffic("icp_synthetic_uniform_n%d" % n) if world == 1 and args.dist_mode == 0
-                                else (None, None))
         achieved_gbs = alg_bytes / nn_avg_s / 1e9
-        pairs_per_s = n * float(m_local) / nn_avg_s
-        lane_ops = pairs_per_s * OPS_PER_PAIR[args.dist_mode]
+        fig = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+               "traffic": None, "kernel": "nn_bruteforce_kernel" if brute else "nn_tree_query_kernel",
+               "avg_launch_ms": nn_avg_s * 1e3, "launches": nn_n, "algorithmic_bytes_per_launch": alg_bytes}
+        if brute:
+            pairs_per_s = n * float(m_local) / nn_avg_s
+            lane_ops = pairs_per_s * OPS_PER_PAIR[args.dist_mode]
+            fig["valu"] = {"bound": "fp32-valu-issue", "achieved": lane_ops, "peak": VALU_LANE_OPS_PEAK, "unit": "lane-ops/s",
+                           "frac": lane_ops / VALU_LANE_OPS_PEAK, "pairs_per_s": pairs_per_s,
+                           "ops_per_pair": OPS_PER_PAIR[args.dist_mode]}
+            fig["note"] = "every-pair search: fp32-VALU-bound (see valu), its compulsory HBM bytes are ~4 us of bandwidth"
+            if world == 1 and args.dist_mode == 0:
+                fig["traffic"], fig["traffic_source"] = committed_traffic("icp_synthetic_uniform_n%d" % n)
+        else:
+            fig["note"] = ("exact box-hierarchy search: latency/L2-bound pointer chasing; algorithmic bytes are the same "
+                           "20N+12M as for the every-pair kernel it replaces")
+        return fig
+
+    if rank == 0:
         out = {
             "metric": "icp_iterations_per_s", "value": args.steps / elapsed, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "icp_synthetic_uniform_n%d" % n, "n_before": n, "n_after": m,
-                       "nn": "bruteforce", "dist_arithmetic": "cpu_rounding" if args.dist_mode == 0 else "fma",
+                       "nn": "box-hierarchy (exact)" if used_tree else "bruteforce",
+                       "dist_arithmetic": "cpu_rounding" if args.dist_mode == 0 else "fma",
                        "compose": "cpu_additive", "parallelism": "target-shard x%d, RCCL u64-min all-reduce" % world,
                        "error_after_steps": err},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "nn_bruteforce_kernel",
-                         "avg_launch_ms": nn_avg_s * 1e3, "launches": nn_n, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "brute force is fp32-VALU-bound, see 'valu'; compulsory HBM bytes are ~4 us of bandwidth"},
-            "valu": {"bound": "fp32-valu-issue", "achieved": lane_ops, "peak": VALU_LANE_OPS_PEAK, "unit": "lane-ops/s",
-                     "frac": lane_ops / VALU_LANE_OPS_PEAK, "pairs_per_s": pairs_per_s,
-                     "ops_per_pair": OPS_PER_PAIR[args.dist_mode]},
+            "roofline": nn_figures(prof["nn"][0], prof["nn"][1], not used_tree),
             "kernels_ms_per_step": {k: (v[0] / args.steps) for k, v in prof.items() if v[1] > 0},
         }
+        if brute_prof is not None:
+            out["bruteforce_nn"] = nn_figures(brute_prof[0], brute_prof[1], True)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, before, after)
         print(json.dumps(out), flush=True)

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libmislam.so")
 MI_OK = 0
 DIST_CPU_ROUNDING, DIST_FMA = 0, 1
 COMPOSE_CPU_ADDITIVE, COMPOSE_EXACT = 0, 1
+NN_AUTO, NN_BRUTEFORCE, NN_TREE = 0, 1, 2
 STOP_RUNNING, STOP_CONVERGED, STOP_MAX_ITERATIONS, STOP_NO_PAIRS, STOP_ERROR_INCREASED, STOP_TOLERANCE, STOP_SIGMA = range(7)
 (KERNEL_NN, KERNEL_MOMENTS, KERNEL_SOLVE, KERNEL_TRANSFORM, KERNEL_FINALIZE, KERNEL_ALLREDUCE, KERNEL_CPD_DENOM,
  KERNEL_CPD_CONTRACT, KERNEL_CPD_MSTEP) = range(9)
@@ -25,7 +26,7 @@ UNIQUE_ID_BYTES = 128
 EXPORTS = [
     "mi_abi_version", "mi_last_error", "mi_device_count", "mi_ctx_create", "mi_dist_unique_id", "mi_ctx_create_dist",
     "mi_ctx_rank", "mi_shard_range", "mi_pack_key", "mi_unpack_key", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_icp_params_default", "mi_icp_params_cuda_slam",
-    "mi_icp_register", "mi_icp_load", "mi_icp_reset", "mi_icp_run", "mi_icp_result", "mi_nn_search", "mi_kabsch",
+    "mi_icp_register", "mi_icp_load", "mi_icp_reset", "mi_icp_run", "mi_icp_result", "mi_nn_search", "mi_nn_search_ex", "mi_kabsch",
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_estep",
     "mi_cpd_mstep", "mi_profile_enable", "mi_profile_reset", "mi_profile_get",
 ]
@@ -34,7 +35,8 @@ EXPORTS = [
 class IcpParams(C.Structure):
     _fields_ = [("eps", C.c_float), ("max_iterations", C.c_int), ("max_distance_squared", C.c_float),
                 ("dist_mode", C.c_int), ("compose_mode", C.c_int), ("filter_pairs", C.c_int),
-                ("abort_on_increase", C.c_int), ("sync_every", C.c_int), ("verbose", C.c_int), ("reserved", C.c_int * 7)]
+                ("abort_on_increase", C.c_int), ("sync_every", C.c_int), ("verbose", C.c_int), ("nn_mode", C.c_int),
+                ("reserved", C.c_int * 6)]
 
 
 class CpdParams(C.Structure):
@@ -206,12 +208,13 @@ class Context:
         return R, t, it.value, err.value, why.value
 
     # ---- primitives
-    def nn_search(self, src, tgt, dist_mode=DIST_CPU_ROUNDING):
+    def nn_search(self, src, tgt, dist_mode=DIST_CPU_ROUNDING, nn_mode=NN_AUTO):
         src, tgt = _cloud(src), _cloud(tgt)
         n = src.shape[0]
         idx = np.empty(n, np.int32)
         d2 = np.empty(n, np.float32)
-        _check(lib().mi_nn_search(self._h, _fp(src), n, _fp(tgt), tgt.shape[0], dist_mode, idx.ctypes.data_as(_i), _fp(d2)))
+        _check(lib().mi_nn_search_ex(self._h, _fp(src), n, _fp(tgt), tgt.shape[0], dist_mode, nn_mode,
+                                     idx.ctypes.data_as(_i), _fp(d2)))
         return idx, d2
 
     def kabsch(self, src, tgt, idx, keep=None):

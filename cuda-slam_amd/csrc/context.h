@@ -11,6 +11,7 @@
 
 #include "../../include/mi_slam.h"
 #include "kernels.h"
+#include "nn_tree.h"
 
 namespace mislam {
 
@@ -94,6 +95,15 @@ struct mi_ctx {
     mislam::DevBuf<unsigned char> keep_tmp;
     mislam::IcpState* d_state = nullptr;
     mislam::IcpState* h_state = nullptr;                 // pinned
+
+    // ---- exact-NN box hierarchy over the fixed-cloud shard (built lazily, valid until the shard is replaced)
+    mislam::DevBuf<unsigned int> tcodes_in, tcodes_out;
+    mislam::DevBuf<int> torder_in, torder_out;
+    mislam::DevBuf<float> tbbox;
+    mislam::DevBuf<unsigned char> tsort_temp;
+    mislam::DevBuf<float4> tpts, tbox_lo, tbox_hi;
+    mislam::NnTreeView tree{};
+    bool tree_valid = false;
 
     // ---- ICP problem currently loaded
     bool icp_loaded = false;

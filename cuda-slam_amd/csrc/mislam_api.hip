@@ -147,6 +147,8 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     c->tx.release(); c->ty.release(); c->tz.release();
     c->tgt4.release(); c->keys.release(); c->part_mom.release(); c->part_err.release();
     c->idx_tmp.release(); c->keep_tmp.release();
+    c->tcodes_in.release(); c->tcodes_out.release(); c->torder_in.release(); c->torder_out.release();
+    c->tbbox.release(); c->tsort_temp.release(); c->tpts.release(); c->tbox_lo.release(); c->tbox_hi.release();
     for (auto& s : c->spans) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->d_state) (void)hipFree(c->d_state);
@@ -285,9 +287,52 @@ int upload_soa(mi_ctx* c, const float* host_aos, int n, int n_pad, float* x, flo
     return MI_OK;
 }
 
-static int launch_nn(mi_ctx* c, const float* sx, const float* sy, const float* sz, int n, int m_local, int index_base, int fma,
-                     const int* done_flag)
+// Builds the box hierarchy over the resident fixed-cloud shard if it is not there yet (once per mi_icp_load / search).
+static int ensure_tree(mi_ctx* c, int m_local, int index_base)
 {
+    if (c->tree_valid) return MI_OK;
+    const int n_leaves = (m_local + TREE_LEAF - 1) / TREE_LEAF;
+    int n_pad = 1, height = 0;
+    while (n_pad < n_leaves) { n_pad <<= 1; height++; }
+    if (height > TREE_MAX_HEIGHT) { set_error("fixed cloud too large for the box hierarchy"); return MI_ERR_INVALID_ARG; }
+    const size_t sort_bytes = tree_sort_temp_bytes(m_local);
+    MI_TRY(c->tcodes_in.reserve((size_t)m_local)); MI_TRY(c->tcodes_out.reserve((size_t)m_local));
+    MI_TRY(c->torder_in.reserve((size_t)m_local)); MI_TRY(c->torder_out.reserve((size_t)m_local));
+    MI_TRY(c->tbbox.reserve(256 * 6 + 8));
+    MI_TRY(c->tsort_temp.reserve(sort_bytes + 16));
+    MI_TRY(c->tpts.reserve((size_t)n_leaves * TREE_LEAF));
+    MI_TRY(c->tbox_lo.reserve((size_t)2 * n_pad)); MI_TRY(c->tbox_hi.reserve((size_t)2 * n_pad));
+    TreeBuildArgs a{};
+    a.tx = c->tx.p; a.ty = c->ty.p; a.tz = c->tz.p;
+    a.m = m_local; a.index_base = index_base; a.n_leaves = n_leaves; a.n_pad = n_pad;
+    a.bbox_partials = c->tbbox.p; a.bbox = c->tbbox.p + 256 * 6;
+    a.codes_in = c->tcodes_in.p; a.codes_out = c->tcodes_out.p; a.order_in = c->torder_in.p; a.order_out = c->torder_out.p;
+    a.sort_temp = c->tsort_temp.p; a.sort_temp_bytes = sort_bytes;
+    a.pts = c->tpts.p; a.box_lo = c->tbox_lo.p; a.box_hi = c->tbox_hi.p;
+    MI_HIP(tree_build(a, c->stream));
+    c->tree.pts = c->tpts.p; c->tree.box_lo = c->tbox_lo.p; c->tree.box_hi = c->tbox_hi.p;
+    c->tree.n_pad = n_pad; c->tree.height = height;
+    c->tree_valid = true;
+    return MI_OK;
+}
+
+static int resolve_nn_mode(int nn_mode, int m_local)
+{
+    const int forced = env_int("MISLAM_NN_MODE", 0);
+    if (forced == MI_NN_BRUTEFORCE || forced == MI_NN_TREE) nn_mode = forced;
+    if (nn_mode == MI_NN_BRUTEFORCE || nn_mode == MI_NN_TREE) return nn_mode;
+    return m_local >= 2048 ? MI_NN_TREE : MI_NN_BRUTEFORCE;
+}
+
+static int launch_nn(mi_ctx* c, const float* sx, const float* sy, const float* sz, int n, int m_local, int index_base, int fma,
+                     const int* done_flag, int nn_mode)
+{
+    if (resolve_nn_mode(nn_mode, m_local) == MI_NN_TREE) {
+        MI_TRY(ensure_tree(c, m_local, index_base));
+        ProfScope ps(c, MI_KERNEL_NN);
+        MI_HIP(nn_tree_query(c->tree, sx, sy, sz, n, c->keys.p, done_flag, fma, c->stream));
+        return MI_OK;
+    }
     const NnPlan p = plan_nn(c, n, m_local);
     NnLaunch a{};
     a.sx = sx; a.sy = sy; a.sz = sz;
@@ -329,6 +374,7 @@ static void shard_range(int m_total, int rank, int world, int* lo, int* hi) { (v
 static int upload_target_shard(mi_ctx* c, const float* after_xyz, int m_total)
 {
     c->m_total = m_total;
+    c->tree_valid = false;   // the hierarchy indexes the previous shard
     shard_range(m_total, c->rank, c->world, &c->shard_lo, &c->shard_hi);
     const int m_local = c->shard_hi - c->shard_lo;
     const size_t len = target_alloc_len(m_local);
@@ -400,6 +446,7 @@ static int icp_check_params(const mi_icp_params* p)
     if (p->dist_mode != MI_DIST_CPU_ROUNDING && p->dist_mode != MI_DIST_FMA) { set_error("ICP: bad dist_mode %d", p->dist_mode); return MI_ERR_INVALID_ARG; }
     if (p->compose_mode != MI_COMPOSE_CPU_ADDITIVE && p->compose_mode != MI_COMPOSE_EXACT) { set_error("ICP: bad compose_mode %d", p->compose_mode); return MI_ERR_INVALID_ARG; }
     if (p->max_iterations < -1) { set_error("ICP: max_iterations %d (use -1 for unbounded)", p->max_iterations); return MI_ERR_INVALID_ARG; }
+    if (p->nn_mode != MI_NN_AUTO && p->nn_mode != MI_NN_BRUTEFORCE && p->nn_mode != MI_NN_TREE) { set_error("ICP: bad nn_mode %d", p->nn_mode); return MI_ERR_INVALID_ARG; }
     return MI_OK;
 }
 
@@ -454,7 +501,7 @@ static int icp_enqueue_iteration(mi_ctx* c)
     const int nb = icp_reduce_blocks(c->n);
     const int nbp = icp_reduce_blocks(c->n_pad);
     // K1 (+ C1)
-    MI_TRY(launch_nn(c, c->cx.p, c->cy.p, c->cz.p, c->n, m_local, c->shard_lo, v.fma, &c->d_state->done));
+    MI_TRY(launch_nn(c, c->cx.p, c->cy.p, c->cz.p, c->n, m_local, c->shard_lo, v.fma, &c->d_state->done, c->icp.nn_mode));
     MI_TRY(allreduce_keys(c, c->n));
     // K2, K3
     { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_moments(v, c->part_mom.p, nb, c->stream)); }
@@ -555,7 +602,14 @@ extern "C" int mi_icp_register(mi_ctx* c, const float* before_xyz, int n_before,
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int mi_nn_search(mi_ctx* c, const float* src_xyz, int n, const float* tgt_xyz, int m, int dist_mode, int* idx, float* d2)
 {
+    return mi_nn_search_ex(c, src_xyz, n, tgt_xyz, m, dist_mode, MI_NN_AUTO, idx, d2);
+}
+
+extern "C" int mi_nn_search_ex(mi_ctx* c, const float* src_xyz, int n, const float* tgt_xyz, int m, int dist_mode, int nn_mode,
+                               int* idx, float* d2)
+{
     if (!c) { set_error("mi_nn_search: null context"); return MI_ERR_INVALID_ARG; }
+    if (nn_mode != MI_NN_AUTO && nn_mode != MI_NN_BRUTEFORCE && nn_mode != MI_NN_TREE) { set_error("mi_nn_search: bad nn_mode"); return MI_ERR_INVALID_ARG; }
     if (n < 0 || m < 0 || (n > 0 && (!src_xyz || !idx)) || (m > 0 && !tgt_xyz)) { set_error("mi_nn_search: bad arguments"); return MI_ERR_INVALID_ARG; }
     if (dist_mode != MI_DIST_CPU_ROUNDING && dist_mode != MI_DIST_FMA) { set_error("mi_nn_search: bad dist_mode"); return MI_ERR_INVALID_ARG; }
     if (n == 0) return MI_OK;
@@ -569,7 +623,7 @@ extern "C" int mi_nn_search(mi_ctx* c, const float* src_xyz, int n, const float*
     MI_TRY(upload_soa(c, src_xyz, n, n_pad, c->cx.p, c->cy.p, c->cz.p, nullptr));
     MI_TRY(upload_target_shard(c, tgt_xyz, m));
     MI_HIP(fill_keys(c->keys.p, n, c->stream));
-    MI_TRY(launch_nn(c, c->cx.p, c->cy.p, c->cz.p, n, c->shard_hi - c->shard_lo, c->shard_lo, dist_mode == MI_DIST_FMA, nullptr));
+    MI_TRY(launch_nn(c, c->cx.p, c->cy.p, c->cz.p, n, c->shard_hi - c->shard_lo, c->shard_lo, dist_mode == MI_DIST_FMA, nullptr, nn_mode));
     MI_TRY(allreduce_keys(c, n));
     MI_TRY(c->idx_tmp.reserve((size_t)n));
     MI_TRY(c->staging.reserve((size_t)n));

@@ -46,6 +46,14 @@ enum {
                                    GetDistanceSquared (source/cuda-slam/cudacommon.cu:51-55) */
 };
 
+/* Execution strategy of the nearest-neighbour search.  Every mode returns the SAME idx[] and d2[] bit for bit (strict '<',
+ * lowest index on ties, same fp32 arithmetic); they differ only in how many candidate pairs are evaluated. */
+enum {
+    MI_NN_AUTO = 0,         /* box hierarchy for fixed clouds of >= 2048 points per GPU, brute force below */
+    MI_NN_BRUTEFORCE = 1,   /* every pair, like FindCorrespondences (cudacommon.cu:57-77): N*M distance evaluations */
+    MI_NN_TREE = 2          /* exact search through a box hierarchy over the Morton-sorted fixed cloud */
+};
+
 /* How the per-iteration solve (Ri, ti) is accumulated into the running transform. */
 enum {
     MI_COMPOSE_CPU_ADDITIVE = 0,  /* R <- Ri*R ; t <- ti + t   -- source/cpu-slam/basicicp.cpp:43-44 (the oracle's rule) */
@@ -115,7 +123,8 @@ typedef struct {
                                     The stop rule itself is evaluated on the device after EVERY iteration, so the result
                                     does not depend on this value. */
     int   verbose;               /* 1: print "loop_nr %d, error: %f" lines like basicicp.cpp:50 at every host check */
-    int   reserved[7];
+    int   nn_mode;               /* MI_NN_*: how the correspondence search is carried out; the RESULT is identical in every mode */
+    int   reserved[6];
 } mi_icp_params;
 
 /* Defaults = cpu-slam semantics (the parity oracle): CPU rounding, additive translation, filtered pairs, no abort. */
@@ -148,6 +157,9 @@ int mi_icp_result(mi_ctx* ctx, float out_T[16], int* iterations, float* error, i
  * idx[i] = argmin_j |tgt[j] - src[i]|^2, strict '<', lowest index wins ties; d2[i] = that minimum (may be NULL). */
 int mi_nn_search(mi_ctx* ctx, const float* src_xyz, int n, const float* tgt_xyz, int m, int dist_mode,
                  int* idx, float* d2);
+/* Same, with an explicit MI_NN_* strategy (mi_nn_search uses MI_NN_AUTO). */
+int mi_nn_search_ex(mi_ctx* ctx, const float* src_xyz, int n, const float* tgt_xyz, int m, int dist_mode, int nn_mode,
+                    int* idx, float* d2);
 
 /* CUDACommon::LeastSquaresSVD (cudacommon.cu:168-253) / Common::LeastSquaresSVD (common.cpp:517-552) on the pairs
  * (src[i], tgt[idx[i]]), i = 0..n-1, keeping pair i only if keep == NULL or keep[i] != 0.

@@ -105,6 +105,18 @@ def test_result_independent_of_host_check_interval(ctx, capi, bunny, sync_every)
     assert base[2] == other[2] and np.array_equal(base[0], other[0]) and np.array_equal(base[1], other[1]) and base[3] == other[3]
 
 
+@pytest.mark.parametrize("cuda_rules", [False, True])
+def test_search_strategy_does_not_change_the_registration(ctx, capi, bunny, cuda_rules):
+    # brute force and the box hierarchy return the same keys, so the whole run is bitwise identical
+    before, after = bunny
+    runs = []
+    for nn_mode in (capi.NN_BRUTEFORCE, capi.NN_TREE):
+        p = capi.icp_params(cuda_slam=cuda_rules, max_iterations=25, max_distance_squared=400.0, nn_mode=nn_mode)
+        runs.append(ctx.icp_register(before, after, p))
+    a, b = runs
+    assert a[2] == b[2] and a[3] == b[3] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_synth2k_matches_cpu_slam(ctx, capi, golden):
     z = golden.npz("synth2k_clouds.npz")
     g = golden.json("synth2k_icp.json")

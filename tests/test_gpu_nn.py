@@ -9,10 +9,12 @@ pytestmark = pytest.mark.gpu
 
 
 def check(ctx, capi, oracle, src, tgt, mode):
-    idx, d2 = ctx.nn_search(src, tgt, mode)
+    # both execution strategies -- every pair (K1) and the exact box hierarchy (K1t) -- must reproduce the oracle bit for bit
     ridx, rd2 = oracle.nn_search(src, tgt, dist_mode=mode)
-    assert np.array_equal(idx, ridx)
-    assert np.array_equal(d2.view(np.uint32), rd2.view(np.uint32))
+    for nn_mode in (capi.NN_BRUTEFORCE, capi.NN_TREE):
+        idx, d2 = ctx.nn_search(src, tgt, mode, nn_mode)
+        assert np.array_equal(idx, ridx), "nn_mode %d" % nn_mode
+        assert np.array_equal(d2.view(np.uint32), rd2.view(np.uint32)), "nn_mode %d" % nn_mode
 
 
 def test_correspondences_known_answer(ctx, capi):
@@ -54,13 +56,34 @@ def test_adversarial_order_descending_distance(ctx, capi, oracle):
     check(ctx, capi, oracle, src, tgt[order].copy(), 0)
 
 
-def test_bunny_iter0_matches_golden(ctx, capi, golden, bunny):
+@pytest.mark.parametrize("nn_mode", [1, 2])
+def test_bunny_iter0_matches_golden(ctx, capi, golden, bunny, nn_mode):
+    # bunny has every vertex ~6 times (face-corner expansion): exact ties everywhere, the lowest index must win
     before, after = bunny
     g = golden.npz("bunny_icp_iter0.npz")
-    idx, d2 = ctx.nn_search(before, after)
+    idx, d2 = ctx.nn_search(before, after, 0, nn_mode)
     keep = d2 < np.float32(400.0)
     assert np.array_equal(np.nonzero(keep)[0], g["idx_before"])
     assert np.array_equal(idx[keep], g["idx_after"])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_tree_equals_bruteforce_on_clustered_and_degenerate_clouds(ctx, capi, mode):
+    rng = np.random.default_rng(77)
+    # clustered targets far from the sources, a plane, a line, all-identical points, one outlier at 1e6
+    clouds = [
+        np.concatenate([rng.normal(loc=c, scale=0.05, size=(3000, 3)) for c in ((0, 0, 0), (10, 10, 10), (-7, 3, 1))]),
+        np.stack([rng.uniform(-5, 5, 9000), rng.uniform(-5, 5, 9000), np.zeros(9000)], 1),
+        np.stack([np.linspace(-3, 3, 5000), np.zeros(5000), np.zeros(5000)], 1),
+        np.tile(np.array([[1.5, -2.5, 0.25]]), (4096, 1)),
+        np.concatenate([rng.uniform(-1, 1, (5000, 3)), [[1e6, -1e6, 1e6]]]),
+    ]
+    src = np.concatenate([rng.uniform(-12, 12, (3000, 3)), rng.normal(size=(1000, 3)) * 1e-3, [[1e6, -1e6, 1e6]]]).astype(np.float32)
+    for tgt in clouds:
+        tgt = tgt.astype(np.float32)
+        a = ctx.nn_search(src, tgt, mode, capi.NN_BRUTEFORCE)
+        b = ctx.nn_search(src, tgt, mode, capi.NN_TREE)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
 
 
 def test_large_sampled_rows_and_properties(ctx, capi, oracle):
@@ -68,7 +91,9 @@ def test_large_sampled_rows_and_properties(ctx, capi, oracle):
     # the rest is covered by size-independent properties (self-search is the identity with d2 = 0; the reported d2 is the
     # true distance to the reported index; no sampled target is closer).
     before, after, _, _ = synth_cloud(100000)
-    idx, d2 = ctx.nn_search(before, after)
+    idx, d2 = ctx.nn_search(before, after, 0, capi.NN_TREE)
+    bidx, bd2 = ctx.nn_search(before, after, 0, capi.NN_BRUTEFORCE)
+    assert np.array_equal(idx, bidx) and np.array_equal(d2.view(np.uint32), bd2.view(np.uint32))   # all 1e10 pairs vs the tree
     rows = np.random.default_rng(0).choice(len(before), 256, replace=False)
     ridx, rd2 = oracle.nn_search(before[rows], after)
     assert np.array_equal(idx[rows], ridx)
