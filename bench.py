@@ -42,17 +42,17 @@ def synth_cloud(np, n, seed=666):
     return before, after
 
 
-def committed_traffic(workload):
+def committed_traffic(workload, kernel):
     """HBM bytes per NN launch from the committed rocprofv3 --pmc summary of this same command (profiles/), if there is one
-    for this workload: bench.py cannot run the counter passes itself (they need their own rocprofv3 runs)."""
+    for this workload and kernel: bench.py cannot run the counter passes itself (they need their own rocprofv3 runs)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_counters.json")), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
             continue
-        if d.get("workload") == workload and "nn_bruteforce_kernel" in d:
-            return d["nn_bruteforce_kernel"].get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
+        if d.get("workload") == workload and kernel in d:
+            return d[kernel].get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -154,7 +154,7 @@ def main():
     R, t, iters, err, why = ctx.icp_result()
     lo, hi = capi.shard_range(m, rank, world)
     m_local = hi - lo
-    used_tree = args.nn == "tree" or (args.nn == "auto" and m_local >= 2048)
+    used_tree = args.nn == "tree" or (args.nn == "auto" and m_local >= 32768)
 
     # Outside the timed region: the same steps with the every-pair search (K1), for the brute-force roofline figures the
     # north star asks for.  Same keys, same registration -- only the number of evaluated pairs differs.
@@ -172,8 +172,10 @@ def main():
         alg_bytes = 20.0 * n + 12.0 * m_local          # 12N source xyz + 8N packed key out + 12 M_local target xyz
         achieved_gbs = alg_bytes / nn_avg_s / 1e9
         fig = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-               "traffic": None, "kernel": "nn_bruteforce_kernel" if brute else "nn_tree_query_kernel",
+               "traffic": None, "kernel": "nn_bruteforce_kernel" if brute else "nn_tree_lane_kernel",
                "avg_launch_ms": nn_avg_s * 1e3, "launches": nn_n, "algorithmic_bytes_per_launch": alg_bytes}
+        if world == 1 and args.dist_mode == 0:
+            fig["traffic"], fig["traffic_source"] = committed_traffic("icp_synthetic_uniform_n%d" % n, fig["kernel"])
         if brute:
             pairs_per_s = n * float(m_local) / nn_avg_s
             lane_ops = pairs_per_s * OPS_PER_PAIR[args.dist_mode]
@@ -181,8 +183,6 @@ def main():
                            "frac": lane_ops / VALU_LANE_OPS_PEAK, "pairs_per_s": pairs_per_s,
                            "ops_per_pair": OPS_PER_PAIR[args.dist_mode]}
             fig["note"] = "every-pair search: fp32-VALU-bound (see valu), its compulsory HBM bytes are ~4 us of bandwidth"
-            if world == 1 and args.dist_mode == 0:
-                fig["traffic"], fig["traffic_source"] = committed_traffic("icp_synthetic_uniform_n%d" % n)
         else:
             fig["note"] = ("exact box-hierarchy search: latency/L2-bound pointer chasing; algorithmic bytes are the same "
                            "20N+12M as for the every-pair kernel it replaces")

@@ -101,9 +101,10 @@ struct mi_ctx {
     mislam::DevBuf<int> torder_in, torder_out;
     mislam::DevBuf<float> tbbox;
     mislam::DevBuf<unsigned char> tsort_temp;
-    mislam::DevBuf<float4> tpts, tbox_lo, tbox_hi;
+    mislam::DevBuf<float4> tpts, tboxes;
     mislam::NnTreeView tree{};
     bool tree_valid = false;
+    mislam::DevBuf<int> sorder;                          // Morton order of the moving cloud (sorted slot -> caller's index)
 
     // ---- ICP problem currently loaded
     bool icp_loaded = false;

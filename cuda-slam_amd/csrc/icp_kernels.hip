@@ -53,13 +53,15 @@ __global__ __launch_bounds__(256) void soa_to_aos_kernel(const float* __restrict
     aos[3 * (size_t)i] = x[i]; aos[3 * (size_t)i + 1] = y[i]; aos[3 * (size_t)i + 2] = z[i];
 }
 
-// keys -> idx[], d2[] (test-grade mi_nn_search output)
-__global__ __launch_bounds__(256) void unpack_keys_kernel(const unsigned long long* __restrict__ keys, int n, int* __restrict__ idx,
-                                                          float* __restrict__ d2)
+// keys -> idx[], d2[] (test-grade mi_nn_search output).  keys[s] belongs to sorted slot s; order[s] (may be null) is the
+// caller's index of that slot.
+__global__ __launch_bounds__(256) void unpack_keys_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ order,
+                                                          int n, int* __restrict__ idx, float* __restrict__ d2)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long k = keys[i];
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const unsigned long long k = keys[s];
+    const int i = order != nullptr ? order[s] : s;
     idx[i] = (int)(unsigned int)(k & 0xffffffffull);
     if (d2 != nullptr) d2[i] = __uint_as_float((unsigned int)(k >> 32));
 }
@@ -327,10 +329,10 @@ hipError_t soa_to_aos(const float* x, const float* y, const float* z, int n, flo
     return hipGetLastError();
 }
 
-hipError_t unpack_keys(const unsigned long long* keys, int n, int* idx, float* d2, hipStream_t s)
+hipError_t unpack_keys(const unsigned long long* keys, const int* order, int n, int* idx, float* d2, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(unpack_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, idx, d2);
+    hipLaunchKernelGGL(unpack_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, keys, order, n, idx, d2);
     return hipGetLastError();
 }
 

@@ -81,7 +81,7 @@ struct IcpRules {
 hipError_t fill_keys(unsigned long long* keys, int n, hipStream_t s);
 hipError_t aos_to_soa(const float* aos, int n, int n_pad, float* x, float* y, float* z, float4* packed, hipStream_t s);
 hipError_t soa_to_aos(const float* x, const float* y, const float* z, int n, float* aos, hipStream_t s);
-hipError_t unpack_keys(const unsigned long long* keys, int n, int* idx, float* d2, hipStream_t s);
+hipError_t unpack_keys(const unsigned long long* keys, const int* order, int n, int* idx, float* d2, hipStream_t s);
 hipError_t pack_keys(const int* idx, const unsigned char* keep, int n, unsigned long long* keys, hipStream_t s);
 
 int icp_reduce_blocks(int n);

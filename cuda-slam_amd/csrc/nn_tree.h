@@ -9,30 +9,39 @@ constexpr int TREE_MAX_HEIGHT = 24;
 
 struct NnTreeView {
     const float4* pts;                // n_leaves * TREE_LEAF sorted points, w = GLOBAL index bits
-    const float4* box_lo;             // 2*n_pad - 1 nodes, implicit heap: children of i are 2i+1, 2i+2; leaves start at n_pad-1
-    const float4* box_hi;
+    const float4* boxes;              // node i: boxes[2i] = lo, boxes[2i+1] = hi; implicit heap, children of i are 2i+1 and
+                                      // 2i+2 (adjacent: one 64-byte record), leaves start at n_pad-1
     int n_pad;                        // leaf count padded to a power of two (padding leaves carry empty boxes)
     int height;                       // log2(n_pad)
 };
 
-struct TreeBuildArgs {
-    const float *tx, *ty, *tz;        // fixed-cloud shard, SoA
-    int m;                            // real points
-    int index_base;                   // global index of point 0
-    int n_leaves, n_pad;
+// Morton order of a SoA cloud: order_out[s] = index of the s-th point along the Z-curve of the cloud's bounding box.
+struct MortonArgs {
+    const float *x, *y, *z;
+    int m;
     float* bbox_partials;             // [256][6]
     float* bbox;                      // [6]
     unsigned int *codes_in, *codes_out;
     int *order_in, *order_out;
     void* sort_temp;
     size_t sort_temp_bytes;
+};
+
+struct TreeBuildArgs {
+    MortonArgs morton;                // over the fixed-cloud shard
+    int index_base;                   // global index of point 0
+    int n_leaves, n_pad;
     float4* pts;
-    float4 *box_lo, *box_hi;
+    float4* boxes;                    // 2 * (2*n_pad - 1) float4
 };
 
 size_t tree_sort_temp_bytes(int m);
+hipError_t morton_order(const MortonArgs& a, hipStream_t s);
+hipError_t permute_soa(const float* x, const float* y, const float* z, const int* order, int m, int n_out, float* ox, float* oy,
+                       float* oz, hipStream_t s);
 hipError_t tree_build(const TreeBuildArgs& a, hipStream_t s);
+// R = sources per lane (1 or 2); sources should be Morton-sorted (speed only -- the result never depends on their order)
 hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, const float* sz, int n, unsigned long long* keys,
-                         const int* done_flag, int fma, hipStream_t s);
+                         const int* done_flag, int fma, int R, hipStream_t s);
 
 }  // namespace mislam

@@ -1,20 +1,36 @@
 // K1t -- EXACT nearest-neighbour search through a bounding-box hierarchy over the Morton-sorted fixed cloud.
 //
-// Same contract as the brute-force K1 (nn_kernel.hip) and therefore as FindCorrespondences (cudacommon.cu:57-77) /
+// Same contract as the every-pair K1 (nn_kernel.hip) and therefore as FindCorrespondences (cudacommon.cu:57-77) /
 // common.cpp:446-462: idx[i] = argmin_j |after[j] - before[i]|^2 under strict '<' with the lowest index winning ties, the
-// distance evaluated with the same fp32 operation sequence.  The result is IDENTICAL to brute force, bit for bit, because
-//   * a leaf point is accepted iff (d, j) is lexicographically smaller than the running (best, bidx) -- the order in which
+// distance evaluated with the same fp32 operation sequence.  The result is IDENTICAL to the every-pair search, bit for bit:
+//   * a candidate is accepted iff (d, j) is lexicographically smaller than the running (best, bidx) -- the order in which
 //     candidates are met does not matter for a lexicographic minimum;
-//   * a subtree is skipped only if its box bound lb is STRICTLY greater than best, where lb is computed with the very same
-//     rounded operations as a distance: for every point q of the box and every axis, |fl(q - s)| >= fl(e) with
-//     e = max(lo - s, s - hi, 0) (rounding is monotonic), hence fl-by-fl lb <= d(q): a skipped point can neither win nor tie.
+//   * a subtree is skipped only if a lower bound lb of its box is STRICTLY greater than the bound it is compared with, and lb is
+//     computed with the very same rounded operations as a distance.  For a point q in the node box [lo,hi] and a source s in
+//     the group box [glo,ghi], per axis q - s >= lo - ghi and s - q >= glo - hi in real arithmetic; rounding is monotonic, so
+//     |fl(q - s)| >= fl(gap) with gap = max(lo - ghi, glo - hi, 0), and squaring / summing in the distance's own order keeps
+//     the inequality: fl-by-fl lb <= d(q, s).  A skipped point can neither win nor tie.  (A single source is the
+//     degenerate group glo = ghi = s.)
 //
-// Build (once per fixed cloud / shard; the fixed cloud does not move during ICP): bounding box -> 30-bit Morton codes ->
+// Build (once per fixed cloud / shard -- the fixed cloud does not move during ICP): bounding box -> 30-bit Morton codes ->
 // radix sort (rocPRIM device primitive; one-time index build, not the per-iteration path) -> leaves of 8 consecutive
-// points as float4 (x, y, z, global index bits) -> implicit binary heap of boxes over the leaves (padded to a power of
-// two with empty boxes).
-// Query: one lane per source point, depth-first, nearer child first, per-lane stack in LDS; starts from the key already
-// posted for the point (the previous ICP iteration's match under the new transform), so late iterations mostly verify.
+// points as float4 (x, y, z, global-index bits) -> implicit binary heap of boxes over the leaves, padded to a power of two
+// with empty boxes.  Node i's children are 2i+1 and 2i+2 and their boxes are ADJACENT in memory: one 64-byte record.
+//
+// The moving cloud is Morton-sorted once at load, so the 64 lanes of a wave hold 64 spatial neighbours.  Two query forms,
+// both exact (the result never depends on which one runs):
+//   * per-lane (default, nn_tree_lane_kernel): each lane walks the hierarchy for its own source, nearer child first,
+//     per-lane stack in LDS, pruning with the lane's OWN best.  Neighbouring lanes take similar paths, so most node loads
+//     of a wave coalesce.  Measured on MI355X, N = M = 1e6 synthetic: 1.8 ms per search in early ICP iterations
+//     (radius 0.44, ~360 points inside the search sphere), 1.1 ms near convergence; 2.7 ms without the source sort.
+//   * wave-cooperative (nn_tree_wave_kernel, MISLAM_TREE_R=1|2): the wave walks the hierarchy ONCE for the whole group; every
+//     address is wave-uniform, so boxes and leaf points arrive through SCALAR loads and feed the VALU as SGPR operands (like
+//     K1), control flow is uniform, and the stack lives across the lanes of one VGPR (v_writelane / v_readlane indexed by
+//     the scalar stack pointer) -- no LDS.  It prunes against the group's WORST running best, so it evaluates
+//     ~(s + 2r)^3 / (4.2 r^3) times more pairs than the per-lane form (s = extent of the 64 neighbours, r = search radius),
+//     and a group that straddles a jump of the Z-curve has a box as large as the cloud and degenerates to the every-pair
+//     search for that wave.  Measured: 77 ms early / 27 ms late at N = 1e6 -- kept as a documented, tested alternative, not
+//     the default.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -27,7 +43,7 @@
 namespace mislam {
 
 // ---------------------------------------------------------------------------------------------------------------
-// build
+// Morton order of a SoA cloud (used for the fixed cloud's leaves and for the moving cloud's lane grouping)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tree_bbox_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                 const float* __restrict__ z, int m, float* __restrict__ partials)
@@ -88,6 +104,49 @@ __global__ __launch_bounds__(256) void tree_morton_kernel(const float* __restric
     order[j] = j;
 }
 
+size_t tree_sort_temp_bytes(int m)
+{
+    size_t bytes = 0;
+    unsigned int* k = nullptr;
+    int* v = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)m, 0u, 30u, (hipStream_t)0, false);
+    return bytes;
+}
+
+hipError_t morton_order(const MortonArgs& a, hipStream_t s)
+{
+    const int m = a.m;
+    const int blocks = (m + 255) / 256;
+    const int rb = blocks < 256 ? blocks : 256;
+    hipLaunchKernelGGL(tree_bbox_partial_kernel, dim3(rb), dim3(256), 0, s, a.x, a.y, a.z, m, a.bbox_partials);
+    hipLaunchKernelGGL(tree_bbox_final_kernel, dim3(1), dim3(64), 0, s, a.bbox_partials, rb, a.bbox);
+    hipLaunchKernelGGL(tree_morton_kernel, dim3(blocks), dim3(256), 0, s, a.x, a.y, a.z, m, a.bbox, a.codes_in, a.order_in);
+    size_t temp = a.sort_temp_bytes;
+    return rocprim::radix_sort_pairs(a.sort_temp, temp, a.codes_in, a.codes_out, a.order_in, a.order_out, (size_t)m, 0u, 30u, s, false);
+}
+
+// out[s] = in[order[min(s, m-1)]] for s < n_out (tail replicates the last sorted point)
+__global__ __launch_bounds__(256) void permute_soa_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const float* __restrict__ z, const int* __restrict__ order, int m, int n_out,
+                                                          float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_out) return;
+    const int j = order[s < m ? s : m - 1];
+    ox[s] = x[j]; oy[s] = y[j]; oz[s] = z[j];
+}
+
+hipError_t permute_soa(const float* x, const float* y, const float* z, const int* order, int m, int n_out, float* ox, float* oy,
+                       float* oz, hipStream_t s)
+{
+    if (n_out <= 0) return hipSuccess;
+    hipLaunchKernelGGL(permute_soa_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, x, y, z, order, m, n_out, ox, oy, oz);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// hierarchy build
+// ---------------------------------------------------------------------------------------------------------------
 // sorted slot s <- point order[s]; slots past the last real point replicate it (same coordinates AND same index: a no-op
 // for a lexicographic minimum)
 __global__ __launch_bounds__(256) void tree_gather_kernel(const float* __restrict__ x, const float* __restrict__ y,
@@ -100,8 +159,8 @@ __global__ __launch_bounds__(256) void tree_gather_kernel(const float* __restric
     pts[s] = make_float4(x[j], y[j], z[j], __int_as_float(j + index_base));
 }
 
-__global__ __launch_bounds__(256) void tree_leaf_box_kernel(const float4* __restrict__ pts, int n_leaves, int n_pad,
-                                                            float4* __restrict__ box_lo, float4* __restrict__ box_hi)
+// boxes[2*node] = lo, boxes[2*node+1] = hi
+__global__ __launch_bounds__(256) void tree_leaf_box_kernel(const float4* __restrict__ pts, int n_leaves, int n_pad, float4* __restrict__ boxes)
 {
     const int leaf = blockIdx.x * 256 + threadIdx.x;
     if (leaf >= n_pad) return;
@@ -114,49 +173,33 @@ __global__ __launch_bounds__(256) void tree_leaf_box_kernel(const float4* __rest
             hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
         }
     }
-    const int node = n_pad - 1 + leaf;
-    box_lo[node] = make_float4(lo[0], lo[1], lo[2], 0.f);
-    box_hi[node] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    const size_t node = (size_t)(n_pad - 1 + leaf);
+    boxes[2 * node] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    boxes[2 * node + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
 }
 
 // nodes [first, first + count) of one level: box = union of the two children
-__global__ __launch_bounds__(256) void tree_level_kernel(int first, int count, float4* __restrict__ box_lo, float4* __restrict__ box_hi)
+__global__ __launch_bounds__(256) void tree_level_kernel(int first, int count, float4* __restrict__ boxes)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
-    const int node = first + i, l = 2 * node + 1, r = l + 1;
-    const float4 a = box_lo[l], b = box_lo[r], c = box_hi[l], d = box_hi[r];
-    box_lo[node] = make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), 0.f);
-    box_hi[node] = make_float4(fmaxf(c.x, d.x), fmaxf(c.y, d.y), fmaxf(c.z, d.z), 0.f);
-}
-
-size_t tree_sort_temp_bytes(int m)
-{
-    size_t bytes = 0;
-    unsigned int* k = nullptr;
-    int* v = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)m, 0u, 30u, (hipStream_t)0, false);
-    return bytes;
+    const size_t node = (size_t)(first + i), l = 2 * node + 1, r = l + 1;
+    const float4 a = boxes[2 * l], c = boxes[2 * l + 1], b = boxes[2 * r], d = boxes[2 * r + 1];
+    boxes[2 * node] = make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), 0.f);
+    boxes[2 * node + 1] = make_float4(fmaxf(c.x, d.x), fmaxf(c.y, d.y), fmaxf(c.z, d.z), 0.f);
 }
 
 hipError_t tree_build(const TreeBuildArgs& a, hipStream_t s)
 {
-    const int m = a.m;
-    const int blocks = (m + 255) / 256;
-    const int rb = blocks < 256 ? blocks : 256;
-    hipLaunchKernelGGL(tree_bbox_partial_kernel, dim3(rb), dim3(256), 0, s, a.tx, a.ty, a.tz, m, a.bbox_partials);
-    hipLaunchKernelGGL(tree_bbox_final_kernel, dim3(1), dim3(64), 0, s, a.bbox_partials, rb, a.bbox);
-    hipLaunchKernelGGL(tree_morton_kernel, dim3(blocks), dim3(256), 0, s, a.tx, a.ty, a.tz, m, a.bbox, a.codes_in, a.order_in);
-    size_t temp = a.sort_temp_bytes;
-    hipError_t e = rocprim::radix_sort_pairs(a.sort_temp, temp, a.codes_in, a.codes_out, a.order_in, a.order_out, (size_t)m, 0u, 30u, s, false);
+    hipError_t e = morton_order(a.morton, s);
     if (e != hipSuccess) return e;
+    const int m = a.morton.m;
     const int n_slots = a.n_leaves * TREE_LEAF;
-    hipLaunchKernelGGL(tree_gather_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, a.tx, a.ty, a.tz, a.order_out, m, n_slots,
-                       a.index_base, a.pts);
-    hipLaunchKernelGGL(tree_leaf_box_kernel, dim3((a.n_pad + 255) / 256), dim3(256), 0, s, a.pts, a.n_leaves, a.n_pad, a.box_lo, a.box_hi);
-    for (int count = a.n_pad / 2; count >= 1; count /= 2) {   // levels bottom-up: nodes [count-1, 2*count-1)
-        hipLaunchKernelGGL(tree_level_kernel, dim3((count + 255) / 256), dim3(256), 0, s, count - 1, count, a.box_lo, a.box_hi);
-    }
+    hipLaunchKernelGGL(tree_gather_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, a.morton.x, a.morton.y, a.morton.z,
+                       a.morton.order_out, m, n_slots, a.index_base, a.pts);
+    hipLaunchKernelGGL(tree_leaf_box_kernel, dim3((a.n_pad + 255) / 256), dim3(256), 0, s, a.pts, a.n_leaves, a.n_pad, a.boxes);
+    for (int count = a.n_pad / 2; count >= 1; count /= 2)   // levels bottom-up: nodes [count-1, 2*count-1)
+        hipLaunchKernelGGL(tree_level_kernel, dim3((count + 255) / 256), dim3(256), 0, s, count - 1, count, a.boxes);
     return hipGetLastError();
 }
 
@@ -170,20 +213,165 @@ __device__ __forceinline__ float sq3(float dx, float dy, float dz)
     else return (dx * dx + dy * dy) + dz * dz;
 }
 
+// lower bound of |q - s|^2 over q in [lo,hi], s in [glo,ghi], rounded like a distance (see the header comment)
 template <bool FMA>
-__device__ __forceinline__ float box_bound(const float4 lo, const float4 hi, float sx, float sy, float sz)
+__device__ __forceinline__ float box_bound(const float4 lo, const float4 hi, const float glo[3], const float ghi[3])
 {
-    const float ex = fmaxf(fmaxf(lo.x - sx, sx - hi.x), 0.f);
-    const float ey = fmaxf(fmaxf(lo.y - sy, sy - hi.y), 0.f);
-    const float ez = fmaxf(fmaxf(lo.z - sz, sz - hi.z), 0.f);
+    const float ex = fmaxf(fmaxf(lo.x - ghi[0], glo[0] - hi.x), 0.f);
+    const float ey = fmaxf(fmaxf(lo.y - ghi[1], glo[1] - hi.y), 0.f);
+    const float ez = fmaxf(fmaxf(lo.z - ghi[2], glo[2] - hi.z), 0.f);
     return sq3<FMA>(ex, ey, ez);
 }
 
-// One lane per source point.  Dynamic LDS: stack_depth x 256 x 8 bytes (node id + bound per entry, column per lane).
+__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// Wave64 max/min returning a wave-uniform value: four DPP steps reduce each 16-lane row in the VALU (quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror, row_mirror), then the four row results are combined through v_readlane.  No LDS
+// permute round trips (a __shfl_xor ladder is six ds_bpermute hops on the wave's critical path).
+template <bool IS_MAX>
+__device__ __forceinline__ float wave_reduce_f(float v)
+{
+    auto op = [](float a, float b) { return IS_MAX ? fmaxf(a, b) : fminf(a, b); };
+#define MI_DPP_F(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), ctrl, 0xf, 0xf, false))
+    v = op(v, MI_DPP_F(v, 0xB1));    // quad_perm:[1,0,3,2]
+    v = op(v, MI_DPP_F(v, 0x4E));    // quad_perm:[2,3,0,1]
+    v = op(v, MI_DPP_F(v, 0x141));   // row_half_mirror
+    v = op(v, MI_DPP_F(v, 0x140));   // row_mirror
+#undef MI_DPP_F
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return uniform_f(op(op(r0, r1), op(r2, r3)));
+}
+__device__ __forceinline__ float wave_min_f(float v) { return wave_reduce_f<false>(v); }
+__device__ __forceinline__ float wave_max_f(float v) { return wave_reduce_f<true>(v); }
+
+// v_writelane_b32: lane `lane` of `vec` <- val (both wave-uniform).  No clang builtin on this toolchain, hence asm: the lane
+// select goes through M0 (written in the same statement), and the leading s_nop covers the "VALU-written SGPR used by
+// v_writelane" wait states, which hipcc does not insert for operands of an asm statement.
+__device__ __forceinline__ int write_lane(int vec, int val, int lane)
+{
+    const int sval = __builtin_amdgcn_readfirstlane(val);
+    const int slane = __builtin_amdgcn_readfirstlane(lane);
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(sval), "s"(slane));
+    return vec;
+}
+
+// One wave = 64*R consecutive (Morton-sorted) sources, lane l owns sources base + r*64 + l.
+template <int R, bool FMA>
+__global__ __launch_bounds__(256) void nn_tree_wave_kernel(const float4* __restrict__ tree_pts, const float4* __restrict__ tree_boxes,
+                                                           int tree_n_pad, const float* __restrict__ sx, const float* __restrict__ sy,
+                                                           const float* __restrict__ sz, int n, unsigned long long* __restrict__ keys,
+                                                           const int* __restrict__ done_flag)
+{
+    if (done_flag != nullptr && *done_flag != 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+    const int base = wave * (64 * R);
+    if (base >= n) return;
+
+    float px[R], py[R], pz[R], best[R];
+    unsigned int bidx[R];
+    float glo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float ghi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = base + r * 64 + lane;
+        const int ic = i < n ? i : n - 1;           // tail lanes shadow the last source (they never store)
+        px[r] = sx[ic]; py[r] = sy[ic]; pz[r] = sz[ic];
+        const unsigned long long k0 = keys[ic];      // starting candidate: the key already posted (KEY_INIT -> none)
+        const unsigned int hi0 = (unsigned int)(k0 >> 32);
+        best[r] = hi0 < 0x7f800000u ? __uint_as_float(hi0) : __builtin_inff();
+        bidx[r] = hi0 < 0x7f800000u ? (unsigned int)(k0 & 0xffffffffull) : 0u;   // (inf, 0): nothing at +inf is ever accepted
+        glo[0] = fminf(glo[0], px[r]); glo[1] = fminf(glo[1], py[r]); glo[2] = fminf(glo[2], pz[r]);
+        ghi[0] = fmaxf(ghi[0], px[r]); ghi[1] = fmaxf(ghi[1], py[r]); ghi[2] = fmaxf(ghi[2], pz[r]);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        glo[a] = uniform_f(wave_min_f(glo[a]));
+        ghi[a] = uniform_f(wave_max_f(ghi[a]));
+    }
+    float gbest;   // the group's worst running best: a subtree farther than this cannot matter to any lane
+    {
+        float b = best[0];
+#pragma unroll
+        for (int r = 1; r < R; r++) b = fmaxf(b, best[r]);
+        gbest = uniform_f(wave_max_f(b));
+    }
+
+    const int first_leaf = tree_n_pad - 1;
+    // traversal stack across the lanes of two VGPRs (entry k lives in lane k), indexed by the scalar stack pointer
+    int st_node = 0;
+    int st_lb = 0;
+    int sp = 0;
+    int node = 0;
+    bool have;
+    {
+        const float lb = uniform_f(box_bound<FMA>(tree_boxes[0], tree_boxes[1], glo, ghi));
+        have = lb <= gbest && lb < __builtin_inff();
+    }
+    while (true) {
+        if (!have) {
+            bool found = false;
+            while (sp > 0) {
+                sp--;
+                const float lb = __int_as_float(__builtin_amdgcn_readlane(st_lb, sp));
+                if (lb <= gbest) { node = __builtin_amdgcn_readlane(st_node, sp); found = true; break; }
+            }
+            if (!found) break;
+        }
+        have = false;
+        node = __builtin_amdgcn_readfirstlane(node);   // wave-uniform by construction; say so, so the loads below are scalar
+        if (node >= first_leaf) {
+            const float4* __restrict__ lp = tree_pts + (size_t)(node - first_leaf) * TREE_LEAF;   // wave-uniform: scalar loads
+#pragma unroll
+            for (int k = 0; k < TREE_LEAF; k++) {
+                const float4 q = lp[k];
+                const unsigned int j = (unsigned int)__float_as_int(q.w);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const float d = sq3<FMA>(q.x - px[r], q.y - py[r], q.z - pz[r]);
+                    const bool better = (d < best[r]) | ((d == best[r]) & (j < bidx[r]));
+                    best[r] = better ? d : best[r];
+                    bidx[r] = better ? j : bidx[r];
+                }
+            }
+            float b = best[0];
+#pragma unroll
+            for (int r = 1; r < R; r++) b = fmaxf(b, best[r]);
+            gbest = uniform_f(wave_max_f(b));
+        } else {
+            const int l = 2 * node + 1;
+            const float4* __restrict__ rec = tree_boxes + 2 * (size_t)l;   // {lo_l, hi_l, lo_r, hi_r}: one 64-byte scalar load
+            const float lbl = uniform_f(box_bound<FMA>(rec[0], rec[1], glo, ghi));
+            const float lbr = uniform_f(box_bound<FMA>(rec[2], rec[3], glo, ghi));
+            const bool left_near = lbl <= lbr;
+            const int near = left_near ? l : l + 1, far = left_near ? l + 1 : l;
+            const float lbn = left_near ? lbl : lbr, lbf = left_near ? lbr : lbl;
+            if (lbf <= gbest && lbf < __builtin_inff()) {
+                st_node = write_lane(st_node, far, sp);
+                st_lb = write_lane(st_lb, __float_as_int(lbf), sp);
+                sp++;
+            }
+            if (lbn <= gbest && lbn < __builtin_inff()) { node = near; have = true; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = base + r * 64 + lane;
+        if (i < n && best[r] < __builtin_inff()) keys[i] = ((unsigned long long)__float_as_uint(best[r]) << 32) | bidx[r];
+    }
+}
+
+// Per-lane form: every lane walks the hierarchy for its own source (degenerate group glo = ghi = s), per-lane stack in LDS
+// (column per lane).  Divergent, but prunes with the lane's OWN best: the better form while the search radius is large
+// compared with the extent of a wave's 64 neighbours (early ICP iterations).
 template <bool FMA>
-__global__ __launch_bounds__(256) void nn_tree_query_kernel(NnTreeView t, const float* __restrict__ sx, const float* __restrict__ sy,
-                                                            const float* __restrict__ sz, int n, unsigned long long* __restrict__ keys,
-                                                            const int* __restrict__ done_flag, int stack_depth)
+__global__ __launch_bounds__(256) void nn_tree_lane_kernel(const float4* __restrict__ tree_pts, const float4* __restrict__ tree_boxes,
+                                                           int tree_n_pad, const float* __restrict__ sx, const float* __restrict__ sy,
+                                                           const float* __restrict__ sz, int n, unsigned long long* __restrict__ keys,
+                                                           const int* __restrict__ done_flag, int stack_depth)
 {
     if (done_flag != nullptr && *done_flag != 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -192,24 +380,19 @@ __global__ __launch_bounds__(256) void nn_tree_query_kernel(NnTreeView t, const 
 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float px = sx[i], py = sy[i], pz = sz[i];
-
-    // starting candidate: the key already posted for this source (KEY_INIT -> none)
+    const float p[3] = {sx[i], sy[i], sz[i]};
     const unsigned long long k0 = keys[i];
-    unsigned int hi0 = (unsigned int)(k0 >> 32);
+    const unsigned int hi0 = (unsigned int)(k0 >> 32);
     float best = hi0 < 0x7f800000u ? __uint_as_float(hi0) : __builtin_inff();
-    // no candidate yet: (inf, 0) -- no index is < 0, so a point at overflowed distance +inf is never accepted, exactly like
-    // the brute-force kernel's strict 'd < inf'
     unsigned int bidx = hi0 < 0x7f800000u ? (unsigned int)(k0 & 0xffffffffull) : 0u;
 
-    const int first_leaf = t.n_pad - 1;
+    const int first_leaf = tree_n_pad - 1;
     int sp = 0;
     int node = 0;
-    float node_lb = box_bound<FMA>(t.box_lo[0], t.box_hi[0], px, py, pz);
-    bool have = node_lb <= best && node_lb < __builtin_inff();
+    const float root_lb = box_bound<FMA>(tree_boxes[0], tree_boxes[1], p, p);
+    bool have = root_lb <= best && root_lb < __builtin_inff();
     while (true) {
         if (!have) {
-            // pop until an entry that can still matter
             bool found = false;
             while (sp > 0) {
                 sp--;
@@ -220,20 +403,23 @@ __global__ __launch_bounds__(256) void nn_tree_query_kernel(NnTreeView t, const 
         }
         have = false;
         if (node >= first_leaf) {
-            const float4* __restrict__ lp = t.pts + (size_t)(node - first_leaf) * TREE_LEAF;
+            const float4* __restrict__ lp = tree_pts + (size_t)(node - first_leaf) * TREE_LEAF;
 #pragma unroll
             for (int k = 0; k < TREE_LEAF; k++) {
                 const float4 q = lp[k];
-                const float d = sq3<FMA>(q.x - px, q.y - py, q.z - pz);
+                const float d = sq3<FMA>(q.x - p[0], q.y - p[1], q.z - p[2]);
                 const unsigned int j = (unsigned int)__float_as_int(q.w);
-                if (d < best || (d == best && j < bidx)) { best = d; bidx = j; }
+                const bool better = (d < best) | ((d == best) & (j < bidx));
+                best = better ? d : best;
+                bidx = better ? j : bidx;
             }
         } else {
-            const int l = 2 * node + 1, r = l + 1;
-            const float lbl = box_bound<FMA>(t.box_lo[l], t.box_hi[l], px, py, pz);
-            const float lbr = box_bound<FMA>(t.box_lo[r], t.box_hi[r], px, py, pz);
+            const int l = 2 * node + 1;
+            const float4* __restrict__ rec = tree_boxes + 2 * (size_t)l;
+            const float lbl = box_bound<FMA>(rec[0], rec[1], p, p);
+            const float lbr = box_bound<FMA>(rec[2], rec[3], p, p);
             const bool left_near = lbl <= lbr;
-            const int near = left_near ? l : r, far = left_near ? r : l;
+            const int near = left_near ? l : l + 1, far = left_near ? l + 1 : l;
             const float lbn = left_near ? lbl : lbr, lbf = left_near ? lbr : lbl;
             if (lbf <= best && lbf < __builtin_inff()) {
                 st_node[sp * 256 + threadIdx.x] = far;
@@ -247,14 +433,27 @@ __global__ __launch_bounds__(256) void nn_tree_query_kernel(NnTreeView t, const 
 }
 
 hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, const float* sz, int n, unsigned long long* keys,
-                         const int* done_flag, int fma, hipStream_t s)
+                         const int* done_flag, int fma, int R, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    const int depth = t.height + 2;
-    const size_t lds = (size_t)depth * 256 * 8;
-    dim3 grid((n + 255) / 256), block(256);
-    if (fma) hipLaunchKernelGGL(nn_tree_query_kernel<true>, grid, block, lds, s, t, sx, sy, sz, n, keys, done_flag, depth);
-    else hipLaunchKernelGGL(nn_tree_query_kernel<false>, grid, block, lds, s, t, sx, sy, sz, n, keys, done_flag, depth);
+    if (R <= 0) {   // per-lane form
+        const int depth = t.height + 2;
+        const size_t lds = (size_t)depth * 256 * 8;
+        dim3 grid((n + 255) / 256), block(256);
+        if (fma) hipLaunchKernelGGL(nn_tree_lane_kernel<true>, grid, block, lds, s, t.pts, t.boxes, t.n_pad, sx, sy, sz, n, keys, done_flag, depth);
+        else hipLaunchKernelGGL(nn_tree_lane_kernel<false>, grid, block, lds, s, t.pts, t.boxes, t.n_pad, sx, sy, sz, n, keys, done_flag, depth);
+        return hipGetLastError();
+    }
+    if (t.height + 2 > 64) return hipErrorInvalidValue;   // the stack is one VGPR wide
+    const int per_block = 4 * 64 * R;
+    dim3 grid((n + per_block - 1) / per_block), block(256);
+    if (R == 2) {
+        if (fma) hipLaunchKernelGGL((nn_tree_wave_kernel<2, true>), grid, block, 0, s, t.pts, t.boxes, t.n_pad, sx, sy, sz, n, keys, done_flag);
+        else hipLaunchKernelGGL((nn_tree_wave_kernel<2, false>), grid, block, 0, s, t.pts, t.boxes, t.n_pad, sx, sy, sz, n, keys, done_flag);
+    } else {
+        if (fma) hipLaunchKernelGGL((nn_tree_wave_kernel<1, true>), grid, block, 0, s, t.pts, t.boxes, t.n_pad, sx, sy, sz, n, keys, done_flag);
+        else hipLaunchKernelGGL((nn_tree_wave_kernel<1, false>), grid, block, 0, s, t.pts, t.boxes, t.n_pad, sx, sy, sz, n, keys, done_flag);
+    }
     return hipGetLastError();
 }
 

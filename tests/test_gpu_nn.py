@@ -86,6 +86,21 @@ def test_tree_equals_bruteforce_on_clustered_and_degenerate_clouds(ctx, capi, mo
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
 
 
+@pytest.mark.parametrize("tree_r", ["1", "2"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_wave_cooperative_walk_is_exact_too(ctx, capi, oracle, monkeypatch, tree_r, mode):
+    # the alternative query form (one hierarchy walk per wave, scalar loads, stack across the lanes of a VGPR)
+    monkeypatch.setenv("MISLAM_TREE_R", tree_r)
+    rng = np.random.default_rng(31)
+    base = rng.uniform(-5, 5, (6000, 3)).astype(np.float32)
+    tgt = np.concatenate([base, base[:2000]])                       # duplicates: ties
+    src = np.concatenate([base[100:900], (base[:3000] + rng.normal(scale=0.05, size=(3000, 3))).astype(np.float32),
+                          rng.uniform(-20, 20, (333, 3)).astype(np.float32)])
+    idx, d2 = ctx.nn_search(src, tgt, mode, capi.NN_TREE)
+    ridx, rd2 = oracle.nn_search(src, tgt, dist_mode=mode)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2.view(np.uint32), rd2.view(np.uint32))
+
+
 def test_large_sampled_rows_and_properties(ctx, capi, oracle):
     # BASELINE size class (cfg 2, N = M = 1e5): full check is 1e10 pairs -- the oracle re-computes a sample of source rows;
     # the rest is covered by size-independent properties (self-search is the identity with d2 = 0; the reported d2 is the
