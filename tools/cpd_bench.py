@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Developer tool: times the rigid-CPD path (cfg 4: bunny clouds, exact Gaussian P) with the VALU and the MFMA form of the
+P~.[X|1] contraction, plus a larger synthetic case.  Prints one JSON line per case.  Used for DESIGN.md's CPD numbers and as
+the command under rocprofv3 for the MFMA counters (profiles/)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+
+def main():
+    capi = load_package().capi
+    z = np.load(os.path.join(ROOT, "tests", "golden", "bunny_clouds.npz"))
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "bunny_cpd.json")))
+    cases = [("bunny_14904", z["before"], z["after"], gold["sigma2_init"])]
+    if "--big" in sys.argv:
+        rng = np.random.default_rng(3)
+        b = rng.uniform(-5, 5, (60000, 3)).astype(np.float32)
+        a = (b[rng.permutation(60000)] + 0.3).astype(np.float32)
+        cases.append(("synthetic_60000", b, a, 0.0))
+    ctx = capi.Context(0)
+    for name, before, after, s2 in cases:
+        for mfma in ("1", "0"):
+            os.environ["MISLAM_CPD_MFMA"] = mfma
+            p = capi.cpd_params(max_iterations=50, const_scale=0, sigma2_init=s2)
+            ctx.cpd_register(before, after, p)          # warm-up (allocations, code load)
+            ctx.profile_enable(True)
+            ctx.profile_reset()
+            t0 = time.perf_counter()
+            sR, t, scale, it, err = ctx.cpd_register(before, after, p)
+            wall = time.perf_counter() - t0
+            prof = {capi.KERNEL_NAMES[k]: ctx.profile_get(k) for k in (capi.KERNEL_CPD_DENOM, capi.KERNEL_CPD_CONTRACT, capi.KERNEL_CPD_MSTEP)}
+            ctx.profile_enable(False)
+            m, n = len(before), len(after)
+            pairs = float(m) * n
+            den_ms = prof["cpd_denom"][0] / max(prof["cpd_denom"][1], 1)
+            con_ms = prof["cpd_contract"][0] / max(prof["cpd_contract"][1], 1)
+            print(json.dumps({"case": name, "contraction": "mfma_4x4x1" if mfma == "1" else "valu", "iterations": it,
+                              "wall_ms_total": wall * 1e3, "ms_per_em_iteration": wall * 1e3 / max(it, 1),
+                              "K7a_denominator_ms": den_ms, "K7b_contraction_ms": con_ms,
+                              "K8_mstep_ms": prof["cpd_mstep"][0] / max(prof["cpd_mstep"][1], 1),
+                              "K7a_pairs_per_s": pairs / (den_ms * 1e-3), "K7b_pairs_per_s": pairs / (con_ms * 1e-3),
+                              "t": [float(x) for x in t], "sigma2": err}), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
