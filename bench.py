@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--points", type=int, default=1000000, help="N = M, BASELINE.json: 10^6")
     ap.add_argument("--dist-mode", type=int, default=0, help="0 = cpu-slam rounding (parity default), 1 = fma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", choices=["auto", "target", "source"], default="auto",
+                    help="what N > 1 GPUs split: auto = moving cloud for the box hierarchy, fixed cloud for the every-pair search")
     ap.add_argument("--brute-ref-steps", type=int, default=2,
                     help="untimed every-pair steps measured after the timed region when the box hierarchy was used (0 = skip)")
     ap.add_argument("--nn", choices=["auto", "brute", "tree"], default="auto",
@@ -102,8 +104,11 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
 
+    # MISLAM_BENCH_FORCE_DIST=1 takes the multi-process path (gloo bootstrap, RCCL communicator) even with one rank:
+    # the rehearsal a single-GPU box allows
+    use_dist = world > 1 or os.environ.get("MISLAM_BENCH_FORCE_DIST") == "1"
     dist = None
-    if world > 1:
+    if use_dist:
         # torch first: its bundled HIP/RCCL runtime must be the one in the process before libmislam.so is loaded
         import torch  # noqa: F401
         import torch.distributed as dist
@@ -117,7 +122,7 @@ def main():
     before, after = synth_cloud(np, args.points)
     n, m = len(before), len(after)
 
-    if world > 1:
+    if use_dist:
         uid = [capi.dist_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx = capi.Context(local_rank, rank, world, uid[0])
@@ -132,7 +137,19 @@ def main():
 
     # eps = 0: the device-side stop rule is evaluated every step and never fires -> every step is a full iteration
     nn_mode = {"auto": capi.NN_AUTO, "brute": capi.NN_BRUTEFORCE, "tree": capi.NN_TREE}[args.nn]
-    params = capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=nn_mode)
+    shard_mode = {"auto": capi.SHARD_AUTO, "target": capi.SHARD_TARGET, "source": capi.SHARD_SOURCE}[args.shard]
+    # what the library will do with these settings (mi_slam.h MI_NN_AUTO / MI_SHARD_AUTO), for the report below
+    per_rank_m = m // world
+    tree_if = lambda mm: args.nn == "tree" or (args.nn == "auto" and mm >= capi.NN_TREE_MIN_POINTS)
+    source_sharded = use_dist and (args.shard == "source" or (args.shard == "auto" and tree_if(m)))
+    if source_sharded:
+        slo, shi = capi.shard_range(n, rank, world)
+        n_local, m_local = shi - slo, m
+    else:
+        lo, hi = capi.shard_range(m, rank, world)
+        n_local, m_local = n, hi - lo
+    used_tree = tree_if(m_local)
+    params = capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=nn_mode, shard_mode=shard_mode)
     ctx.icp_load(before, after, params)            # H2D upload + SoA conversion: outside the timed region
     if args.warmup > 0:
         ctx.icp_run(args.warmup)
@@ -152,15 +169,13 @@ def main():
 
     prof = {capi.KERNEL_NAMES[k]: ctx.profile_get(k) for k in range(len(capi.KERNEL_NAMES))}
     R, t, iters, err, why = ctx.icp_result()
-    lo, hi = capi.shard_range(m, rank, world)
-    m_local = hi - lo
-    used_tree = args.nn == "tree" or (args.nn == "auto" and m_local >= 32768)
 
     # Outside the timed region: the same steps with the every-pair search (K1), for the brute-force roofline figures the
     # north star asks for.  Same keys, same registration -- only the number of evaluated pairs differs.
     brute_prof = None
     if used_tree and args.brute_ref_steps > 0:
-        ctx.icp_load(before, after, capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=capi.NN_BRUTEFORCE))
+        ctx.icp_load(before, after, capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=capi.NN_BRUTEFORCE,
+                                                    shard_mode=capi.SHARD_SOURCE if source_sharded else capi.SHARD_TARGET))
         ctx.icp_run(1)
         ctx.profile_reset()
         ctx.icp_run(args.brute_ref_steps)
@@ -169,7 +184,7 @@ def main():
 
     def nn_figures(nn_ms, nn_n, brute):
         nn_avg_s = nn_ms / max(nn_n, 1) * 1e-3
-        alg_bytes = 20.0 * n + 12.0 * m_local          # 12N source xyz + 8N packed key out + 12 M_local target xyz
+        alg_bytes = 20.0 * n_local + 12.0 * m_local    # this rank: 12 B source xyz + 8 B packed key per moving point, 12 B per fixed point
         achieved_gbs = alg_bytes / nn_avg_s / 1e9
         fig = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                "traffic": None, "kernel": "nn_bruteforce_kernel" if brute else "nn_tree_lane_kernel",
@@ -177,7 +192,7 @@ def main():
         if world == 1 and args.dist_mode == 0:
             fig["traffic"], fig["traffic_source"] = committed_traffic("icp_synthetic_uniform_n%d" % n, fig["kernel"])
         if brute:
-            pairs_per_s = n * float(m_local) / nn_avg_s
+            pairs_per_s = n_local * float(m_local) / nn_avg_s
             lane_ops = pairs_per_s * OPS_PER_PAIR[args.dist_mode]
             fig["valu"] = {"bound": "fp32-valu-issue", "achieved": lane_ops, "peak": VALU_LANE_OPS_PEAK, "unit": "lane-ops/s",
                            "frac": lane_ops / VALU_LANE_OPS_PEAK, "pairs_per_s": pairs_per_s,
@@ -196,7 +211,11 @@ def main():
             "config": {"workload": "icp_synthetic_uniform_n%d" % n, "n_before": n, "n_after": m,
                        "nn": "box-hierarchy (exact)" if used_tree else "bruteforce",
                        "dist_arithmetic": "cpu_rounding" if args.dist_mode == 0 else "fma",
-                       "compose": "cpu_additive", "parallelism": "target-shard x%d, RCCL u64-min all-reduce" % world,
+                       "compose": "cpu_additive",
+                       "parallelism": ("single GPU" if world == 1 else
+                                       "moving cloud sharded x%d, fixed cloud replicated, RCCL 16+2-double sum all-reduces" % world
+                                       if source_sharded else
+                                       "fixed cloud sharded x%d, RCCL u64-min all-reduce of the packed keys + 16+2-double sums" % world),
                        "error_after_steps": err},
             "roofline": nn_figures(prof["nn"][0], prof["nn"][1], not used_tree),
             "kernels_ms_per_step": {k: (v[0] / args.steps) for k, v in prof.items() if v[1] > 0},

@@ -110,6 +110,7 @@ struct mi_ctx {
     bool icp_loaded = false;
     int n = 0, n_pad = 0;
     int m_total = 0, shard_lo = 0, shard_hi = 0;
+    bool source_sharded = false;                         // MI_SHARD_SOURCE in effect: n = this rank's slice, fixed cloud replicated
     mi_icp_params icp{};
 
     // ---- CPD workspace (allocated on first use)

@@ -395,11 +395,12 @@ static int allreduce_doubles(mi_ctx* c, double* dev_ptr, int count)
 static void shard_range(int m_total, int rank, int world, int* lo, int* hi) { (void)mi_shard_range(m_total, rank, world, lo, hi); }
 
 // Uploads this rank's shard of the fixed cloud (SoA streams for K1 + float4 for gathers).
-static int upload_target_shard(mi_ctx* c, const float* after_xyz, int m_total)
+static int upload_target_shard(mi_ctx* c, const float* after_xyz, int m_total, bool replicate = false)
 {
     c->m_total = m_total;
     c->tree_valid = false;   // the hierarchy indexes the previous shard
-    shard_range(m_total, c->rank, c->world, &c->shard_lo, &c->shard_hi);
+    if (replicate) { c->shard_lo = 0; c->shard_hi = m_total; }      // source-sharded: every rank holds the whole fixed cloud
+    else shard_range(m_total, c->rank, c->world, &c->shard_lo, &c->shard_hi);
     const int m_local = c->shard_hi - c->shard_lo;
     const size_t len = target_alloc_len(m_local);
     MI_TRY(c->tx.reserve(len)); MI_TRY(c->ty.reserve(len)); MI_TRY(c->tz.reserve(len));
@@ -471,6 +472,7 @@ static int icp_check_params(const mi_icp_params* p)
     if (p->compose_mode != MI_COMPOSE_CPU_ADDITIVE && p->compose_mode != MI_COMPOSE_EXACT) { set_error("ICP: bad compose_mode %d", p->compose_mode); return MI_ERR_INVALID_ARG; }
     if (p->max_iterations < -1) { set_error("ICP: max_iterations %d (use -1 for unbounded)", p->max_iterations); return MI_ERR_INVALID_ARG; }
     if (p->nn_mode != MI_NN_AUTO && p->nn_mode != MI_NN_BRUTEFORCE && p->nn_mode != MI_NN_TREE) { set_error("ICP: bad nn_mode %d", p->nn_mode); return MI_ERR_INVALID_ARG; }
+    if (p->shard_mode != MI_SHARD_AUTO && p->shard_mode != MI_SHARD_TARGET && p->shard_mode != MI_SHARD_SOURCE) { set_error("ICP: bad shard_mode %d", p->shard_mode); return MI_ERR_INVALID_ARG; }
     return MI_OK;
 }
 
@@ -498,11 +500,24 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
 {
     if (!c) { set_error("mi_icp_load: null context"); return MI_ERR_INVALID_ARG; }
     if (!before_xyz || !after_xyz || n_before <= 0 || n_after <= 0) { set_error("mi_icp_load: empty or null cloud (n_before=%d, n_after=%d)", n_before, n_after); return MI_ERR_INVALID_ARG; }
-    if (n_after < c->world) { set_error("mi_icp_load: fewer target points (%d) than ranks (%d)", n_after, c->world); return MI_ERR_INVALID_ARG; }
+    if (n_after < c->world || n_before < c->world) { set_error("mi_icp_load: fewer points (%d, %d) than ranks (%d)", n_before, n_after, c->world); return MI_ERR_INVALID_ARG; }
     MI_TRY(icp_check_params(params));
     MI_HIP(hipSetDevice(c->device));
     c->icp_loaded = false;
     c->icp = *params;
+    // what the ranks split (mi_slam.h MI_SHARD_*): decided from GLOBAL sizes, so every rank decides alike
+    c->source_sharded = false;
+    if (c->comm) {   // (a one-rank communicator takes the same path: that is what the single-GPU box can test)
+        const int per_rank = n_after / c->world;
+        const bool tree = resolve_nn_mode(params->nn_mode, params->shard_mode == MI_SHARD_TARGET ? per_rank : n_after) == MI_NN_TREE;
+        c->source_sharded = params->shard_mode == MI_SHARD_SOURCE || (params->shard_mode == MI_SHARD_AUTO && tree);
+    }
+    if (c->source_sharded) {
+        int slo = 0, shi = 0;
+        shard_range(n_before, c->rank, c->world, &slo, &shi);
+        before_xyz += 3 * (size_t)slo;
+        n_before = shi - slo;
+    }
     c->n = n_before;
     c->n_pad = round_up(n_before, NN_SRC_PAD);
     const size_t np = (size_t)c->n_pad;
@@ -514,7 +529,7 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
     // moving cloud: upload in the caller's order (cx.. as scratch), keep it Morton-sorted in bx..
     MI_TRY(upload_soa(c, before_xyz, n_before, c->n_pad, c->cx.p, c->cy.p, c->cz.p, nullptr));
     MI_TRY(sort_sources(c, c->cx.p, c->cy.p, c->cz.p, n_before, c->n_pad, c->bx.p, c->by.p, c->bz.p));
-    MI_TRY(upload_target_shard(c, after_xyz, n_after));
+    MI_TRY(upload_target_shard(c, after_xyz, n_after, c->source_sharded));
     c->icp_loaded = true;
     return mi_icp_reset(c);
 }
@@ -528,7 +543,7 @@ static int icp_enqueue_iteration(mi_ctx* c)
     const int nbp = icp_reduce_blocks(c->n_pad);
     // K1 (+ C1)
     MI_TRY(launch_nn(c, c->cx.p, c->cy.p, c->cz.p, c->n, m_local, c->shard_lo, v.fma, &c->d_state->done, c->icp.nn_mode));
-    MI_TRY(allreduce_keys(c, c->n));
+    if (!c->source_sharded) MI_TRY(allreduce_keys(c, c->n));   // source-sharded ranks hold disjoint moving points: nothing to merge
     // K2, K3
     { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_moments(v, c->part_mom.p, nb, c->stream)); }
     if (c->comm) {

@@ -54,6 +54,20 @@ enum {
     MI_NN_TREE = 2          /* exact search through a box hierarchy over the Morton-sorted fixed cloud */
 };
 
+/* What a multi-GPU context (mi_ctx_create_dist) splits across its ranks.  Same registration result either way.
+ *   TARGET: rank r owns fixed points [M*r/W, M*(r+1)/W) and ALL moving points; one ncclAllReduce(ncclUint64, ncclMin) of the
+ *           N packed (min-dist, argmin) keys per iteration, then owner-accumulated moments/error + two small sum all-reduces.
+ *           The every-pair search scales perfectly this way (its work is N*M/W per rank).
+ *   SOURCE: rank r owns moving points [N*r/W, N*(r+1)/W) and a replica of the fixed cloud (12 B/point: trivial at 288 GB);
+ *           no per-point exchange at all, only the 16- and 2-double sum all-reduces.  The box-hierarchy search needs this
+ *           split to scale: its cost per moving point hardly depends on how many fixed points a rank holds.
+ *   AUTO:   SOURCE when the search runs through the box hierarchy, TARGET when it is the every-pair search. */
+enum {
+    MI_SHARD_AUTO = 0,
+    MI_SHARD_TARGET = 1,
+    MI_SHARD_SOURCE = 2
+};
+
 /* How the per-iteration solve (Ri, ti) is accumulated into the running transform. */
 enum {
     MI_COMPOSE_CPU_ADDITIVE = 0,  /* R <- Ri*R ; t <- ti + t   -- source/cpu-slam/basicicp.cpp:43-44 (the oracle's rule) */
@@ -124,7 +138,8 @@ typedef struct {
                                     does not depend on this value. */
     int   verbose;               /* 1: print "loop_nr %d, error: %f" lines like basicicp.cpp:50 at every host check */
     int   nn_mode;               /* MI_NN_*: how the correspondence search is carried out; the RESULT is identical in every mode */
-    int   reserved[6];
+    int   shard_mode;            /* MI_SHARD_*: what a multi-GPU context splits across ranks (ignored with one rank) */
+    int   reserved[5];
 } mi_icp_params;
 
 /* Defaults = cpu-slam semantics (the parity oracle): CPU rounding, additive translation, filtered pairs, no abort. */

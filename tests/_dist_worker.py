@@ -70,6 +70,21 @@ def main():
     assert abs(te[0].item() - (dfull ** 2).sum()) < 1e-9 * max(1.0, (dfull ** 2).sum())
     assert te[1].item() == kept.sum()
 
+    # MI_SHARD_SOURCE: rank r owns moving points [N*r/W, N*(r+1)/W) and the whole fixed cloud; nothing per-point is exchanged,
+    # the moments / error sums of the slices add up to the unsharded ones
+    slo, shi = capi.shard_range(n, rank, world)
+    sidx, sd2 = O.nn_search(src[slo:shi], tgt, threads=1)
+    assert np.array_equal(sidx, ridx[slo:shi]) and np.array_equal(sd2.view(np.uint32), rd2[slo:shi].view(np.uint32))
+    skept = sd2 < np.float32(30.0)
+    ts = torch.from_numpy(moments(src[slo:shi], tgt, sidx, skept).copy())
+    dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+    assert ts[0].item() == full[0]
+    assert np.allclose(ts.numpy(), full, rtol=1e-12, atol=1e-9)
+    sdiff = tgt[sidx[skept]].astype(np.float64) - cur[slo:shi][skept]
+    tse = torch.tensor([float((sdiff ** 2).sum()), float(skept.sum())], dtype=torch.float64)
+    dist.all_reduce(tse, op=dist.ReduceOp.SUM)
+    assert abs(tse[0].item() - (dfull ** 2).sum()) < 1e-9 * max(1.0, (dfull ** 2).sum()) and tse[1].item() == kept.sum()
+
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:

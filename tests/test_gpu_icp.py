@@ -215,10 +215,12 @@ def test_world1_rccl_context_matches_plain_context(capi, bunny):
     uid = capi.dist_unique_id()
     with capi.Context(0, 0, 1, uid) as dctx, capi.Context(0) as sctx:
         assert dctx.rank_world() == (0, 1)
-        p = capi.icp_params(max_iterations=12, max_distance_squared=400.0)
-        a = dctx.icp_register(before, after, p)
-        b = sctx.icp_register(before, after, p)
-        assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        for nn_mode in (capi.NN_BRUTEFORCE, capi.NN_TREE):
+            for shard_mode in (capi.SHARD_TARGET, capi.SHARD_SOURCE, capi.SHARD_AUTO):
+                p = capi.icp_params(max_iterations=12, max_distance_squared=400.0, nn_mode=nn_mode, shard_mode=shard_mode)
+                a = dctx.icp_register(before, after, p)
+                b = sctx.icp_register(before, after, p)
+                assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (nn_mode, shard_mode)
         i1, d1 = dctx.nn_search(before[:1000], after)
         i2, d2 = sctx.nn_search(before[:1000], after)
         assert np.array_equal(i1, i2) and np.array_equal(d1, d2)

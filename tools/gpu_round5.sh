@@ -1,0 +1,11 @@
+#!/bin/bash
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+step() { name=$1; shift; echo "== $name"; "$@" > gpurun_out/$name.log 2>&1; rc=$?; echo "$name rc=$rc"; tail -n 3 gpurun_out/$name.log | cut -c1-700; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "killed: stopping"; exit $rc; fi; }
+step pytest_gpu timeout -k 10 900 python -m pytest tests -m gpu -q --timeout 600
+# rehearsal of the driver's multi-GPU launch line with one rank: torchrun + gloo bootstrap + RCCL communicator
+export MISLAM_BENCH_FORCE_DIST=1
+step bench_dist1_auto timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2
+step bench_dist1_target_brute timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 3 --warmup 1 --nn brute --shard target --points 200000
+step bench_dist1_target_tree timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29535 bench.py --gpus 1 --steps 5 --warmup 2 --nn tree --shard target
+exit 0
