@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmislam.so")
+LIB_PATH = os.environ.get("MISLAM_LIB") or os.path.join(_HERE, "libmislam.so")   # MISLAM_LIB: developer override (variant builds)
 
 MI_OK = 0
 DIST_CPU_ROUNDING, DIST_FMA = 0, 1

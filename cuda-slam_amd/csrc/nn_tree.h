@@ -4,7 +4,12 @@
 
 namespace mislam {
 
-constexpr int TREE_LEAF = 8;          // points per leaf (one leaf = 128 B of float4)
+#ifndef MISLAM_TREE_LEAF
+#define MISLAM_TREE_LEAF 16
+#endif
+// points per leaf.  Measured on MI355X (N = M = 1e6, ms per search early / near convergence; 1e7 early):
+//   4: 2.03 / 1.17 / 36.8    8: 1.84 / 1.08 / 33.3    16: 1.68 / 1.04 / 30.0    32: 1.62 / 1.06 / 28.0
+constexpr int TREE_LEAF = MISLAM_TREE_LEAF;
 constexpr int TREE_MAX_HEIGHT = 24;
 
 struct NnTreeView {

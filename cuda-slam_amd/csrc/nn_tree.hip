@@ -13,7 +13,7 @@
 //     degenerate group glo = ghi = s.)
 //
 // Build (once per fixed cloud / shard -- the fixed cloud does not move during ICP): bounding box -> 30-bit Morton codes ->
-// radix sort (rocPRIM device primitive; one-time index build, not the per-iteration path) -> leaves of 8 consecutive
+// radix sort (rocPRIM device primitive; one-time index build, not the per-iteration path) -> leaves of TREE_LEAF (16) consecutive
 // points as float4 (x, y, z, global-index bits) -> implicit binary heap of boxes over the leaves, padded to a power of two
 // with empty boxes.  Node i's children are 2i+1 and 2i+2 and their boxes are ADJACENT in memory: one 64-byte record.
 //
@@ -23,6 +23,9 @@
 //     per-lane stack in LDS, pruning with the lane's OWN best.  Neighbouring lanes take similar paths, so most node loads
 //     of a wave coalesce.  Measured on MI355X, N = M = 1e6 synthetic: 1.8 ms per search in early ICP iterations
 //     (radius 0.44, ~360 points inside the search sphere), 1.1 ms near convergence; 2.7 ms without the source sort.
+//   * per-lane, stackless (nn_tree_trail_kernel, MISLAM_TREE_R=-1): the heap numbering replaces the stack by a 32-bit trail of
+//     pending levels -- no LDS, full occupancy, but one extra box load per pending sibling: 1.84 / 1.09 ms, i.e. the walk is
+//     bound by vector-memory request throughput, not by occupancy.
 //   * wave-cooperative (nn_tree_wave_kernel, MISLAM_TREE_R=1|2): the wave walks the hierarchy ONCE for the whole group; every
 //     address is wave-uniform, so boxes and leaf points arrive through SCALAR loads and feed the VALU as SGPR operands (like
 //     K1), control flow is uniform, and the stack lives across the lanes of one VGPR (v_writelane / v_readlane indexed by
@@ -432,11 +435,81 @@ __global__ __launch_bounds__(256) void nn_tree_lane_kernel(const float4* __restr
     if (best < __builtin_inff()) keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
 }
 
+// Per-lane form without any stack: the heap numbering makes ancestors and siblings computable, so a 32-bit "trail" (bit l set
+// = the sibling of this lane's level-l ancestor is still to be visited) replaces the LDS stack.  Same visiting order as the
+// stack form (deepest pending sibling first); a pending sibling's bound is re-computed from its box when it comes up
+// (one 32-byte load) instead of being remembered.  No LDS at all, so occupancy is set by ~40 VGPRs alone.
+template <bool FMA>
+__global__ __launch_bounds__(256) void nn_tree_trail_kernel(const float4* __restrict__ tree_pts, const float4* __restrict__ tree_boxes,
+                                                            int tree_n_pad, const float* __restrict__ sx, const float* __restrict__ sy,
+                                                            const float* __restrict__ sz, int n, unsigned long long* __restrict__ keys,
+                                                            const int* __restrict__ done_flag)
+{
+    if (done_flag != nullptr && *done_flag != 0) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float p[3] = {sx[i], sy[i], sz[i]};
+    const unsigned long long k0 = keys[i];
+    const unsigned int hi0 = (unsigned int)(k0 >> 32);
+    float best = hi0 < 0x7f800000u ? __uint_as_float(hi0) : __builtin_inff();
+    unsigned int bidx = hi0 < 0x7f800000u ? (unsigned int)(k0 & 0xffffffffull) : 0u;
+
+    const int first_leaf = tree_n_pad - 1;
+    unsigned int trail = 0;
+    int node = 0, level = 0;
+    const float root_lb = box_bound<FMA>(tree_boxes[0], tree_boxes[1], p, p);
+    bool have = root_lb <= best && root_lb < __builtin_inff();
+    while (true) {
+        if (!have) {
+            bool found = false;
+            while (trail != 0) {
+                const int b = 31 - __builtin_clz(trail);          // deepest pending level
+                trail &= ~(1u << b);
+                const int anc = ((node + 1) >> (level - b)) - 1;  // this lane's ancestor at level b ...
+                const int sib = ((anc + 1) ^ 1) - 1;              // ... and its sibling
+                const float lb = box_bound<FMA>(tree_boxes[2 * (size_t)sib], tree_boxes[2 * (size_t)sib + 1], p, p);
+                node = sib; level = b;                            // (bits deeper than b are all clear now)
+                if (lb <= best && lb < __builtin_inff()) { found = true; break; }
+            }
+            if (!found) break;
+        }
+        have = false;
+        if (node >= first_leaf) {
+            const float4* __restrict__ lp = tree_pts + (size_t)(node - first_leaf) * TREE_LEAF;
+#pragma unroll
+            for (int k = 0; k < TREE_LEAF; k++) {
+                const float4 q = lp[k];
+                const float d = sq3<FMA>(q.x - p[0], q.y - p[1], q.z - p[2]);
+                const unsigned int j = (unsigned int)__float_as_int(q.w);
+                const bool better = (d < best) | ((d == best) & (j < bidx));
+                best = better ? d : best;
+                bidx = better ? j : bidx;
+            }
+        } else {
+            const int l = 2 * node + 1;
+            const float4* __restrict__ rec = tree_boxes + 2 * (size_t)l;
+            const float lbl = box_bound<FMA>(rec[0], rec[1], p, p);
+            const float lbr = box_bound<FMA>(rec[2], rec[3], p, p);
+            const bool left_near = lbl <= lbr;
+            const float lbn = left_near ? lbl : lbr, lbf = left_near ? lbr : lbl;
+            const bool go_near = lbn <= best && lbn < __builtin_inff();
+            const bool keep_far = lbf <= best && lbf < __builtin_inff();
+            // move to the near child either way: the trail is relative to the current node, and a pending far child is
+            // "the sibling of my ancestor at level+1"
+            node = left_near ? l : l + 1;
+            level += 1;
+            if (keep_far) trail |= 1u << level;
+            have = go_near;
+        }
+    }
+    if (best < __builtin_inff()) keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
+}
+
 hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, const float* sz, int n, unsigned long long* keys,
                          const int* done_flag, int fma, int R, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    if (R <= 0) {   // per-lane form
+    if (R == 0) {   // per-lane form with an LDS stack (default: 1.68 / 1.04 ms at N = M = 1e6 early / late; trail form 1.84 / 1.09)
         const int depth = t.height + 2;
         const size_t lds = (size_t)depth * 256 * 8;
         dim3 grid((n + 255) / 256), block(256);
@@ -444,6 +517,14 @@ hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, 
         else hipLaunchKernelGGL(nn_tree_lane_kernel<false>, grid, block, lds, s, t.pts, t.boxes, t.n_pad, sx, sy, sz, n, keys, done_flag, depth);
         return hipGetLastError();
     }
+    if (R < 0) {    // per-lane form, stackless trail (MISLAM_TREE_R=-1): no LDS, but re-loads a box per pending sibling
+        if (t.height > 30) return hipErrorInvalidValue;
+        dim3 grid((n + 255) / 256), block(256);
+        if (fma) hipLaunchKernelGGL(nn_tree_trail_kernel<true>, grid, block, 0, s, t.pts, t.boxes, t.n_pad, sx, sy, sz, n, keys, done_flag);
+        else hipLaunchKernelGGL(nn_tree_trail_kernel<false>, grid, block, 0, s, t.pts, t.boxes, t.n_pad, sx, sy, sz, n, keys, done_flag);
+        return hipGetLastError();
+    }
+    // R = 1, 2: wave-cooperative form
     if (t.height + 2 > 64) return hipErrorInvalidValue;   // the stack is one VGPR wide
     const int per_block = 4 * 64 * R;
     dim3 grid((n + per_block - 1) / per_block), block(256);

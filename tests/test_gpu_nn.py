@@ -86,10 +86,11 @@ def test_tree_equals_bruteforce_on_clustered_and_degenerate_clouds(ctx, capi, mo
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
 
 
-@pytest.mark.parametrize("tree_r", ["1", "2"])
+@pytest.mark.parametrize("tree_r", ["-1", "1", "2"])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_wave_cooperative_walk_is_exact_too(ctx, capi, oracle, monkeypatch, tree_r, mode):
-    # the alternative query form (one hierarchy walk per wave, scalar loads, stack across the lanes of a VGPR)
+def test_alternative_hierarchy_walks_are_exact_too(ctx, capi, oracle, monkeypatch, tree_r, mode):
+    # the alternative query forms: -1 = per-lane stackless trail walk (the default is the per-lane walk with an LDS stack);
+    # 1, 2 = one walk per wave (scalar loads, stack across the lanes of a VGPR)
     monkeypatch.setenv("MISLAM_TREE_R", tree_r)
     rng = np.random.default_rng(31)
     base = rng.uniform(-5, 5, (6000, 3)).astype(np.float32)
