@@ -34,6 +34,22 @@ __device__ __forceinline__ float sq_dist(float ax, float ay, float az, float bx,
     return (dx * dx + dy * dy) + dz * dz;
 }
 
+// exp(x) for the Gaussian affinities (x <= 0).  The libm-grade expf the compiler inlines costs ~17 VALU issue slots per call
+// (range reduction, ldexp, overflow/underflow selects) and is >60 % of a pair; this one is 9: the exponent x*log2(e) is formed
+// as a rounded product h plus its exact residual (fma) plus the low part of log2(e), 2^h comes from v_exp_f32 (1 ulp) and the
+// residual is applied to first order, 2^(h+r) = 2^h (1 + r ln 2) with |r| < 2^-23 |h|.  Max relative error ~2 ulp against
+// glibc's expf over [-104, 0]; results below FLT_MIN flush to zero (they add to a denominator >= c, c ~ 1e1..1e2).
+__device__ __forceinline__ float exp_neg(float x)
+{
+    const float L_hi = 1.44269502162933349609375f;     // float(log2 e)
+    const float L_lo = 1.925963033500011e-08f;         // log2 e - L_hi
+    const float h = x * L_hi;
+    float r = __builtin_fmaf(x, L_hi, -h);
+    r = __builtin_fmaf(x, L_lo, r);
+    const float e = __builtin_amdgcn_exp2f(h);
+    return __builtin_fmaf(e * r, 0.693147182464599609375f, e);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // sigma^2 initialisation: sum_ij |b_i - a_j|^2 = N sum|b|^2 + M sum|a|^2 - 2 (sum a).(sum b), O(M+N) in fp64
 // (CalculateSigmaSquared, cpdcuda.cu:65-78, is O(M*N); see mi_slam.h on why the closed form is used)
@@ -113,13 +129,13 @@ __global__ __launch_bounds__(256) void cpd_denominator_kernel(CpdView v)
         for (int u = 0; u < CPD_T; u++) {
             const float yx = v.yx[k + u], yy = v.yy[k + u], yz = v.yz[k + u];   // wave-uniform -> scalar loads
 #pragma unroll
-            for (int r = 0; r < R; r++) sum[r] += expf(mult * sq_dist(ax[r], ay[r], az[r], yx, yy, yz));
+            for (int r = 0; r < R; r++) sum[r] += exp_neg(mult * sq_dist(ax[r], ay[r], az[r], yx, yy, yz));
         }
     }
     for (; k < k_end; k++) {
         const float yx = v.yx[k], yy = v.yy[k], yz = v.yz[k];
 #pragma unroll
-        for (int r = 0; r < R; r++) sum[r] += expf(mult * sq_dist(ax[r], ay[r], az[r], yx, yy, yz));
+        for (int r = 0; r < R; r++) sum[r] += exp_neg(mult * sq_dist(ax[r], ay[r], az[r], yx, yy, yz));
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(256) void cpd_contract_kernel(CpdView v)
         const float4 w = v.xw4[x];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const float p = expf(mult * sq_dist(ax, ay, az, yx[r], yy[r], yz[r]));
+            const float p = exp_neg(mult * sq_dist(ax, ay, az, yx[r], yy[r], yz[r]));
             p1[r] += p * w.w;            // p1(k) += p/den          coherentpointdrift.cpp:210-211
             pxx[r] += p * w.x;           // px.row(k) += x * p/den  :212
             pxy[r] += p * w.y;
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(256) void cpd_contract_mfma_kernel(CpdView v)
     const float* __restrict__ wrec = reinterpret_cast<const float*>(v.xw4);
     for (int x = x_begin; x < x_end; x++) {
         const float ax = v.ax[x], ay = v.ay[x], az = v.az[x];
-        const float p = expf(mult * sq_dist(ax, ay, az, yx, yy, yz));
+        const float p = exp_neg(mult * sq_dist(ax, ay, az, yx, yy, yz));
         const float b = wrec[4 * (size_t)x + (lane & 3)];
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(p, b, acc, 0, 0, 0);
     }
