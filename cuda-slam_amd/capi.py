@@ -17,6 +17,7 @@ DIST_CPU_ROUNDING, DIST_FMA = 0, 1
 COMPOSE_CPU_ADDITIVE, COMPOSE_EXACT = 0, 1
 NN_AUTO, NN_BRUTEFORCE, NN_TREE = 0, 1, 2
 SHARD_AUTO, SHARD_TARGET, SHARD_SOURCE = 0, 1, 2
+SUM_EXACT, SUM_CPU_SEQUENTIAL = 0, 1
 NN_TREE_MIN_POINTS = 32768          # MI_NN_AUTO switches to the box hierarchy at this many fixed points (mi_slam.h)
 STOP_RUNNING, STOP_CONVERGED, STOP_MAX_ITERATIONS, STOP_NO_PAIRS, STOP_ERROR_INCREASED, STOP_TOLERANCE, STOP_SIGMA = range(7)
 (KERNEL_NN, KERNEL_MOMENTS, KERNEL_SOLVE, KERNEL_TRANSFORM, KERNEL_FINALIZE, KERNEL_ALLREDUCE, KERNEL_CPD_DENOM,
@@ -38,7 +39,7 @@ class IcpParams(C.Structure):
     _fields_ = [("eps", C.c_float), ("max_iterations", C.c_int), ("max_distance_squared", C.c_float),
                 ("dist_mode", C.c_int), ("compose_mode", C.c_int), ("filter_pairs", C.c_int),
                 ("abort_on_increase", C.c_int), ("sync_every", C.c_int), ("verbose", C.c_int), ("nn_mode", C.c_int),
-                ("shard_mode", C.c_int), ("reserved", C.c_int * 5)]
+                ("shard_mode", C.c_int), ("sum_mode", C.c_int), ("reserved", C.c_int * 4)]
 
 
 class CpdParams(C.Structure):

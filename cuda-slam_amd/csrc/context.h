@@ -105,6 +105,8 @@ struct mi_ctx {
     mislam::NnTreeView tree{};
     bool tree_valid = false;
     mislam::DevBuf<int> sorder;                          // Morton order of the moving cloud (sorted slot -> caller's index)
+    mislam::DevBuf<int> sinv;                            // its inverse (caller's index -> sorted slot), MI_SUM_CPU_SEQUENTIAL only
+    mislam::DevBuf<float> resid;                         // per-slot squared residuals, same mode
 
     // ---- ICP problem currently loaded
     bool icp_loaded = false;

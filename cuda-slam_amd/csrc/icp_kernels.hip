@@ -131,7 +131,10 @@ __global__ __launch_bounds__(256) void icp_reduce_error_kernel(IcpState* __restr
 // ---------------------------------------------------------------------------------------------------------------
 // K3: solve + compose (one lane).  partials == nullptr: the moments are already in state->mom (multi-GPU path).
 // ---------------------------------------------------------------------------------------------------------------
-__device__ void solve_from_moments(const double* mom, float Ri[9], float ti[3])
+// seq_b / seq_a (MI_SUM_CPU_SEQUENTIAL, else null): cpu-slam's sequential fp32 running sums of the kept pairs; its centroids
+// are those sums divided by (float)count (common.cpp:283), and t inherits their rounding.  The cross-covariance keeps the
+// fp64 form: replacing the exact centroids by the rounded ones changes H by n*da*db^T, ~1e-9 relative.
+__device__ void solve_from_moments(const double* mom, const float* seq_b, const float* seq_a, float Ri[9], float ti[3])
 {
     const double n = mom[0];
     const double cbx = mom[1] / n, cby = mom[2] / n, cbz = mom[3] / n;
@@ -145,8 +148,12 @@ __device__ void solve_from_moments(const double* mom, float Ri[9], float ti[3])
     // column-major like glm::mat3 (ConvertRotationMatrix, common.cpp:335-346)
     for (int c = 0; c < 3; c++)
         for (int r = 0; r < 3; r++) Ri[3 * c + r] = k.R.a[r][c];
-    const float fcb[3] = {(float)cbx, (float)cby, (float)cbz};
-    const float fca[3] = {(float)cax, (float)cay, (float)caz};
+    float fcb[3] = {(float)cbx, (float)cby, (float)cbz};
+    float fca[3] = {(float)cax, (float)cay, (float)caz};
+    if (seq_b != nullptr) {
+        const float fn = (float)n;
+        for (int d = 0; d < 3; d++) { fcb[d] = seq_b[d] / fn; fca[d] = seq_a[d] / fn; }
+    }
     // t = centroidAfter - R * centroidBefore (common.cpp:549), glm mat3*vec3 operation order
     for (int i = 0; i < 3; i++) ti[i] = fca[i] - ((Ri[i] * fcb[0] + Ri[3 + i] * fcb[1]) + Ri[6 + i] * fcb[2]);
 }
@@ -161,7 +168,7 @@ __device__ void mat3_mul_cm(const float a[9], const float b[9], float out[9])
 }
 
 __global__ __launch_bounds__(256) void icp_solve_kernel(IcpState* __restrict__ state, const double* __restrict__ partials, int nblocks,
-                                                        int compose_mode)
+                                                        int compose_mode, int seq_sums)
 {
     if (state->done != 0) return;
     __shared__ double lds[256];
@@ -182,7 +189,9 @@ __global__ __launch_bounds__(256) void icp_solve_kernel(IcpState* __restrict__ s
         return;
     }
     float Ri[9], ti[3];
-    solve_from_moments(mom, Ri, ti);
+    float seq_b[3], seq_a[3];
+    for (int d = 0; d < 3; d++) { seq_b[d] = state->seq_sum_b[d]; seq_a[d] = state->seq_sum_a[d]; }
+    solve_from_moments(mom, seq_sums ? seq_b : nullptr, seq_sums ? seq_a : nullptr, Ri, ti);
     for (int i = 0; i < 9; i++) state->Ri[i] = Ri[i];
     for (int i = 0; i < 3; i++) state->ti[i] = ti[i];
     float R[9], t[3];
@@ -231,6 +240,7 @@ __global__ __launch_bounds__(256) void icp_transform_error_kernel(IcpView v, dou
             const bool mine = gidx >= v.shard_lo && gidx < v.shard_hi;
             const bool kept = v.filter_pairs ? (d2 < v.max_distance_squared) : true;
             unsigned long long next_key = KEY_INIT;
+            float resid = 0.f;
             if (mine) {
                 const float4 a = v.tgt4[gidx - v.shard_lo];
                 const float dx = a.x - ox, dy = a.y - oy, dz = a.z - oz;
@@ -238,6 +248,7 @@ __global__ __launch_bounds__(256) void icp_transform_error_kernel(IcpView v, dou
                 if (kept) {
                     acc[0] += (double)e;
                     acc[1] += 1.0;
+                    resid = e;
                 }
                 // The old match under the new transform is a real candidate of the next search, evaluated with the
                 // search's own arithmetic, so its key is a valid starting bound for K1.
@@ -246,9 +257,77 @@ __global__ __launch_bounds__(256) void icp_transform_error_kernel(IcpView v, dou
             }
             if (rearm == 1) v.keys[i] = KEY_INIT;
             else if (rearm == 2) v.keys[i] = next_key;
+            if (v.resid != nullptr) v.resid[i] = resid;
         }
     }
     block_sum_store<ICP_ERRSUMS>(acc, partials + (size_t)blockIdx.x * ICP_ERRSUMS);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// MI_SUM_CPU_SEQUENTIAL: cpu-slam's running sums, bit for bit.
+// cpu-slam accumulates its centroids and its error with ONE sequential fp32 running sum each (std::accumulate over Point_f,
+// common.cpp:281-284; `diffSum +=`, :259-268), in the order of the kept pairs = the caller's point order.  At 2e4 points the
+// centroid is already 1.3e-4 off the exact mean, and the error feeds the stop rule -- so retracing cpu-slam's trajectory
+// beyond bunny size needs these very roundings.  A sequential fp32 sum cannot be re-associated, but it can be fed fast:
+// one wave per running sum, 64 terms gathered per step by the 64 lanes (in the caller's order, through inv_order), then
+// added one by one from lane registers via v_readlane.  A dropped pair contributes +0.0f, which leaves an fp32 sum
+// unchanged, so no flags are needed.  ~8 cycles per term: 3.3 ms per million points, paid only in this mode.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float seq_add64(float acc, float term)
+{
+#pragma unroll
+    for (int j = 0; j < 64; j++) acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(term), j));
+    return acc;
+}
+
+// 6 waves: wave w < 3 sums component w of the kept moving points, wave w >= 3 component w-3 of their matched fixed points
+__global__ __launch_bounds__(384) void icp_seq_centroid_kernel(IcpView v)
+{
+    if (v.state->done != 0) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (int i0 = 0; i0 < v.n; i0 += 64) {
+        const int i = i0 + lane;
+        float term = 0.f;
+        if (i < v.n) {
+            const int s = v.inv_order[i];
+            const unsigned long long key = v.keys[s];
+            const int gidx = (int)(unsigned int)(key & 0xffffffffull);
+            const float d2 = __uint_as_float((unsigned int)(key >> 32));
+            const bool kept = v.filter_pairs ? (d2 < v.max_distance_squared) : true;
+            if (kept) {
+                if (wave < 3) term = wave == 0 ? v.cx[s] : (wave == 1 ? v.cy[s] : v.cz[s]);
+                else {
+                    const float4 a = v.tgt4[gidx - v.shard_lo];
+                    term = wave == 3 ? a.x : (wave == 4 ? a.y : a.z);
+                }
+            }
+        }
+        acc = seq_add64(acc, term);
+    }
+    if (lane == 0) {
+        if (wave < 3) v.state->seq_sum_b[wave] = acc;
+        else v.state->seq_sum_a[wave - 3] = acc;
+    }
+}
+
+__global__ __launch_bounds__(64) void icp_seq_error_kernel(IcpView v)
+{
+    if (v.state->done != 0) return;
+    const int lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (int i0 = 0; i0 < v.n; i0 += 64) {
+        const int i = i0 + lane;
+        const float term = i < v.n ? v.resid[v.inv_order[i]] : 0.f;
+        acc = seq_add64(acc, term);
+    }
+    if (lane == 0) v.state->seq_sum_err = acc;
+}
+
+__global__ __launch_bounds__(256) void invert_order_kernel(const int* __restrict__ order, int n, int* __restrict__ inv)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s < n) inv[order[s]] = s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -271,7 +350,8 @@ __global__ __launch_bounds__(256) void icp_finalize_kernel(IcpState* __restrict_
     state->err[1] = e[1];
     // cpu-slam: mean over the surviving pairs (common.cpp:267); cuda-slam: sum / after.size() (cudacommon.cu:147)
     const double denom = rules.filter_pairs ? e[1] : (double)rules.m_total;
-    const float error = (float)(e[0] / denom);
+    float error = (float)(e[0] / denom);
+    if (rules.seq_sums) error = state->seq_sum_err / (float)denom;   // cpu-slam's own fp32 running sum / pair count (common.cpp:267)
     state->error = error;
     state->passes += 1;
     if (error < rules.eps) {                                       // basicicp.cpp:52 / icpcuda.cu:40
@@ -363,9 +443,28 @@ hipError_t icp_reduce_error(IcpState* state, const double* partials, int nblocks
     return hipGetLastError();
 }
 
-hipError_t icp_solve(IcpState* state, const double* partials, int nblocks, int compose_mode, hipStream_t s)
+hipError_t icp_solve(IcpState* state, const double* partials, int nblocks, int compose_mode, int seq_sums, hipStream_t s)
 {
-    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks, compose_mode);
+    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks, compose_mode, seq_sums);
+    return hipGetLastError();
+}
+
+hipError_t invert_order(const int* order, int n, int* inv, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(invert_order_kernel, dim3((n + 255) / 256), dim3(256), 0, s, order, n, inv);
+    return hipGetLastError();
+}
+
+hipError_t icp_seq_centroids(const IcpView& v, hipStream_t s)
+{
+    hipLaunchKernelGGL(icp_seq_centroid_kernel, dim3(1), dim3(384), 0, s, v);
+    return hipGetLastError();
+}
+
+hipError_t icp_seq_error(const IcpView& v, hipStream_t s)
+{
+    hipLaunchKernelGGL(icp_seq_error_kernel, dim3(1), dim3(64), 0, s, v);
     return hipGetLastError();
 }
 

@@ -55,6 +55,11 @@ struct IcpState {
     int pad_;
     double mom[ICP_MOMENTS];
     double err[ICP_ERRSUMS];
+    // MI_SUM_CPU_SEQUENTIAL only: cpu-slam's own sequential fp32 running sums over the kept pairs in the caller's order
+    float seq_sum_b[3];      // sum of the moving points        (GetCenterOfMass, common.cpp:281-284)
+    float seq_sum_a[3];      // sum of their matched fixed points
+    float seq_sum_err;       // sum of squared residuals         (GetMeanSquaredError, common.cpp:259-268)
+    float pad2_;
 };
 
 struct IcpView {
@@ -68,6 +73,8 @@ struct IcpView {
     int filter_pairs;
     float max_distance_squared;
     int fma;                         // distance arithmetic used when re-arming keys with the previous match
+    const int* inv_order;            // caller's index -> sorted slot (MI_SUM_CPU_SEQUENTIAL), else null
+    float* resid;                    // per sorted slot: squared residual of the kept pair, +0 otherwise (same mode), else null
 };
 
 struct IcpRules {
@@ -76,6 +83,7 @@ struct IcpRules {
     int filter_pairs;
     int abort_on_increase;
     int m_total;                     // |after| over all ranks
+    int seq_sums;                    // MI_SUM_CPU_SEQUENTIAL: the error comes from state->seq_sum_err
 };
 
 hipError_t fill_keys(unsigned long long* keys, int n, hipStream_t s);
@@ -88,10 +96,14 @@ int icp_reduce_blocks(int n);
 hipError_t icp_moments(const IcpView& v, double* partials, int nblocks, hipStream_t s);
 hipError_t icp_reduce_moments(IcpState* state, const double* partials, int nblocks, hipStream_t s);
 hipError_t icp_reduce_error(IcpState* state, const double* partials, int nblocks, hipStream_t s);
-hipError_t icp_solve(IcpState* state, const double* partials, int nblocks, int compose_mode, hipStream_t s);
+hipError_t icp_solve(IcpState* state, const double* partials, int nblocks, int compose_mode, int seq_sums, hipStream_t s);
 // rearm: 0 = leave keys, 1 = KEY_INIT, 2 = the previous match's key under the NEW transform (a real candidate: K1 then
 // starts from a tight bound and hardly ever takes its re-scan path)
 hipError_t icp_transform_error(const IcpView& v, double* partials, int nblocks, int rearm, hipStream_t s);
 hipError_t icp_finalize(IcpState* state, const double* partials, int nblocks, const IcpRules& rules, hipStream_t s);
+// MI_SUM_CPU_SEQUENTIAL: cpu-slam's sequential fp32 running sums, reproduced bit for bit (one wave per sum)
+hipError_t invert_order(const int* order, int n, int* inv, hipStream_t s);
+hipError_t icp_seq_centroids(const IcpView& v, hipStream_t s);
+hipError_t icp_seq_error(const IcpView& v, hipStream_t s);
 
 }  // namespace mislam

@@ -148,7 +148,7 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     c->tgt4.release(); c->keys.release(); c->part_mom.release(); c->part_err.release();
     c->idx_tmp.release(); c->keep_tmp.release();
     c->tcodes_in.release(); c->tcodes_out.release(); c->torder_in.release(); c->torder_out.release();
-    c->tbbox.release(); c->tsort_temp.release(); c->tpts.release(); c->tboxes.release(); c->sorder.release();
+    c->tbbox.release(); c->tsort_temp.release(); c->tpts.release(); c->tboxes.release(); c->sorder.release(); c->sinv.release(); c->resid.release();
     for (auto& s : c->spans) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->d_state) (void)hipFree(c->d_state);
@@ -423,6 +423,9 @@ static IcpView make_view(mi_ctx* c)
     v.filter_pairs = c->icp.filter_pairs;
     v.max_distance_squared = c->icp.max_distance_squared;
     v.fma = c->icp.dist_mode == MI_DIST_FMA;
+    const bool seq = c->icp.sum_mode == MI_SUM_CPU_SEQUENTIAL;
+    v.inv_order = seq ? c->sinv.p : nullptr;
+    v.resid = seq ? c->resid.p : nullptr;
     return v;
 }
 
@@ -473,6 +476,7 @@ static int icp_check_params(const mi_icp_params* p)
     if (p->max_iterations < -1) { set_error("ICP: max_iterations %d (use -1 for unbounded)", p->max_iterations); return MI_ERR_INVALID_ARG; }
     if (p->nn_mode != MI_NN_AUTO && p->nn_mode != MI_NN_BRUTEFORCE && p->nn_mode != MI_NN_TREE) { set_error("ICP: bad nn_mode %d", p->nn_mode); return MI_ERR_INVALID_ARG; }
     if (p->shard_mode != MI_SHARD_AUTO && p->shard_mode != MI_SHARD_TARGET && p->shard_mode != MI_SHARD_SOURCE) { set_error("ICP: bad shard_mode %d", p->shard_mode); return MI_ERR_INVALID_ARG; }
+    if (p->sum_mode != MI_SUM_EXACT && p->sum_mode != MI_SUM_CPU_SEQUENTIAL) { set_error("ICP: bad sum_mode %d", p->sum_mode); return MI_ERR_INVALID_ARG; }
     return MI_OK;
 }
 
@@ -502,6 +506,7 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
     if (!before_xyz || !after_xyz || n_before <= 0 || n_after <= 0) { set_error("mi_icp_load: empty or null cloud (n_before=%d, n_after=%d)", n_before, n_after); return MI_ERR_INVALID_ARG; }
     if (n_after < c->world || n_before < c->world) { set_error("mi_icp_load: fewer points (%d, %d) than ranks (%d)", n_before, n_after, c->world); return MI_ERR_INVALID_ARG; }
     MI_TRY(icp_check_params(params));
+    if (params->sum_mode == MI_SUM_CPU_SEQUENTIAL && c->comm) { set_error("mi_icp_load: MI_SUM_CPU_SEQUENTIAL needs a single-GPU context (the running sums follow one global point order)"); return MI_ERR_INVALID_ARG; }
     MI_HIP(hipSetDevice(c->device));
     c->icp_loaded = false;
     c->icp = *params;
@@ -529,6 +534,11 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
     // moving cloud: upload in the caller's order (cx.. as scratch), keep it Morton-sorted in bx..
     MI_TRY(upload_soa(c, before_xyz, n_before, c->n_pad, c->cx.p, c->cy.p, c->cz.p, nullptr));
     MI_TRY(sort_sources(c, c->cx.p, c->cy.p, c->cz.p, n_before, c->n_pad, c->bx.p, c->by.p, c->bz.p));
+    if (params->sum_mode == MI_SUM_CPU_SEQUENTIAL) {   // the sequential sums run in the CALLER's point order
+        MI_TRY(c->sinv.reserve((size_t)n_before));
+        MI_TRY(c->resid.reserve(np));
+        MI_HIP(invert_order(c->sorder.p, n_before, c->sinv.p, c->stream));
+    }
     MI_TRY(upload_target_shard(c, after_xyz, n_after, c->source_sharded));
     c->icp_loaded = true;
     return mi_icp_reset(c);
@@ -545,24 +555,28 @@ static int icp_enqueue_iteration(mi_ctx* c)
     MI_TRY(launch_nn(c, c->cx.p, c->cy.p, c->cz.p, c->n, m_local, c->shard_lo, v.fma, &c->d_state->done, c->icp.nn_mode));
     if (!c->source_sharded) MI_TRY(allreduce_keys(c, c->n));   // source-sharded ranks hold disjoint moving points: nothing to merge
     // K2, K3
+    const int seq = c->icp.sum_mode == MI_SUM_CPU_SEQUENTIAL;
     { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_moments(v, c->part_mom.p, nb, c->stream)); }
+    if (seq) { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_seq_centroids(v, c->stream)); }
     if (c->comm) {
         ProfScope ps(c, MI_KERNEL_SOLVE);
         MI_HIP(icp_reduce_moments(c->d_state, c->part_mom.p, nb, c->stream));
         MI_TRY(allreduce_doubles(c, c->d_state->mom, ICP_MOMENTS));
-        MI_HIP(icp_solve(c->d_state, nullptr, 0, c->icp.compose_mode, c->stream));
+        MI_HIP(icp_solve(c->d_state, nullptr, 0, c->icp.compose_mode, 0, c->stream));
     } else {
         ProfScope ps(c, MI_KERNEL_SOLVE);
-        MI_HIP(icp_solve(c->d_state, c->part_mom.p, nb, c->icp.compose_mode, c->stream));
+        MI_HIP(icp_solve(c->d_state, c->part_mom.p, nb, c->icp.compose_mode, seq, c->stream));
     }
     // K4+K5, K6
     { ProfScope ps(c, MI_KERNEL_TRANSFORM); MI_HIP(icp_transform_error(v, c->part_err.p, nbp, 2, c->stream)); }
+    if (seq) { ProfScope ps(c, MI_KERNEL_TRANSFORM); MI_HIP(icp_seq_error(v, c->stream)); }
     IcpRules rules{};
     rules.eps = c->icp.eps;
     rules.max_iterations = c->icp.max_iterations;
     rules.filter_pairs = c->icp.filter_pairs;
     rules.abort_on_increase = c->icp.abort_on_increase;
     rules.m_total = c->m_total;
+    rules.seq_sums = seq;
     if (c->comm) {
         ProfScope ps(c, MI_KERNEL_FINALIZE);
         MI_HIP(icp_reduce_error(c->d_state, c->part_err.p, nbp, c->stream));
@@ -590,9 +604,12 @@ extern "C" int mi_icp_run(mi_ctx* c, int max_new_iterations, int* iterations_don
     const int passes_before = c->h_state->passes;
     int batch = c->icp.sync_every;
     if (batch <= 0) {
-        // auto: large searches dwarf a host round trip (sync each iteration); small ones are launch-bound (batch them)
-        const double pairs = (double)c->n * (double)(c->shard_hi - c->shard_lo);
-        batch = pairs >= 2e9 ? 1 : (pairs >= 2e8 ? 4 : 8);
+        // auto: a long iteration dwarfs a host round trip (check after each one); short ones are launch-bound (batch them).
+        // Estimated from the measured rates: every-pair ~7e12 pairs/s, box hierarchy ~2 ns per moving point.
+        const int m_local = c->shard_hi - c->shard_lo;
+        const bool tree = resolve_nn_mode(c->icp.nn_mode, m_local) == MI_NN_TREE;
+        const double est_s = tree ? 2e-9 * (double)c->n : (double)c->n * (double)m_local / 7e12;
+        batch = est_s >= 5e-3 ? 1 : (est_s >= 2e-4 ? 4 : 8);
     }
     int enqueued = 0;
     while (!c->h_state->done && (max_new_iterations < 0 || enqueued < max_new_iterations)) {
@@ -728,7 +745,7 @@ extern "C" int mi_kabsch(mi_ctx* c, const float* src_xyz, int n, const float* tg
     const IcpView v = make_view(c);
     const int nb = icp_reduce_blocks(n);
     { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_moments(v, c->part_mom.p, nb, c->stream)); }
-    { ProfScope ps(c, MI_KERNEL_SOLVE); MI_HIP(icp_solve(c->d_state, c->part_mom.p, nb, MI_COMPOSE_EXACT, c->stream)); }
+    { ProfScope ps(c, MI_KERNEL_SOLVE); MI_HIP(icp_solve(c->d_state, c->part_mom.p, nb, MI_COMPOSE_EXACT, 0, c->stream)); }
     MI_TRY(icp_fetch_state(c));
     if (pairs_used) *pairs_used = c->h_state->pairs;
     if (c->h_state->pairs <= 0) { set_error("mi_kabsch: no pair kept"); return MI_ERR_INVALID_ARG; }

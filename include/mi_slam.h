@@ -68,6 +68,19 @@ enum {
     MI_SHARD_SOURCE = 2
 };
 
+/* How the two centroids and the error of an ICP iteration are summed.
+ *   EXACT:          fp64 two-stage sums (the default; correctly rounded to fp32 at the end).
+ *   CPU_SEQUENTIAL: cpu-slam's own arithmetic, bit for bit: ONE sequential fp32 running sum per quantity over the kept
+ *                   pairs in the caller's point order (GetCenterOfMass common.cpp:281-284, GetMeanSquaredError :259-268).
+ *                   That sum is 1.3e-4 off the exact mean at 2e4 points and worse beyond, and it feeds both the translation
+ *                   and the stop rule -- choose this mode to retrace cpu-slam's trajectory at sizes where its own summation
+ *                   noise exceeds the 1e-4 parity budget.  Single-GPU contexts only; costs ~3.3 ms per million points per
+ *                   iteration (a sequential fp32 sum cannot be re-associated). */
+enum {
+    MI_SUM_EXACT = 0,
+    MI_SUM_CPU_SEQUENTIAL = 1
+};
+
 /* How the per-iteration solve (Ri, ti) is accumulated into the running transform. */
 enum {
     MI_COMPOSE_CPU_ADDITIVE = 0,  /* R <- Ri*R ; t <- ti + t   -- source/cpu-slam/basicicp.cpp:43-44 (the oracle's rule) */
@@ -139,7 +152,8 @@ typedef struct {
     int   verbose;               /* 1: print "loop_nr %d, error: %f" lines like basicicp.cpp:50 at every host check */
     int   nn_mode;               /* MI_NN_*: how the correspondence search is carried out; the RESULT is identical in every mode */
     int   shard_mode;            /* MI_SHARD_*: what a multi-GPU context splits across ranks (ignored with one rank) */
-    int   reserved[5];
+    int   sum_mode;              /* MI_SUM_*: how the centroids and the error are summed */
+    int   reserved[4];
 } mi_icp_params;
 
 /* Defaults = cpu-slam semantics (the parity oracle): CPU rounding, additive translation, filtered pairs, no abort. */

@@ -209,6 +209,34 @@ def test_cfg2_size_properties(ctx, capi, oracle):
     assert frob(R1, t1, R64, ca - R64 @ cb) < 5e-6
 
 
+@pytest.mark.parametrize("n,iters", [(20000, 1), (20000, 6), (40000, 3)])
+def test_cpu_sequential_sums_retrace_cpu_slam_beyond_bunny_size(ctx, capi, oracle, n, iters):
+    # MI_SUM_CPU_SEQUENTIAL: cpu-slam's sequential fp32 centroid / error sums reproduced bit for bit.  With them the HIP path
+    # follows the oracle's trajectory at sizes where the exact-sum default is 1.3e-4+ away (see test_cfg2_size_properties):
+    # R|t within 5e-6 per iteration count, error within 2e-5 relative.
+    before, after, _, _ = synth_cloud(100000)
+    nb, na = before[:n], after[:n]
+    Ro, to, ito, eo = oracle.icp(nb, na, 1e-3, 1000.0, iters)
+    R, t, it, err = ctx.icp_register(nb, na, capi.icp_params(max_iterations=iters, sum_mode=capi.SUM_CPU_SEQUENTIAL))
+    assert it == ito
+    d = frob(R, t, Ro, to)
+    print("n=%d iters=%d |d(R|t)|_F vs oracle with cpu-slam's sums = %.3e" % (n, iters, d))
+    assert d < 5e-6 * iters + 5e-6
+    assert abs(err - eo) <= 2e-5 * eo        # the residuals themselves move with the ~1e-6 difference in R|t
+    Re, te, _, _ = ctx.icp_register(nb, na, capi.icp_params(max_iterations=iters))
+    assert frob(Re, te, Ro, to) > d          # the default (exact sums) is farther from cpu-slam than its own arithmetic
+
+
+def test_cpu_sequential_sums_on_bunny(ctx, capi, golden, bunny):
+    before, after = bunny
+    g = golden.json("bunny_icp.json")
+    p = capi.icp_params(eps=1e-3, max_iterations=50, max_distance_squared=400.0, sum_mode=capi.SUM_CPU_SEQUENTIAL)
+    R, t, it, err = ctx.icp_register(before, after, p)
+    d = frob(R, t, g["R"], g["t"])
+    print("bunny ICP with cpu-slam's sums: |d(R|t)|_F vs cpu-slam = %.3e" % d)
+    assert it == g["iterations"] and d < 1e-5 and abs(err - g["error"]) < 1e-7
+
+
 def test_world1_rccl_context_matches_plain_context(capi, bunny):
     # the multi-GPU code path (RCCL communicator, packed-min all-reduce, shard-local moments + sum all-reduce) with one rank
     before, after = bunny
