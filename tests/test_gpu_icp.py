@@ -209,11 +209,11 @@ def test_cfg2_size_properties(ctx, capi, oracle):
     assert frob(R1, t1, R64, ca - R64 @ cb) < 5e-6
 
 
-@pytest.mark.parametrize("n,iters", [(20000, 1), (20000, 6), (40000, 3)])
+@pytest.mark.parametrize("n,iters", [(20000, 1), (20000, 6), (40000, 3), (100000, 2)])   # the last one is cfg 2's size
 def test_cpu_sequential_sums_retrace_cpu_slam_beyond_bunny_size(ctx, capi, oracle, n, iters):
     # MI_SUM_CPU_SEQUENTIAL: cpu-slam's sequential fp32 centroid / error sums reproduced bit for bit.  With them the HIP path
     # follows the oracle's trajectory at sizes where the exact-sum default is 1.3e-4+ away (see test_cfg2_size_properties):
-    # R|t within 5e-6 per iteration count, error within 2e-5 relative.
+    # R|t within 1e-5 per iteration, error within 2e-5 relative.
     before, after, _, _ = synth_cloud(100000)
     nb, na = before[:n], after[:n]
     Ro, to, ito, eo = oracle.icp(nb, na, 1e-3, 1000.0, iters)
@@ -221,7 +221,7 @@ def test_cpu_sequential_sums_retrace_cpu_slam_beyond_bunny_size(ctx, capi, oracl
     assert it == ito
     d = frob(R, t, Ro, to)
     print("n=%d iters=%d |d(R|t)|_F vs oracle with cpu-slam's sums = %.3e" % (n, iters, d))
-    assert d < 5e-6 * iters + 5e-6
+    assert d < 1e-5 * iters + 5e-6           # measured: 4.8e-7, 2.0e-6, 6.7e-6, 1.3e-5 for the four cases
     assert abs(err - eo) <= 2e-5 * eo        # the residuals themselves move with the ~1e-6 difference in R|t
     Re, te, _, _ = ctx.icp_register(nb, na, capi.icp_params(max_iterations=iters))
     assert frob(Re, te, Ro, to) > d          # the default (exact sums) is farther from cpu-slam than its own arithmetic
