@@ -56,22 +56,26 @@ def committed_traffic(workload, kernel):
     return None, None
 
 
-def cpu_baseline(np, before, after, budget_pairs=4.0e10):
-    """The reference's cpu-slam correspondence search (>99 % of its iteration) on a bounded row sample."""
+def cpu_baseline(np, before, after, target_seconds=15.0):
+    """The reference's cpu-slam correspondence search (>99 % of its iteration) on a bounded row sample: a
+    short probe measures this host's pair rate, then the sample is sized for ~15 s of CPU work."""
     from oracle import refbind, oraclebind
     n, m = len(before), len(after)
-    rows = int(max(1, min(n, budget_pairs // m)))
     cores = os.cpu_count() or 1
     if refbind.available():
         kind = "reference"
-        t0 = time.perf_counter()
-        refbind.corresponding_points(before[:rows], after, 1000.0, True)
-        dt = time.perf_counter() - t0
+        search = lambda rows: refbind.corresponding_points(before[:rows], after, 1000.0, True)
     else:
         kind = "port"
-        t0 = time.perf_counter()
-        oraclebind.nn_search(before[:rows], after, threads=0)
-        dt = time.perf_counter() - t0
+        search = lambda rows: oraclebind.nn_search(before[:rows], after, threads=0)
+    probe_rows = int(max(cores, min(n, 2.0e9 // m)))
+    t0 = time.perf_counter()
+    search(probe_rows)
+    rate = probe_rows * float(m) / (time.perf_counter() - t0)
+    rows = int(max(probe_rows, min(n, rate * target_seconds // m)))
+    t0 = time.perf_counter()
+    search(rows)
+    dt = time.perf_counter() - t0
     full_iter_s = dt * (n / rows)
     return {"value": 1.0 / full_iter_s, "unit": "iterations/s", "cores": cores, "kind": kind,
             "sample": "GetCorrespondingPoints (common.cpp:441-507, %d threads) on %d of %d source rows x all %d targets: "

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Developer tool: the reference's benchmark sweeps on this path, in the reference's own CSV schema.
+
+The reference's `#define TEST` harness (source/common/testrunner.cpp:14,63-74) writes `<set>-<method>.csv` with the columns
+`test-no;cloud-size;rotation;translation;time(ms);iterations;error`, timing the WHOLE SlamFunc call -- device allocation,
+upload and release included (doc/documentation.tex:397).  This script does the same for the configurations of
+GetSizesTestSet / GetPerformanceTestSet (source/common/testset.cpp:48-117: same cloud as before/after, rotation 0.2 rad,
+translation 10, max-iterations 50, max-distance-squared 10000, cpd-weight 0.1, exact P for CPD), on synthetic uniform clouds
+of spread 10 (the reference's large OBJ files are missing blobs), through the one-call ABI entry points on host buffers.
+One extra column, ms-per-iteration, is what BASELINE.md's plot-derived rows quote.
+
+    python tools/sweep_sizes.py [outdir]      ->  outdir/performance-icp.csv, sizes-icp.csv, sizes-cpd.csv
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+from bench import synth_cloud  # noqa: E402
+
+HEADER = "test-no;cloud-size;rotation;translation;time(ms);iterations;error;ms-per-iteration\n"
+
+
+def run_set(ctx, capi, path, method, sizes):
+    with open(path, "w") as f:
+        f.write(HEADER)
+        for k, n in enumerate(sizes):
+            before, after = synth_cloud(np, n, seed=666 + k)
+            if method == "icp":
+                p = capi.icp_params(cuda_slam=True, max_iterations=50, eps=1e-3, max_distance_squared=10000.0)
+                t0 = time.perf_counter()
+                R, t, it, err = ctx.icp_register(before, after, p)
+                ms = (time.perf_counter() - t0) * 1e3
+                passes = it + 1 if err < 1e-3 else max(it, 1)
+            else:
+                p = capi.cpd_params(max_iterations=50, weight=0.1, const_scale=0, eps=1e-3, tolerance=1e-3)
+                t0 = time.perf_counter()
+                sR, t, sc, it, err = ctx.cpd_register(before, after, p)
+                ms = (time.perf_counter() - t0) * 1e3
+                passes = max(it, 1)
+            f.write("%d;%d;%f;%f;%d;%d;%f;%.4f\n" % (k, n, 0.2, 10.0, round(ms), it, err, ms / passes))
+            f.flush()
+            print(method, n, "%.2f ms" % ms, it, err, flush=True)
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "sweep")
+    os.makedirs(out, exist_ok=True)
+    capi = load_package().capi
+    ctx = capi.Context(0)
+    ctx.icp_register(*synth_cloud(np, 4096), capi.icp_params(cuda_slam=True, max_iterations=2))      # warm the code objects
+    # GetPerformanceTestSet: 25 000 ... 1 300 000 step 25 000 (every fifth size here, plus BASELINE.md's plot points)
+    perf = sorted(set(list(range(25000, 1300001, 125000)) + [50000, 100000, 500000, 1000000, 1300000]))
+    run_set(ctx, capi, os.path.join(out, "performance-icp.csv"), "icp", perf)
+    # GetSizesTestSet: ICP 1 000 ... 100 000 step 4 000 (every third), CPD 100 ... 1 000 step 100 (+ BASELINE.md's 10 000 / 49 000)
+    run_set(ctx, capi, os.path.join(out, "sizes-icp.csv"), "icp", list(range(1000, 100001, 12000)) + [10000])
+    run_set(ctx, capi, os.path.join(out, "sizes-cpd.csv"), "cpd", list(range(100, 1001, 100)) + [10000, 49000])
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
