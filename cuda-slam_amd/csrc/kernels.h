@@ -31,7 +31,7 @@ hipError_t nn_launch(const NnLaunch& a, hipStream_t stream);
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int ICP_MOMENTS = 16;              // count, sum b (3), sum a (3), sum a b^T (9)
 constexpr int ICP_ERRSUMS = 2;               // sum |a - b'|^2, kept pairs
-constexpr int ICP_MAX_PARTIAL_BLOCKS = 1024;
+constexpr int ICP_MAX_PARTIAL_BLOCKS = 512;   // 2 blocks per CU: enough loads in flight for the O(N) passes, few rows to reduce
 
 // mirror of the public MI_STOP_* values (mi_slam.h) for device code
 enum { MI_STOP_RUNNING_ = 0, MI_STOP_CONVERGED_ = 1, MI_STOP_MAX_ITERATIONS_ = 2, MI_STOP_NO_PAIRS_ = 3,
