@@ -21,8 +21,9 @@ SUM_EXACT, SUM_CPU_SEQUENTIAL = 0, 1
 NN_TREE_MIN_POINTS = 32768          # MI_NN_AUTO switches to the box hierarchy at this many fixed points (mi_slam.h)
 STOP_RUNNING, STOP_CONVERGED, STOP_MAX_ITERATIONS, STOP_NO_PAIRS, STOP_ERROR_INCREASED, STOP_TOLERANCE, STOP_SIGMA = range(7)
 (KERNEL_NN, KERNEL_MOMENTS, KERNEL_SOLVE, KERNEL_TRANSFORM, KERNEL_FINALIZE, KERNEL_ALLREDUCE, KERNEL_CPD_DENOM,
- KERNEL_CPD_CONTRACT, KERNEL_CPD_MSTEP) = range(9)
-KERNEL_NAMES = ["nn", "moments", "solve", "transform", "finalize", "allreduce", "cpd_denom", "cpd_contract", "cpd_mstep"]
+ KERNEL_CPD_CONTRACT, KERNEL_CPD_MSTEP, KERNEL_CPD_FGT) = range(10)
+KERNEL_NAMES = ["nn", "moments", "solve", "transform", "finalize", "allreduce", "cpd_denom", "cpd_contract", "cpd_mstep", "cpd_fgt"]
+CPD_APPROX_NONE, CPD_APPROX_FULL, CPD_APPROX_HYBRID = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 
 # every symbol include/mi_slam.h declares (tests check that the library exports each of them)
@@ -31,6 +32,7 @@ EXPORTS = [
     "mi_ctx_rank", "mi_shard_range", "mi_pack_key", "mi_unpack_key", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_icp_params_default", "mi_icp_params_cuda_slam",
     "mi_icp_register", "mi_icp_load", "mi_icp_reset", "mi_icp_run", "mi_icp_result", "mi_nn_search", "mi_nn_search_ex", "mi_kabsch",
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_estep",
+    "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_tables",
     "mi_cpd_mstep", "mi_profile_enable", "mi_profile_reset", "mi_profile_get",
 ]
 
@@ -45,7 +47,8 @@ class IcpParams(C.Structure):
 class CpdParams(C.Structure):
     _fields_ = [("eps", C.c_float), ("weight", C.c_float), ("const_scale", C.c_int), ("max_iterations", C.c_int),
                 ("tolerance", C.c_float), ("sigma2_init", C.c_float), ("sync_every", C.c_int), ("verbose", C.c_int),
-                ("reserved", C.c_int * 8)]
+                ("approximation", C.c_int), ("fgt_ratio_of_far_field", C.c_float), ("fgt_order_of_truncation", C.c_int),
+                ("reserved", C.c_int * 5)]
 
 
 class MiSlamError(RuntimeError):
@@ -117,6 +120,18 @@ def cpd_params(**kw):
             raise AttributeError(k)
         setattr(p, k, v)
     return p
+
+
+def fgt_tables(order):
+    """Host-only: exponents (a, b, c) per monomial in the reference's graded order, C_k and the Horner slot (mi_fgt_tables)."""
+    pd = C.c_int(0)
+    _check(lib().mi_fgt_tables(int(order), None, None, None, C.byref(pd)))
+    mono = np.empty(pd.value, np.uint32)
+    ck = np.empty(pd.value, np.float32)
+    slot = np.empty(pd.value, np.int32)
+    _check(lib().mi_fgt_tables(int(order), mono.ctypes.data_as(C.POINTER(C.c_uint)), _fp(ck), slot.ctypes.data_as(_i), C.byref(pd)))
+    exps = np.stack([mono & 0xff, (mono >> 8) & 0xff, (mono >> 16) & 0xff], axis=1).astype(np.int32)
+    return exps, ck, slot
 
 
 def shard_range(m_total, rank, world):
@@ -280,6 +295,30 @@ class Context:
         _check(lib().mi_cpd_estep(self._h, _fp(y), m, _fp(x), n, C.c_float(constant), C.c_float(sigma2), _fp(p1), _fp(pt1),
                                   _fp(px), C.byref(L)))
         return p1, pt1, px, L.value
+
+    def cpd_estep_truncated(self, y, x, constant, sigma2, truncate=1e-3):
+        y, x = _cloud(y), _cloud(x)
+        m, n = y.shape[0], x.shape[0]
+        p1, pt1, px, L = np.empty(m, np.float32), np.empty(n, np.float32), np.empty((m, 3), np.float32), C.c_float(0)
+        _check(lib().mi_cpd_estep_truncated(self._h, _fp(y), m, _fp(x), n, C.c_float(constant), C.c_float(sigma2),
+                                            C.c_float(truncate), _fp(p1), _fp(pt1), _fp(px), C.byref(L)))
+        return p1, pt1, px, L.value
+
+    def cpd_estep_fgt(self, y, x, weight, sigma2, sigma2_init, ratio_of_far_field=10.0, order_of_truncation=8):
+        y, x = _cloud(y), _cloud(x)
+        m, n = y.shape[0], x.shape[0]
+        p1, pt1, px, L = np.empty(m, np.float32), np.empty(n, np.float32), np.empty((m, 3), np.float32), C.c_float(0)
+        _check(lib().mi_cpd_estep_fgt(self._h, _fp(y), m, _fp(x), n, C.c_float(weight), C.c_float(sigma2), C.c_float(sigma2_init),
+                                      C.c_float(ratio_of_far_field), int(order_of_truncation), _fp(p1), _fp(pt1), _fp(px),
+                                      C.byref(L)))
+        return p1, pt1, px, L.value
+
+    def fgt_kcenter(self, cloud, K):
+        cloud = _cloud(cloud)
+        centers = np.empty((K, 3), np.float32)
+        cluster = np.empty(cloud.shape[0], np.int32)
+        _check(lib().mi_fgt_kcenter(self._h, _fp(cloud), cloud.shape[0], int(K), _fp(centers), cluster.ctypes.data_as(_i)))
+        return centers, cluster
 
     def cpd_mstep(self, before, after, p1, pt1, px, const_scale, scale=1.0, sigma2=0.0):
         before, after = _cloud(before), _cloud(after)

@@ -4,17 +4,47 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "context.h"
+#include "cpd_fgt.h"
 #include "cpd_kernels.h"
 
 using namespace mislam;
 
 namespace mislam {
 
+// Buffers of one clustered cloud (FgtClusters, cpd_fgt.h)
+struct FgtSide {
+    DevBuf<float> dist, xc;
+    DevBuf<int> indx, iota, memb, off;
+    DevBuf<unsigned int> keys;
+    int iota_n = 0;
+    void release() { dist.release(); xc.release(); indx.release(); iota.release(); memb.release(); off.release(); keys.release(); iota_n = 0; }
+};
+
+// Fast-Gauss-Transform E-step workspace ("approximation-type" full / hybrid)
+struct FgtWork {
+    FgtSide y, a;
+    DevBuf<float> By, Ba;                // coefficients: [1][K][pd] (moving cloud as sources), [4][K][pd] (fixed cloud as sources)
+    DevBuf<float> kt1, v4;               // transform outputs: [n], [4][m]
+    DevBuf<unsigned char> sort_temp;
+    DevBuf<unsigned int> mono;
+    DevBuf<float> ck;
+    DevBuf<int> hpos;
+    int p = 0, pd = 0;
+    void release()
+    {
+        y.release(); a.release(); By.release(); Ba.release(); kt1.release(); v4.release(); sort_temp.release();
+        mono.release(); ck.release(); hpos.release(); p = pd = 0;
+    }
+};
+
 struct CpdWorkspace {
+    FgtWork fgt;
     DevBuf<float> ax, ay, az;            // fixed cloud, SoA
     DevBuf<float> den_part, pt1, p1_part, px_part, p1, px;
     DevBuf<float4> xw4;
@@ -33,6 +63,7 @@ void cpd_workspace_destroy(mi_ctx* c)
     w->ax.release(); w->ay.release(); w->az.release();
     w->den_part.release(); w->pt1.release(); w->p1_part.release(); w->px_part.release(); w->p1.release(); w->px.release();
     w->xw4.release(); w->part_x.release(); w->part_k.release(); w->part_init.release();
+    w->fgt.release();
     if (w->d_state) (void)hipFree(w->d_state);
     if (w->h_state) (void)hipHostFree(w->h_state);
     delete w;
@@ -167,6 +198,109 @@ static int cpd_init(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const CpdRules
     return MI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fast Gauss Transform E-step (ComputePMatrixWithFGT, common/cpdutils.cpp:19-77)
+// ---------------------------------------------------------------------------------------------------------------
+void fgt_build_tables(int p, std::vector<unsigned int>& mono, std::vector<float>& ck, std::vector<int>& hpos)
+{
+    const int pd = p * (p + 1) * (p + 2) / 6;                      // nchoosek(p + 2, 3), fgt.cpp:69
+    mono.assign(pd, 0u); ck.assign(pd, 0.f); hpos.assign(pd, 0);
+    // slot of exponents (a, b, c) in the reference's graded order: all of degree d-1 first, then x-power descending, then y-power
+    auto slot = [](int a, int b, int c) { const int d = a + b + c, r = d - a; return d * (d + 1) * (d + 2) / 6 + r * (r + 1) / 2 + (r - b); };
+    for (int d = 0; d < p; d++)
+        for (int a = d; a >= 0; a--)
+            for (int b = d - a; b >= 0; b--) {
+                const int c = d - a - b, t = slot(a, b, c);
+                mono[t] = (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16);
+                // 2^|alpha| / alpha!, rounded the way ComputeC_k walks the recursion: z steps, then y steps, then x steps, each step
+                // C = float(2.0 * C) followed by C = float(C / (double)q), q = the running exponent (fgt.cpp:236-238)
+                float C = 1.0f;
+                const int steps[3] = {c, b, a};
+                for (int axis = 0; axis < 3; axis++)
+                    for (int q = 1; q <= steps[axis]; q++) { C = (float)(2.0 * C); C = (float)(C / (double)q); }
+                ck[t] = C;
+            }
+    int h = 0;                                                     // Horner traversal of fgt_predict_kernel
+    for (int a = p - 1; a >= 0; a--)
+        for (int b = p - 1 - a; b >= 0; b--)
+            for (int c = p - 1 - a - b; c >= 0; c--) hpos[slot(a, b, c)] = h++;
+}
+
+static int fgt_tables(mi_ctx* c, FgtWork* f, int p, FgtTables* out)
+{
+    if (p < 1 || p > FGT_MAX_ORDER) { set_error("FGT: order of truncation %d outside [1, %d]", p, FGT_MAX_ORDER); return MI_ERR_INVALID_ARG; }
+    if (f->p != p) {
+        std::vector<unsigned int> mono; std::vector<float> ck; std::vector<int> hpos;
+        fgt_build_tables(p, mono, ck, hpos);
+        const size_t pd = mono.size();
+        MI_TRY(f->mono.reserve(pd)); MI_TRY(f->ck.reserve(pd)); MI_TRY(f->hpos.reserve(pd));
+        MI_HIP(hipMemcpyAsync(f->mono.p, mono.data(), pd * sizeof(unsigned int), hipMemcpyHostToDevice, c->stream));
+        MI_HIP(hipMemcpyAsync(f->ck.p, ck.data(), pd * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        MI_HIP(hipMemcpyAsync(f->hpos.p, hpos.data(), pd * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        MI_HIP(hipStreamSynchronize(c->stream));                   // the staging vectors die here
+        f->p = p; f->pd = (int)pd;
+    }
+    out->mono = f->mono.p; out->ck = f->ck.p; out->hpos = f->hpos.p; out->p = f->p; out->pd = f->pd;
+    return MI_OK;
+}
+
+static int fgt_side(mi_ctx* c, FgtWork* f, FgtSide* sd, const float* x, const float* y, const float* z, int n, int K, FgtClusters* out)
+{
+    MI_TRY(sd->dist.reserve(n)); MI_TRY(sd->indx.reserve(n)); MI_TRY(sd->iota.reserve(n)); MI_TRY(sd->memb.reserve(n));
+    MI_TRY(sd->keys.reserve(n)); MI_TRY(sd->off.reserve((size_t)K + 1)); MI_TRY(sd->xc.reserve(3 * (size_t)K));
+    if (sd->iota_n < n) { MI_HIP(fgt_fill_iota(sd->iota.p, n, c->stream)); sd->iota_n = n; }
+    MI_TRY(f->sort_temp.reserve(std::max<size_t>(fgt_sort_temp_bytes(n), 16)));
+    out->x = x; out->y = y; out->z = z; out->n = n; out->K = K;
+    out->dist = sd->dist.p; out->indx = sd->indx.p; out->iota = sd->iota.p; out->keys_sorted = sd->keys.p;
+    out->memb = sd->memb.p; out->off = sd->off.p; out->xc = sd->xc.p;
+    return MI_OK;
+}
+
+// K of the transform: cpdutils.cpp:36
+static int fgt_cluster_count(int m, int n, float sigma2, float sigma2_init)
+{
+    return (int)std::round(std::min({(float)n, (float)m, 50.0f + sigma2_init / sigma2}));
+}
+
+// ndi: cpdutils.cpp:45 -- pow and the numerator in double, the denominator a float product, narrowed to float
+static float fgt_ndi(float sigma2, float weight, int m, int n)
+{
+    return (float)((std::pow(2 * 3.14159265358979323846 * sigma2, (double)(3.f * 0.5f)) * weight * m) / (double)((1 - weight) * n));
+}
+
+static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, float weight, float sigma2, float sigma2_init,
+                                 float ratio_of_far_field, int order)
+{
+    ProfScope ps(c, MI_KERNEL_CPD_FGT);
+    FgtWork* f = &w->fgt;
+    if (w->m < 2 || w->n < 2) { set_error("FGT E-step needs at least 2 points per cloud (m=%d, n=%d)", w->m, w->n); return MI_ERR_INVALID_ARG; }
+    if (!(sigma2 > 0.f)) { set_error("FGT E-step: sigma2 must be positive"); return MI_ERR_INVALID_ARG; }
+    FgtTables t{};
+    MI_TRY(fgt_tables(c, f, order, &t));
+    const int K = fgt_cluster_count(w->m, w->n, sigma2, sigma2_init);
+    if (K < 1 || K >= (1 << FGT_KEY_BITS)) { set_error("FGT E-step: %d cells outside [1, %d)", K, 1 << FGT_KEY_BITS); return MI_ERR_INVALID_ARG; }
+    const float hsigma = std::sqrt(2.0f * sigma2);                 // cpdutils.cpp:31
+    const float ndi = fgt_ndi(sigma2, weight, w->m, w->n);
+    FgtClusters cy{}, ca{};
+    MI_TRY(fgt_side(c, f, &f->y, v.yx, v.yy, v.yz, w->m, K, &cy));
+    MI_TRY(fgt_side(c, f, &f->a, v.ax, v.ay, v.az, w->n, K, &ca));
+    MI_TRY(f->By.reserve((size_t)K * t.pd)); MI_TRY(f->Ba.reserve(4 * (size_t)K * t.pd));
+    MI_TRY(f->kt1.reserve(w->n)); MI_TRY(f->v4.reserve(4 * (size_t)w->m));
+    const size_t temp = f->sort_temp.cap;
+    // Kt1 = K^T 1: sources = moving cloud, unit weights, queried at the fixed cloud   (cpdutils.cpp:42-43)
+    MI_HIP(fgt_cluster(cy, f->sort_temp.p, temp, c->stream));
+    MI_HIP(fgt_model(cy, nullptr, hsigma, t, f->By.p, c->stream));
+    MI_HIP(fgt_predict(v.ax, v.ay, v.az, w->n, cy.xc, f->By.p, K, 1, hsigma, ratio_of_far_field, t, f->kt1.p, c->stream));
+    MI_HIP(fgt_post_kt1(f->kt1.p, v.ax, v.ay, v.az, w->n, ndi, v.pt1, v.xw4, c->stream));
+    // P1 and PX: sources = fixed cloud weighted by 1/den and x/den, queried at the moving cloud   (:54-66; the reference
+    // clusters the fixed cloud four times with the same result -- once is enough)
+    MI_HIP(fgt_cluster(ca, f->sort_temp.p, temp, c->stream));
+    MI_HIP(fgt_model(ca, v.xw4, hsigma, t, f->Ba.p, c->stream));
+    MI_HIP(fgt_predict(v.yx, v.yy, v.yz, w->m, ca.xc, f->Ba.p, K, 4, hsigma, ratio_of_far_field, t, f->v4.p, c->stream));
+    MI_HIP(fgt_post_px(f->v4.p, w->m, v.p1, v.px, c->stream));
+    return MI_OK;
+}
+
 }  // namespace mislam
 
 extern "C" void mi_cpd_params_default(mi_cpd_params* p)
@@ -181,6 +315,9 @@ extern "C" void mi_cpd_params_default(mi_cpd_params* p)
     p->sigma2_init = 0.f;
     p->sync_every = 0;
     p->verbose = 0;
+    p->approximation = MI_CPD_APPROX_NONE;   // the exact P; the reference's parser default is hybrid (configparser.cpp:221-230)
+    p->fgt_ratio_of_far_field = 10.0f;       // "fgt-ratio-of-far-field"   configparser.cpp:263
+    p->fgt_order_of_truncation = 8;          // "fgt-order-of-truncation"  configparser.cpp:264
 }
 
 static int cpd_check(mi_ctx* c, const float* b, int m, const float* a, int n)
@@ -196,6 +333,15 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
 {
     MI_TRY(cpd_check(c, before_xyz, m_before, after_xyz, n_after));
     if (!params || !out_sR_t || !iterations || !error) { set_error("mi_cpd_register: null argument"); return MI_ERR_INVALID_ARG; }
+    if (params->approximation < MI_CPD_APPROX_NONE || params->approximation > MI_CPD_APPROX_HYBRID) {
+        set_error("mi_cpd_register: unknown approximation %d", params->approximation);
+        return MI_ERR_INVALID_ARG;
+    }
+    if (params->approximation != MI_CPD_APPROX_NONE &&
+        (params->fgt_order_of_truncation < 1 || params->fgt_order_of_truncation > FGT_MAX_ORDER || m_before < 2 || n_after < 2)) {
+        set_error("mi_cpd_register: the FGT modes need 1 <= order of truncation <= %d and >= 2 points per cloud", FGT_MAX_ORDER);
+        return MI_ERR_INVALID_ARG;
+    }
     MI_HIP(hipSetDevice(c->device));
     CpdWorkspace* w = nullptr;
     MI_TRY(cpd_workspace(c, &w));
@@ -210,9 +356,34 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
         const double pairs = (double)m_before * (double)n_after;
         batch = pairs >= 2e9 ? 1 : (pairs >= 2e8 ? 2 : 8);
     }
+    if (params->approximation != MI_CPD_APPROX_NONE) batch = 1;   // the E-step's shape depends on sigma^2: host-stepped
     while (!w->h_state->done) {
         for (int b = 0; b < batch; b++) {
-            MI_TRY(cpd_estep_enqueue(c, w, v));
+            if (params->approximation == MI_CPD_APPROX_NONE) {
+                MI_TRY(cpd_estep_enqueue(c, w, v));
+            } else {
+                // ComputePMatrixFast, coherentpointdrift.cpp:141-167 (the comparisons are double there: 0.05 and 0.015 are doubles)
+                float sigma2 = w->h_state->sigma2;
+                const float sigma2_init = w->h_state->sigma2_init;
+                bool fgt = true;
+                if (params->approximation == MI_CPD_APPROX_FULL) {
+                    if ((double)sigma2 < 0.05) {
+                        sigma2 = (float)0.05;
+                        MI_HIP(cpd_set_sigma2(w->d_state, sigma2, c->stream));
+                    }
+                } else {
+                    fgt = (double)sigma2 > 0.015 * (double)sigma2_init;
+                }
+                if (fgt) {
+                    MI_TRY(cpd_estep_fgt_enqueue(c, w, v, rules.weight, sigma2, sigma2_init, params->fgt_ratio_of_far_field,
+                                                 params->fgt_order_of_truncation));
+                } else {
+                    CpdView vt = v;
+                    vt.truncate = 1;
+                    vt.trunc_log = std::log(1e-3f);                // ComputePMatrix(..., true, 1e-3f), :166 / :182-183
+                    MI_TRY(cpd_estep_enqueue(c, w, vt));
+                }
+            }
             MI_TRY(cpd_mstep_enqueue(c, w, v, rules, 1));
             MI_HIP(cpd_transform(v, w->m_pad, c->stream));
         }
@@ -250,26 +421,36 @@ extern "C" int mi_cpd_sigma_squared(mi_ctx* c, const float* before_xyz, int m, c
     return MI_OK;
 }
 
-extern "C" int mi_cpd_estep(mi_ctx* c, const float* y_xyz, int m, const float* x_xyz, int n, float constant, float sigma2,
-                            float* p1, float* pt1, float* px, float* L)
+// The three E-step flavours behind one primitive: mode 0 exact, 1 truncated exact, 2 Fast Gauss Transform.
+static int estep_primitive(mi_ctx* c, const float* y_xyz, int m, const float* x_xyz, int n, int mode, float constant, float sigma2,
+                           float truncate, float weight, float sigma2_init, float ratio_of_far_field, int order,
+                           float* p1, float* pt1, float* px, float* L)
 {
     MI_TRY(cpd_check(c, y_xyz, m, x_xyz, n));
-    if (!p1 || !pt1 || !px || !L) { set_error("mi_cpd_estep: null output"); return MI_ERR_INVALID_ARG; }
-    if (!(sigma2 > 0.f)) { set_error("mi_cpd_estep: sigma2 must be positive"); return MI_ERR_INVALID_ARG; }
+    if (!p1 || !pt1 || !px || !L) { set_error("CPD E-step: null output"); return MI_ERR_INVALID_ARG; }
+    if (!(sigma2 > 0.f)) { set_error("CPD E-step: sigma2 must be positive"); return MI_ERR_INVALID_ARG; }
     MI_HIP(hipSetDevice(c->device));
     CpdWorkspace* w = nullptr;
     MI_TRY(cpd_workspace(c, &w));
     MI_TRY(cpd_load(c, w, y_xyz, m, x_xyz, n));
-    const CpdView v = cpd_view(c, w);
+    CpdView v = cpd_view(c, w);
     memset(w->h_state, 0, sizeof(CpdState));
     w->h_state->sigma2 = sigma2;
     w->h_state->constant = constant;
     w->h_state->scale = 1.f;
     MI_HIP(hipMemcpyAsync(w->d_state, w->h_state, sizeof(CpdState), hipMemcpyHostToDevice, c->stream));
-    MI_TRY(cpd_estep_enqueue(c, w, v));
+    if (mode == 2) {
+        MI_TRY(cpd_estep_fgt_enqueue(c, w, v, weight, sigma2, sigma2_init, ratio_of_far_field, order));
+    } else {
+        if (mode == 1) {
+            if (!(truncate > 0.f)) { set_error("mi_cpd_estep_truncated: truncate must be positive"); return MI_ERR_INVALID_ARG; }
+            v.truncate = 1;
+            v.trunc_log = std::log(truncate);
+        }
+        MI_TRY(cpd_estep_enqueue(c, w, v));
+    }
     const int nxb = icp_reduce_blocks(n);
     MI_HIP(cpd_xsums(v, w->part_x.p, nxb, c->stream));
-    MI_TRY(c->part_mom.reserve((size_t)ICP_MAX_PARTIAL_BLOCKS * ICP_MOMENTS));
     MI_HIP(hipMemcpyAsync(p1, w->p1.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
     MI_HIP(hipMemcpyAsync(pt1, w->pt1.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     MI_HIP(hipMemcpyAsync(px, w->px.p, sizeof(float) * 3 * (size_t)m, hipMemcpyDeviceToHost, c->stream));
@@ -278,7 +459,63 @@ extern "C" int mi_cpd_estep(mi_ctx* c, const float* y_xyz, int m, const float* x
     MI_HIP(hipStreamSynchronize(c->stream));
     double logsum = 0.0;
     for (int b = 0; b < nxb; b++) logsum += part[(size_t)b * CPD_XSUMS];
-    *L = (float)(-logsum) + (float)(3 * n) * logf(sigma2) / 2.0f;     // coherentpointdrift.cpp:215-217
+    *L = (float)(-logsum) + (float)(3 * n) * logf(sigma2) / 2.0f;     // coherentpointdrift.cpp:215-217 / cpdutils.cpp:69-72
+    return MI_OK;
+}
+
+extern "C" int mi_cpd_estep(mi_ctx* c, const float* y_xyz, int m, const float* x_xyz, int n, float constant, float sigma2,
+                            float* p1, float* pt1, float* px, float* L)
+{
+    return estep_primitive(c, y_xyz, m, x_xyz, n, 0, constant, sigma2, 0.f, 0.f, 0.f, 0.f, 0, p1, pt1, px, L);
+}
+
+extern "C" int mi_cpd_estep_truncated(mi_ctx* c, const float* y_xyz, int m, const float* x_xyz, int n, float constant, float sigma2,
+                                      float truncate, float* p1, float* pt1, float* px, float* L)
+{
+    return estep_primitive(c, y_xyz, m, x_xyz, n, 1, constant, sigma2, truncate, 0.f, 0.f, 0.f, 0, p1, pt1, px, L);
+}
+
+extern "C" int mi_cpd_estep_fgt(mi_ctx* c, const float* y_xyz, int m, const float* x_xyz, int n, float weight, float sigma2,
+                                float sigma2_init, float ratio_of_far_field, int order_of_truncation,
+                                float* p1, float* pt1, float* px, float* L)
+{
+    if (!(sigma2_init > 0.f)) { set_error("mi_cpd_estep_fgt: sigma2_init must be positive"); return MI_ERR_INVALID_ARG; }
+    if (!(weight > 0.f && weight < 1.f)) { set_error("mi_cpd_estep_fgt: weight must lie in (0, 1)"); return MI_ERR_INVALID_ARG; }
+    return estep_primitive(c, y_xyz, m, x_xyz, n, 2, 0.f, sigma2, 0.f, weight, sigma2_init, ratio_of_far_field, order_of_truncation,
+                           p1, pt1, px, L);
+}
+
+extern "C" int mi_fgt_kcenter(mi_ctx* c, const float* cloud_xyz, int n, int K, float* centers_xyz, int* cluster)
+{
+    if (!c) { set_error("mi_fgt_kcenter: null context"); return MI_ERR_INVALID_ARG; }
+    if (!cloud_xyz || !centers_xyz || !cluster) { set_error("mi_fgt_kcenter: null argument"); return MI_ERR_INVALID_ARG; }
+    if (n < 2 || K < 1 || K >= (1 << FGT_KEY_BITS)) { set_error("mi_fgt_kcenter: need n >= 2 and 1 <= K < %d (n=%d, K=%d)", 1 << FGT_KEY_BITS, n, K); return MI_ERR_INVALID_ARG; }
+    MI_HIP(hipSetDevice(c->device));
+    CpdWorkspace* w = nullptr;
+    MI_TRY(cpd_workspace(c, &w));
+    c->icp_loaded = false;
+    const int n_pad = round_up_i(n, NN_SRC_PAD);
+    MI_TRY(c->bx.reserve(n_pad)); MI_TRY(c->by.reserve(n_pad)); MI_TRY(c->bz.reserve(n_pad));
+    MI_TRY(upload_soa(c, cloud_xyz, n, n_pad, c->bx.p, c->by.p, c->bz.p, nullptr));
+    FgtClusters cl{};
+    MI_TRY(fgt_side(c, &w->fgt, &w->fgt.y, c->bx.p, c->by.p, c->bz.p, n, K, &cl));
+    MI_HIP(fgt_cluster(cl, w->fgt.sort_temp.p, w->fgt.sort_temp.cap, c->stream));
+    MI_HIP(hipMemcpyAsync(cluster, cl.indx, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP(hipMemcpyAsync(centers_xyz, cl.xc, sizeof(float) * 3 * (size_t)K, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+// Host-only: the monomial tables the FGT kernels use (exponents a | b<<8 | c<<16, C_k, Horner slot), for the CPU-side tests.
+extern "C" int mi_fgt_tables(int order_of_truncation, unsigned int* mono, float* ck, int* horner_slot, int* pd_out)
+{
+    if (order_of_truncation < 1 || order_of_truncation > FGT_MAX_ORDER) { set_error("mi_fgt_tables: order outside [1, %d]", FGT_MAX_ORDER); return MI_ERR_INVALID_ARG; }
+    std::vector<unsigned int> m; std::vector<float> k; std::vector<int> h;
+    fgt_build_tables(order_of_truncation, m, k, h);
+    if (pd_out) *pd_out = (int)m.size();
+    if (mono) memcpy(mono, m.data(), m.size() * sizeof(unsigned int));
+    if (ck) memcpy(ck, k.data(), k.size() * sizeof(float));
+    if (horner_slot) memcpy(horner_slot, h.data(), h.size() * sizeof(int));
     return MI_OK;
 }
 

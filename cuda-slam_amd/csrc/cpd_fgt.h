@@ -1,0 +1,50 @@
+// Internal launch interfaces of the Fast-Gauss-Transform E-step (cpd_fgt.hip): the reference's approximation-type
+// "full" / "hybrid" (source/common/fgt.cpp, source/common/cpdutils.cpp:19-77), restated for the GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace mislam {
+
+constexpr int FGT_MAX_ORDER = 16;          // p: monomials of total degree < p; exponents are packed in 8 bits each
+constexpr int FGT_KEY_BITS = 16;           // cluster ids are sorted on this many bits: K <= 65535
+
+// Monomial tables of one truncation order p, device resident (built on the host, cpd_api.hip).  Index t is the reference's
+// graded order (fgt.cpp:124-137): degree by degree, x-power descending, then y-power descending.
+struct FgtTables {
+    const unsigned int* mono;   // [pd]  a | b << 8 | c << 16
+    const float* ck;            // [pd]  2^|alpha| / alpha!, rounded step by step as ComputeC_k does (fgt.cpp:214-244)
+    const int* hpos;            // [pd]  position of monomial t in the Horner traversal the predict kernel reads
+    int p, pd;
+};
+
+// One cloud clustered into K cells (KCenter, fgt.cpp:152-212)
+struct FgtClusters {
+    const float *x, *y, *z;     // the cloud, SoA
+    int n, K;
+    float* dist;                // [n]   scratch: squared distance to the nearest centre so far
+    int* indx;                  // [n]   cluster of each point
+    int* iota;                  // [n]   0..n-1 (sort values in)
+    unsigned int* keys_sorted;  // [n]
+    int* memb;                  // [n]   point ids grouped by cluster, ascending inside a cluster
+    int* off;                   // [K+1] cluster k owns memb[off[k] .. off[k+1])
+    float* xc;                  // [K][3] cluster means
+};
+
+size_t fgt_sort_temp_bytes(int n);
+hipError_t fgt_fill_iota(int* iota, int n, hipStream_t s);
+// K-centre clustering + member lists + cluster means; everything a model build needs
+hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
+// coefficients B[w][k][hpos] = C_k * sum_{i in cluster k} weight_w(i) exp(-|dx|^2) dx^alpha, dx = (pt - xc_k) / sigma.
+// w4 == nullptr: one weight set of ones (W = 1); else four: (w4.x, w4.y, w4.z, w4.w) (W = 4).
+hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const FgtTables& t, float* B, hipStream_t s);
+// v[w][i] = sum_k [ |dy|^2 <= e ] exp(-|dy|^2) sum_alpha B[w][k][alpha] dy^alpha, dy = (q_i - xc_k) / sigma   (fgt.cpp:88-150)
+hipError_t fgt_predict(const float* qx, const float* qy, const float* qz, int nq, const float* xc, const float* B, int K, int W,
+                       float sigma, float e_param, const FgtTables& t, float* v, hipStream_t s);
+// Kt1 -> 1/denominator, Pt1 and the four weight sets of the second transform (cpdutils.cpp:45-52, :79-99)
+hipError_t fgt_post_kt1(const float* kt1, const float* ax, const float* ay, const float* az, int n, float ndi, float* pt1,
+                        float4* xw4, hipStream_t s);
+// v[4][m] -> P1[m], PX[m][3]
+hipError_t fgt_post_px(const float* v, int m, float* p1, float* px, hipStream_t s);
+
+}  // namespace mislam

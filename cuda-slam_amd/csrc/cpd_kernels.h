@@ -58,6 +58,9 @@ struct CpdView {
     float* px;             // [m][3] row-major, the reference's px.row(k)
     int k_chunks, k_chunk_len;   // K7a: chunks over k
     int x_chunks, x_chunk_len;   // K7b: chunks over x
+    // hybrid mode's truncated kernel (coherentpointdrift.cpp:182-196): affinities whose exponent is < trunc_log count as 0
+    int truncate;
+    float trunc_log;
 };
 
 hipError_t cpd_init_sums(const CpdView& v, double* partials, int nblocks, hipStream_t s);
@@ -72,5 +75,6 @@ hipError_t cpd_reduce_sums(CpdState* state, const double* xpart, int nxb, const 
 hipError_t cpd_solve(CpdState* state, const double* xpart, int nxb, const double* kpart, int nkb, const CpdRules& rules,
                      int update_loop_state, hipStream_t s);                                    // K8 solve (+ EM bookkeeping)
 hipError_t cpd_transform(const CpdView& v, int m_pad, hipStream_t s);                          // y = s*R*b + t
+hipError_t cpd_set_sigma2(CpdState* state, float sigma2, hipStream_t s);
 
 }  // namespace mislam

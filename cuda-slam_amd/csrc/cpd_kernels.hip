@@ -50,6 +50,15 @@ __device__ __forceinline__ float exp_neg(float x)
     return __builtin_fmaf(e * r, 0.693147182464599609375f, e);
 }
 
+// One Gaussian affinity from its exponent.  TRUNC: the hybrid mode's truncated kernel (coherentpointdrift.cpp:193-196) --
+// an exponent below log(truncate) contributes exactly 0 to the denominator and to P1/PX.
+template <bool TRUNC>
+__device__ __forceinline__ float affinity(float index, float trunc_log)
+{
+    if (TRUNC) return index < trunc_log ? 0.f : exp_neg(index);
+    return exp_neg(index);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // sigma^2 initialisation: sum_ij |b_i - a_j|^2 = N sum|b|^2 + M sum|a|^2 - 2 (sum a).(sum b), O(M+N) in fp64
 // (CalculateSigmaSquared, cpdcuda.cu:65-78, is O(M*N); see mi_slam.h on why the closed form is used)
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(256) void cpd_init_state_kernel(CpdState* __restric
 // ---------------------------------------------------------------------------------------------------------------
 // K7a: partial denominators.  grid = x_blocks * k_chunks, lane owns R fixed points, y_k broadcast from SGPRs.
 // ---------------------------------------------------------------------------------------------------------------
-template <int R>
+template <int R, bool TRUNC>
 __global__ __launch_bounds__(256) void cpd_denominator_kernel(CpdView v)
 {
     if (v.state->done != 0) return;
@@ -129,13 +138,13 @@ __global__ __launch_bounds__(256) void cpd_denominator_kernel(CpdView v)
         for (int u = 0; u < CPD_T; u++) {
             const float yx = v.yx[k + u], yy = v.yy[k + u], yz = v.yz[k + u];   // wave-uniform -> scalar loads
 #pragma unroll
-            for (int r = 0; r < R; r++) sum[r] += exp_neg(mult * sq_dist(ax[r], ay[r], az[r], yx, yy, yz));
+            for (int r = 0; r < R; r++) sum[r] += affinity<TRUNC>(mult * sq_dist(ax[r], ay[r], az[r], yx, yy, yz), v.trunc_log);
         }
     }
     for (; k < k_end; k++) {
         const float yx = v.yx[k], yy = v.yy[k], yz = v.yz[k];
 #pragma unroll
-        for (int r = 0; r < R; r++) sum[r] += exp_neg(mult * sq_dist(ax[r], ay[r], az[r], yx, yy, yz));
+        for (int r = 0; r < R; r++) sum[r] += affinity<TRUNC>(mult * sq_dist(ax[r], ay[r], az[r], yx, yy, yz), v.trunc_log);
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256) void cpd_post_den_kernel(CpdView v)
 // K7b: contraction.  grid = k_blocks * x_chunks, lane owns R moving points, x (and its weights) broadcast from SGPRs.
 // VALU form: 4 fused-free multiply-adds per pair on the vector pipe.
 // ---------------------------------------------------------------------------------------------------------------
-template <int R>
+template <int R, bool TRUNC>
 __global__ __launch_bounds__(256) void cpd_contract_kernel(CpdView v)
 {
     if (v.state->done != 0) return;
@@ -185,7 +194,7 @@ __global__ __launch_bounds__(256) void cpd_contract_kernel(CpdView v)
         const float4 w = v.xw4[x];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const float p = exp_neg(mult * sq_dist(ax, ay, az, yx[r], yy[r], yz[r]));
+            const float p = affinity<TRUNC>(mult * sq_dist(ax, ay, az, yx[r], yy[r], yz[r]), v.trunc_log);
             p1[r] += p * w.w;            // p1(k) += p/den          coherentpointdrift.cpp:210-211
             pxx[r] += p * w.x;           // px.row(k) += x * p/den  :212
             pxy[r] += p * w.y;
@@ -210,6 +219,7 @@ __global__ __launch_bounds__(256) void cpd_contract_kernel(CpdView v)
 // The B operand comes from a per-x 16-byte record expanded over lanes by a lane-indexed load (lane l reads word l&3).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+template <bool TRUNC>
 __global__ __launch_bounds__(256) void cpd_contract_mfma_kernel(CpdView v)
 {
     if (v.state->done != 0) return;
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(256) void cpd_contract_mfma_kernel(CpdView v)
     const float* __restrict__ wrec = reinterpret_cast<const float*>(v.xw4);
     for (int x = x_begin; x < x_end; x++) {
         const float ax = v.ax[x], ay = v.ay[x], az = v.az[x];
-        const float p = exp_neg(mult * sq_dist(ax, ay, az, yx, yy, yz));
+        const float p = affinity<TRUNC>(mult * sq_dist(ax, ay, az, yx, yy, yz), v.trunc_log);
         const float b = wrec[4 * (size_t)x + (lane & 3)];
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(p, b, acc, 0, 0, 0);
     }
@@ -391,7 +401,8 @@ hipError_t cpd_init_state(CpdState* state, const double* partials, int nblocks, 
 hipError_t cpd_denominators(const CpdView& v, hipStream_t s)
 {
     const int xblocks = (v.n + 256 * CPD_R - 1) / (256 * CPD_R);
-    hipLaunchKernelGGL(cpd_denominator_kernel<CPD_R>, dim3(xblocks * v.k_chunks), dim3(256), 0, s, v);
+    if (v.truncate) hipLaunchKernelGGL((cpd_denominator_kernel<CPD_R, true>), dim3(xblocks * v.k_chunks), dim3(256), 0, s, v);
+    else hipLaunchKernelGGL((cpd_denominator_kernel<CPD_R, false>), dim3(xblocks * v.k_chunks), dim3(256), 0, s, v);
     return hipGetLastError();
 }
 
@@ -405,10 +416,12 @@ hipError_t cpd_contract(const CpdView& v, int use_mfma, hipStream_t s)
 {
     if (use_mfma) {
         const int kblocks = (v.m + 255) / 256;
-        hipLaunchKernelGGL(cpd_contract_mfma_kernel, dim3(kblocks * v.x_chunks), dim3(256), 0, s, v);
+        if (v.truncate) hipLaunchKernelGGL(cpd_contract_mfma_kernel<true>, dim3(kblocks * v.x_chunks), dim3(256), 0, s, v);
+        else hipLaunchKernelGGL(cpd_contract_mfma_kernel<false>, dim3(kblocks * v.x_chunks), dim3(256), 0, s, v);
     } else {
         const int kblocks = (v.m + 256 * CPD_R - 1) / (256 * CPD_R);
-        hipLaunchKernelGGL(cpd_contract_kernel<CPD_R>, dim3(kblocks * v.x_chunks), dim3(256), 0, s, v);
+        if (v.truncate) hipLaunchKernelGGL((cpd_contract_kernel<CPD_R, true>), dim3(kblocks * v.x_chunks), dim3(256), 0, s, v);
+        else hipLaunchKernelGGL((cpd_contract_kernel<CPD_R, false>), dim3(kblocks * v.x_chunks), dim3(256), 0, s, v);
     }
     return hipGetLastError();
 }
@@ -441,6 +454,15 @@ hipError_t cpd_solve(CpdState* state, const double* xpart, int nxb, const double
 hipError_t cpd_transform(const CpdView& v, int m_pad, hipStream_t s)
 {
     hipLaunchKernelGGL(cpd_transform_kernel, dim3((m_pad + 255) / 256), dim3(256), 0, s, v, m_pad);
+    return hipGetLastError();
+}
+
+// approximation-type "full": if (sigma2 < 0.05) sigma2 = 0.05 before the E-step, and it stays so (coherentpointdrift.cpp:154-155)
+__global__ void cpd_set_sigma2_kernel(CpdState* st, float sigma2) { st->sigma2 = sigma2; }
+
+hipError_t cpd_set_sigma2(CpdState* state, float sigma2, hipStream_t s)
+{
+    hipLaunchKernelGGL(cpd_set_sigma2_kernel, dim3(1), dim3(1), 0, s, state, sigma2);
     return hipGetLastError();
 }
 

@@ -60,13 +60,18 @@ static int ctx_create_common(int device, mi_ctx** out)
     MI_HIP(hipSetDevice(device));
     mi_ctx* c = new mi_ctx();
     c->device = device;
-    hipDeviceProp_t prop;
-    MI_HIP(hipGetDeviceProperties(&prop, device));
-    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    MI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    MI_HIP(hipMalloc((void**)&c->d_state, sizeof(IcpState)));
-    MI_HIP(hipHostMalloc((void**)&c->h_state, sizeof(IcpState), hipHostMallocDefault));
-    memset(c->h_state, 0, sizeof(IcpState));
+    // a failure half way releases what was created so far (mi_ctx_destroy copes with null members)
+    const int rc = [&]() -> int {
+        hipDeviceProp_t prop;
+        MI_HIP(hipGetDeviceProperties(&prop, device));
+        c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        MI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        MI_HIP(hipMalloc((void**)&c->d_state, sizeof(IcpState)));
+        MI_HIP(hipHostMalloc((void**)&c->h_state, sizeof(IcpState), hipHostMallocDefault));
+        memset(c->h_state, 0, sizeof(IcpState));
+        return MI_OK;
+    }();
+    if (rc != MI_OK) { mi_ctx_destroy(c); return rc; }
     *out = c;
     return MI_OK;
 }

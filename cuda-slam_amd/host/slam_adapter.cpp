@@ -74,12 +74,12 @@ std::pair<Mat3, Vec3> GetCudaCpdTransformationMatrix(const std::vector<Point_f>&
                                                     ApproximationType fgt, int* iterations, float* error, const float& ratioOfFarField,
                                                     const float& orderOfTruncation)
 {
-    (void)ratioOfFarField;
-    (void)orderOfTruncation;
-    if (fgt != ApproximationType::None)
-        printf("approximation-type full/hybrid (Fast Gauss Transform) is not part of the accelerated path: using the exact Gaussian P\n");
     mi_cpd_params p;
     mi_cpd_params_default(&p);
+    // enumerators.h:18-23 and MI_CPD_APPROX_* share the numbering (none, full, hybrid)
+    p.approximation = fgt == ApproximationType::Full ? MI_CPD_APPROX_FULL : fgt == ApproximationType::Hybrid ? MI_CPD_APPROX_HYBRID : MI_CPD_APPROX_NONE;
+    p.fgt_ratio_of_far_field = ratioOfFarField;
+    p.fgt_order_of_truncation = (int)orderOfTruncation;      // cpdutils.cpp:37 narrows the float the same way
     p.eps = eps;
     p.weight = weight;
     p.const_scale = const_scale ? 1 : 0;

@@ -221,8 +221,18 @@ typedef struct {
                               (3.604 instead of 12.943 on the bunny clouds); pass that number here to retrace cpu-slam. */
     int   sync_every;      /* as in mi_icp_params */
     int   verbose;
-    int   reserved[8];
+    int   approximation;   /* MI_CPD_APPROX_*: "approximation-type" (configparser.cpp:221-230).  0 = the exact Gaussian P. */
+    float fgt_ratio_of_far_field;    /* "fgt-ratio-of-far-field" e (default 10): cells farther than sqrt(e)*sigma are skipped */
+    int   fgt_order_of_truncation;   /* "fgt-order-of-truncation" p (default 8): monomials of total degree < p, 1..16 */
+    int   reserved[5];
 } mi_cpd_params;
+
+/* "approximation-type" of the reference (common/enumerators.h:18-23, coherentpointdrift.cpp:141-167):
+ *   FULL    every E-step is the Fast Gauss Transform (common/fgt.cpp) and sigma^2 is clamped to >= 0.05;
+ *   HYBRID  the FGT E-step while sigma^2 > 0.015 * sigma^2_init, then the exact P truncated below 1e-3 (the parser's default).
+ * The reference runs the FGT on the CPU in both of its builds; here it runs on the device (K9).  With either
+ * mode the loop is host-stepped (the cell count and the switch depend on sigma^2), one state read-back per iteration. */
+enum { MI_CPD_APPROX_NONE = 0, MI_CPD_APPROX_FULL = 1, MI_CPD_APPROX_HYBRID = 2 };
 
 void mi_cpd_params_default(mi_cpd_params* p);
 
@@ -238,6 +248,27 @@ int mi_cpd_sigma_squared(mi_ctx* ctx, const float* before_xyz, int m, const floa
  * PX[k] = sum_x x * p_xk/den_x (row-major M x 3); *L = -sum_x log den_x + 1.5*N*log sigma^2. */
 int mi_cpd_estep(mi_ctx* ctx, const float* y_xyz, int m, const float* x_xyz, int n, float constant, float sigma2,
                  float* p1, float* pt1, float* px, float* L);
+
+/* ComputePMatrix with doTruncate (coherentpointdrift.cpp:168-221; the hybrid mode calls it with truncate = 1e-3, :166):
+ * affinities with -|x - y_k|^2 / (2 sigma^2) < log(truncate) count as 0. */
+int mi_cpd_estep_truncated(mi_ctx* ctx, const float* y_xyz, int m, const float* x_xyz, int n, float constant, float sigma2,
+                           float truncate, float* p1, float* pt1, float* px, float* L);
+
+/* ComputePMatrixWithFGT (common/cpdutils.cpp:19-77): the same four products through three Fast Gauss Transforms with
+ * K = round(min(N, M, 50 + sigma2_init/sigma2)) cells, bandwidth sqrt(2 sigma2) and the outlier term taken at the CURRENT
+ * sigma2.  Needs m, n >= 2 (the clustering starts from point 1, fgt.cpp:162). */
+int mi_cpd_estep_fgt(mi_ctx* ctx, const float* y_xyz, int m, const float* x_xyz, int n, float weight, float sigma2,
+                     float sigma2_init, float ratio_of_far_field, int order_of_truncation,
+                     float* p1, float* pt1, float* px, float* L);
+
+/* KCenter (common/fgt.cpp:152-212): greedy farthest-point clustering from point 1; cluster[i] in [0, K), centers_xyz[K][3] the
+ * cell means.  Labels are bit-identical to the reference's (same arithmetic, same tie rules).  n >= 2, 1 <= K <= 65535. */
+int mi_fgt_kcenter(mi_ctx* ctx, const float* cloud_xyz, int n, int K, float* centers_xyz, int* cluster);
+
+/* Host-only (no device needed): the monomial tables of truncation order p the FGT kernels use, pd = C(p+2,3) entries each in
+ * the reference's graded monomial order (fgt.cpp:124-137): exponents packed a | b<<8 | c<<16, the constants 2^|alpha|/alpha!
+ * of ComputeC_k (fgt.cpp:214-244), and each monomial's slot in the Horner traversal.  Any output may be NULL. */
+int mi_fgt_tables(int order_of_truncation, unsigned int* mono, float* ck, int* horner_slot, int* pd);
 
 /* MStep (cpdcuda.cu:172-300 / coherentpointdrift.cpp:223-277).  scale, sigma2 are in/out as in the reference. */
 int mi_cpd_mstep(mi_ctx* ctx, const float* before_xyz, int m, const float* after_xyz, int n, const float* p1,
@@ -257,7 +288,8 @@ enum {
     MI_KERNEL_CPD_DENOM = 6,   /* K7a column sums (den, Pt1, L) */
     MI_KERNEL_CPD_CONTRACT = 7,/* K7b P~.[X|1] contraction (MFMA) */
     MI_KERNEL_CPD_MSTEP = 8,   /* K8 weighted moments + solve */
-    MI_KERNEL_COUNT = 9
+    MI_KERNEL_CPD_FGT = 9,     /* K9 Fast-Gauss-Transform E-step (clustering, model, predict) */
+    MI_KERNEL_COUNT = 10
 };
 int mi_profile_enable(mi_ctx* ctx, int enable);
 int mi_profile_reset(mi_ctx* ctx);

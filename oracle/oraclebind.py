@@ -190,3 +190,96 @@ def cpd(before, after, eps=1e-3, weight=0.3, const_scale=False, max_iterations=5
     if trace_cap:
         return out + (trace[:min(tl.value, trace_cap)].copy(),)
     return out
+
+
+# ---- Fast Gauss Transform E-step and the full / hybrid drivers (oracle/fgt_oracle.c) ----
+APPROX_NONE, APPROX_FULL, APPROX_HYBRID = 0, 1, 2
+
+
+def fgt_pd(p):
+    return int(lib().oracle_fgt_pd(int(p)))
+
+
+def fgt_ck(p):
+    ck = np.empty(fgt_pd(p), np.float32)
+    lib().oracle_fgt_ck(int(p), _fp(ck))
+    return ck
+
+
+def fgt_kcenter(cloud, K):
+    cloud = _cloud(cloud)
+    xc = np.empty((K, 3), np.float32)
+    indx = np.empty(cloud.shape[0], np.int32)
+    lib().oracle_fgt_kcenter(_fp(cloud), cloud.shape[0], K, _fp(xc), _ip(indx))
+    return xc, indx
+
+
+def fgt_model(cloud, weights, sigma, K, p):
+    cloud = _cloud(cloud)
+    weights = np.ascontiguousarray(weights, np.float32)
+    xc = np.empty((K, 3), np.float32)
+    ak = np.empty((K, fgt_pd(p)), np.float32)
+    lib().oracle_fgt_model(_fp(cloud), cloud.shape[0], _fp(weights), C.c_float(sigma), K, p, _fp(xc), _fp(ak))
+    return xc, ak
+
+
+def fgt_predict(cloud, xc, ak, sigma, e_param, p):
+    cloud = _cloud(cloud)
+    xc = np.ascontiguousarray(xc, np.float32)
+    ak = np.ascontiguousarray(ak, np.float32)
+    v = np.empty(cloud.shape[0], np.float32)
+    lib().oracle_fgt_predict(_fp(cloud), cloud.shape[0], _fp(xc), _fp(ak), C.c_float(sigma), C.c_float(e_param),
+                             ak.shape[0], p, _fp(v))
+    return v
+
+
+def cpd_fgt_clusters(m, n, sigma_squared, sigma_squared_init):
+    return int(lib().oracle_cpd_fgt_clusters(m, n, C.c_float(sigma_squared), C.c_float(sigma_squared_init)))
+
+
+def cpd_fgt_ndi(sigma_squared, weight, m, n):
+    lib().oracle_cpd_fgt_ndi.restype = C.c_float
+    return float(lib().oracle_cpd_fgt_ndi(C.c_float(sigma_squared), C.c_float(weight), m, n))
+
+
+def _estep_out(m, n):
+    return np.empty(m, np.float32), np.empty(n, np.float32), np.empty((m, 3), np.float32), C.c_float(0)
+
+
+def cpd_estep_fgt(transformed, after, weight, sigma_squared, sigma_squared_init, ratio_of_far_field=10.0,
+                  order_of_truncation=8.0):
+    transformed, after = _cloud(transformed), _cloud(after)
+    m, n = transformed.shape[0], after.shape[0]
+    p1, pt1, px, L = _estep_out(m, n)
+    lib().oracle_cpd_estep_fgt(_fp(transformed), m, _fp(after), n, C.c_float(weight), C.c_float(sigma_squared),
+                               C.c_float(sigma_squared_init), C.c_float(ratio_of_far_field), C.c_float(order_of_truncation),
+                               _fp(p1), _fp(pt1), _fp(px), C.byref(L))
+    return p1, pt1, px, L.value
+
+
+def cpd_estep_truncated(transformed, after, constant, sigma_squared, truncate=1e-3):
+    transformed, after = _cloud(transformed), _cloud(after)
+    m, n = transformed.shape[0], after.shape[0]
+    p1, pt1, px, L = _estep_out(m, n)
+    lib().oracle_cpd_estep_truncated(_fp(transformed), m, _fp(after), n, C.c_float(constant), C.c_float(sigma_squared),
+                                     C.c_float(truncate), _fp(p1), _fp(pt1), _fp(px), C.byref(L))
+    return p1, pt1, px, L.value
+
+
+def cpd_approx(before, after, approximation, eps=1e-3, weight=0.3, const_scale=False, max_iterations=50, tolerance=1e-3,
+               ratio_of_far_field=10.0, order_of_truncation=8.0, trace_cap=0):
+    before, after = _cloud(before), _cloud(after)
+    p = CpdParams(eps, weight, 1 if const_scale else 0, max_iterations, tolerance)
+    r = np.empty(9, np.float32)
+    t = np.empty(3, np.float32)
+    it = C.c_int(0)
+    err = C.c_float(0)
+    trace = np.zeros((max(trace_cap, 1), 17), np.float32)
+    tl = C.c_int(0)
+    lib().oracle_cpd_approx(_fp(before), before.shape[0], _fp(after), after.shape[0], C.byref(p), approximation,
+                            C.c_float(ratio_of_far_field), C.c_float(order_of_truncation), _fp(r), _fp(t),
+                            C.byref(it), C.byref(err), _fp(trace) if trace_cap else None, trace_cap, C.byref(tl))
+    out = (_from_col9(r), t, it.value, err.value)
+    if trace_cap:
+        return out + (trace[:min(tl.value, trace_cap)].copy(),)
+    return out

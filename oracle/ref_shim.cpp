@@ -16,6 +16,8 @@
 #include "basicicp.h"
 #include "coherentpointdrift.h"
 #include "cpdutils.h"
+#include "fgt.h"
+#include "fgt_model.h"
 
 using Common::Point_f;
 
@@ -189,4 +191,59 @@ REF_API void ref_cpd(const float* before_xyz, int m, const float* after_xyz, int
         max_iterations, tolerance, static_cast<Common::ApproximationType>(fgt), ratio_of_far_field, order_of_truncation);
     from_mat3(r.first, rot9_colmajor);
     trans3[0] = r.second.x; trans3[1] = r.second.y; trans3[2] = r.second.z;
+}
+
+// CoherentPointDrift::ComputePMatrix with the truncated kernel of the hybrid mode (doTruncate = true)
+// cpu-slam/coherentpointdrift.cpp:166 (call site) / :168-221
+REF_API void ref_cpd_estep_truncated(const float* transformed_xyz, int m, const float* after_xyz, int n, float constant,
+                                     float sigma_squared, float truncate, float* p1, float* pt1, float* px, float* L)
+{
+    auto p = CoherentPointDrift::ComputePMatrix(to_cloud(transformed_xyz, m), to_cloud(after_xyz, n), constant,
+                                                sigma_squared, true, truncate);
+    for (int k = 0; k < m; k++) {
+        p1[k] = p.p1(k);
+        for (int d = 0; d < 3; d++) px[3 * k + d] = p.px(k, d);
+    }
+    for (int x = 0; x < n; x++) pt1[x] = p.pt1(x);
+    *L = p.error;
+}
+
+// CoherentPointDrift::ComputePMatrixWithFGT  common/cpdutils.cpp:19-77
+REF_API void ref_cpd_estep_fgt(const float* transformed_xyz, int m, const float* after_xyz, int n, float weight,
+                               float sigma_squared, float sigma_squared_init, float ratio_of_far_field,
+                               float order_of_truncation, float* p1, float* pt1, float* px, float* L)
+{
+    auto p = CoherentPointDrift::ComputePMatrixWithFGT(to_cloud(transformed_xyz, m), to_cloud(after_xyz, n), weight,
+                                                       sigma_squared, sigma_squared_init, ratio_of_far_field,
+                                                       order_of_truncation);
+    for (int k = 0; k < m; k++) {
+        p1[k] = p.p1(k);
+        for (int d = 0; d < 3; d++) px[3 * k + d] = p.px(k, d);
+    }
+    for (int x = 0; x < n; x++) pt1[x] = p.pt1(x);
+    *L = p.error;
+}
+
+// FastGaussTransform::ComputeFGTModel  common/fgt.cpp:63-86: xc_out[3*K], ak_out[pd*K] column-major (pd rows).
+// Returns pd.
+REF_API int ref_fgt_model(const float* cloud_xyz, int n, const float* weights, float sigma, int K, int p,
+                          float* xc_out, float* ak_out)
+{
+    std::vector<float> w(weights, weights + n);
+    auto model = FastGaussTransform::ComputeFGTModel(to_cloud(cloud_xyz, n), w, sigma, K, p);
+    from_cloud(model.xc, xc_out);
+    const int pd = static_cast<int>(model.Ak.rows());
+    std::memcpy(ak_out, model.Ak.data(), sizeof(float) * pd * K);
+    return pd;
+}
+
+// FastGaussTransform::ComputeFGTPredict  common/fgt.cpp:88-150 on a model handed back in ref_fgt_model's layout.
+REF_API void ref_fgt_predict(const float* cloud_xyz, int n, const float* xc, const float* ak, int pd, float sigma,
+                             float e_param, int K, int p, float* v_out)
+{
+    FastGaussTransform::FGT_Model model;
+    model.xc = to_cloud(xc, K);
+    model.Ak = Eigen::Map<const Eigen::MatrixXf>(ak, pd, K);
+    auto v = FastGaussTransform::ComputeFGTPredict(to_cloud(cloud_xyz, n), model, sigma, e_param, K, p);
+    std::memcpy(v_out, v.data(), sizeof(float) * n);
 }

@@ -147,3 +147,55 @@ def cpd(before, after, eps=1e-3, weight=0.3, const_scale=False, max_iterations=5
                   1 if const_scale else 0, max_iterations, C.c_float(tolerance), fgt, C.c_float(ratio_of_far_field),
                   C.c_float(order_of_truncation), _fp(r), _fp(t), C.byref(it), C.byref(err))
     return r.reshape(3, 3).T.copy(), t, it.value, err.value
+
+
+def cpd_estep_truncated(transformed, after, constant, sigma_squared, truncate=1e-3):
+    transformed, after = _cloud(transformed), _cloud(after)
+    m, n = transformed.shape[0], after.shape[0]
+    p1 = np.empty(m, np.float32)
+    pt1 = np.empty(n, np.float32)
+    px = np.empty((m, 3), np.float32)
+    L = C.c_float(0)
+    lib().ref_cpd_estep_truncated(_fp(transformed), m, _fp(after), n, C.c_float(constant), C.c_float(sigma_squared),
+                                  C.c_float(truncate), _fp(p1), _fp(pt1), _fp(px), C.byref(L))
+    return p1, pt1, px, L.value
+
+
+def cpd_estep_fgt(transformed, after, weight, sigma_squared, sigma_squared_init, ratio_of_far_field=10.0,
+                  order_of_truncation=8.0):
+    transformed, after = _cloud(transformed), _cloud(after)
+    m, n = transformed.shape[0], after.shape[0]
+    p1 = np.empty(m, np.float32)
+    pt1 = np.empty(n, np.float32)
+    px = np.empty((m, 3), np.float32)
+    L = C.c_float(0)
+    lib().ref_cpd_estep_fgt(_fp(transformed), m, _fp(after), n, C.c_float(weight), C.c_float(sigma_squared),
+                            C.c_float(sigma_squared_init), C.c_float(ratio_of_far_field), C.c_float(order_of_truncation),
+                            _fp(p1), _fp(pt1), _fp(px), C.byref(L))
+    return p1, pt1, px, L.value
+
+
+def fgt_pd(p):
+    """nchoosek(p + 2, 3): number of monomials of total degree < p in 3 variables (fgt.cpp:69)."""
+    return (p + 2) * (p + 1) * p // 6
+
+
+def fgt_model(cloud, weights, sigma, K, p):
+    cloud = _cloud(cloud)
+    weights = np.ascontiguousarray(weights, np.float32)
+    xc = np.empty((K, 3), np.float32)
+    ak = np.empty(fgt_pd(p) * K, np.float32)
+    lib().ref_fgt_model.restype = C.c_int
+    pd = lib().ref_fgt_model(_fp(cloud), cloud.shape[0], _fp(weights), C.c_float(sigma), K, p, _fp(xc), _fp(ak))
+    assert pd == fgt_pd(p)
+    return xc, ak.reshape(K, pd)      # row k = column k of the reference's (pd x K) matrix
+
+
+def fgt_predict(cloud, xc, ak, sigma, e_param, p):
+    cloud = _cloud(cloud)
+    xc = np.ascontiguousarray(xc, np.float32)
+    ak = np.ascontiguousarray(ak, np.float32)
+    K, pd = ak.shape
+    v = np.empty(cloud.shape[0], np.float32)
+    lib().ref_fgt_predict(_fp(cloud), cloud.shape[0], _fp(xc), _fp(ak), pd, C.c_float(sigma), C.c_float(e_param), K, p, _fp(v))
+    return v

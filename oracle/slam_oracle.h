@@ -62,6 +62,26 @@ typedef struct {
 void  oracle_cpd(const float* before, int m, const float* after, int n, const oracle_cpd_params* p,
                  float rot9[9], float trans3[3], int* iterations, float* error, float* trace, int trace_cap, int* trace_len);
 
+/* ---- Fast Gauss Transform E-step and the full / hybrid CPD drivers (oracle/fgt_oracle.c) ---- */
+int   oracle_fgt_nchoosek(int n, int k);
+int   oracle_fgt_pd(int p);
+void  oracle_fgt_kcenter(const float* cloud, int n, int K, float* xc, int* indx);
+void  oracle_fgt_ck(int p, float* C_k);
+void  oracle_fgt_model(const float* cloud, int n, const float* weights, float sigma, int K, int p, float* xc, float* ak);
+void  oracle_fgt_predict(const float* cloud, int n, const float* xc, const float* ak, float sigma, float e_param, int K, int p,
+                         float* v);
+int   oracle_cpd_fgt_clusters(int m, int n, float sigma_squared, float sigma_squared_init);
+float oracle_cpd_fgt_ndi(float sigma_squared, float weight, int m, int n);
+void  oracle_cpd_estep_fgt(const float* transformed, int m, const float* after, int n, float weight, float sigma_squared,
+                           float sigma_squared_init, float ratio_of_far_field, float order_of_truncation,
+                           float* p1, float* pt1, float* px, float* L);
+void  oracle_cpd_estep_truncated(const float* transformed, int m, const float* after, int n, float constant, float sigma_squared,
+                                 float truncate, float* p1, float* pt1, float* px, float* L);
+/* approximation: 0 none, 1 full, 2 hybrid.  trace: per EM iteration 17 floats = sigma2, L, ntol, scale, R(9), t(3), used_fgt. */
+void  oracle_cpd_approx(const float* before, int m, const float* after, int n, const oracle_cpd_params* p, int approximation,
+                        float ratio_of_far_field, float order_of_truncation, float rot9[9], float trans3[3], int* iterations,
+                        float* error, float* trace, int trace_cap, int* trace_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,212 @@
+"""GPU suite: the Fast-Gauss-Transform E-step and the full / hybrid CPD drivers through the C ABI, against the plain-C
+restatement (oracle/fgt_oracle.c, itself bit-identical to the reference's CPU build on these paths) and the fixtures generated
+from that build (tests/golden/bunny_fgt*).  Integer work (the K-centre labels) must match bit for bit; the transforms differ
+from cpu-slam by expf's last bit and the polynomial evaluation order only -- tolerances are written next to each check."""
+import numpy as np
+import pytest
+
+from conftest import frob
+
+pytestmark = pytest.mark.gpu
+
+
+def cloud(seed, n, spread=2.0):
+    return (np.random.default_rng(seed).normal(size=(n, 3)) * spread).astype(np.float32)
+
+
+def pair(seed, m, n):
+    rng = np.random.default_rng(seed)
+    y = (rng.normal(size=(m, 3)) * 2).astype(np.float32)
+    x = (y[rng.integers(0, m, n)] + rng.normal(size=(n, 3)) * 0.3).astype(np.float32)
+    return y, x
+
+
+def rel(a, b):
+    return float(np.abs(a.astype(np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K-centre clustering: labels and cell means bit for bit
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed,n,K", [(0, 2, 1), (1, 2, 2), (2, 300, 50), (3, 4096, 117), (4, 4097, 64), (5, 14904, 117),
+                                      (6, 16384, 51), (7, 16385, 33), (8, 50000, 70), (9, 1000, 1000)])
+def test_kcenter_matches_oracle_bit_for_bit(ctx, oracle, seed, n, K):
+    c = cloud(seed, n)
+    xc_o, lab_o = oracle.fgt_kcenter(c, K)
+    xc, lab = ctx.fgt_kcenter(c, K)
+    assert np.array_equal(lab, lab_o)
+    assert np.array_equal(xc, xc_o)
+
+
+def test_kcenter_ties_and_duplicates(ctx, oracle):
+    # a lattice (many equal distances: the FIRST maximum must win) with every point duplicated (strict < keeps the old label)
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    c = np.concatenate([g, g])[np.random.default_rng(0).permutation(1024)]
+    for K in (2, 9, 64, 200):
+        xc_o, lab_o = oracle.fgt_kcenter(c, K)
+        xc, lab = ctx.fgt_kcenter(c, K)
+        assert np.array_equal(lab, lab_o)
+        assert np.array_equal(xc, xc_o)
+    # more cells than distinct points: empty cells, NaN means, exactly as the reference
+    few = np.repeat(cloud(3, 6), 5, axis=0)
+    xc_o, lab_o = oracle.fgt_kcenter(few, 10)
+    xc, lab = ctx.fgt_kcenter(few, 10)
+    assert np.array_equal(lab, lab_o) and np.array_equal(np.isnan(xc), np.isnan(xc_o)) and np.isnan(xc).any()
+    assert np.array_equal(np.nan_to_num(xc, nan=7.0), np.nan_to_num(xc_o, nan=7.0))
+
+
+def test_bunny_kcenter_golden(ctx, golden, bunny):
+    _, after = bunny
+    e = golden.npz("bunny_fgt_estep.npz")
+    xc, lab = ctx.fgt_kcenter(after, 117)
+    assert np.array_equal(lab, e["kcenter117_labels"].astype(np.int32)) and np.array_equal(xc, e["kcenter117_xc"])
+
+
+def test_kcenter_rejects_bad_arguments(ctx, capi):
+    with pytest.raises(capi.MiSlamError):
+        ctx.fgt_kcenter(cloud(0, 1), 1)              # the sweep starts from point 1: needs two points
+    with pytest.raises(capi.MiSlamError):
+        ctx.fgt_kcenter(cloud(0, 10), 0)
+    with pytest.raises(capi.MiSlamError):
+        ctx.fgt_kcenter(cloud(0, 10), 1 << 16)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# E-steps
+# ---------------------------------------------------------------------------------------------------------------------
+# Tolerance: P1/Pt1/PX are sums of products of O(1e2) fp32 terms; against the reference's own evaluation order the Horner
+# form agrees to a few 1e-6 of the largest entry, 1e-5 leaves headroom.
+ESTEP_TOL = 1e-5
+
+
+@pytest.mark.parametrize("seed,m,n,s2,order", [(0, 400, 500, 2.0, 8), (1, 700, 300, 0.3, 8), (2, 100, 100, 0.05, 8), (3, 2, 2, 1.0, 8),
+                                               (4, 3000, 2500, 0.8, 5), (5, 513, 255, 1.5, 1), (6, 5000, 6000, 0.2, 11)])
+def test_fgt_estep_matches_oracle(ctx, oracle, seed, m, n, s2, order):
+    y, x = pair(seed, m, n)
+    s2_init = 4.0
+    want = oracle.cpd_estep_fgt(y, x, 0.3, s2, s2_init, 10.0, float(order))
+    got = ctx.cpd_estep_fgt(y, x, 0.3, s2, s2_init, 10.0, order)
+    for g, w in zip(got[:3], want[:3]):
+        assert rel(g, w) < ESTEP_TOL
+    assert abs(got[3] - want[3]) < 2e-6 * abs(want[3]) + 1e-3
+
+
+@pytest.mark.parametrize("name", ["init", "s006"])
+def test_bunny_fgt_estep_golden(ctx, golden, bunny, name):
+    before, after = bunny
+    g = golden.json("bunny_fgt.json")
+    e = golden.npz("bunny_fgt_estep.npz")
+    c = g["esteps"][name]
+    st = g["stride"]
+    p1, pt1, px, L = ctx.cpd_estep_fgt(before, after, g["weight"], c["sigma2"], g["sigma2_init"])
+    assert rel(p1[::st], e[name + "_p1"]) < ESTEP_TOL
+    assert rel(pt1[::st], e[name + "_pt1"]) < ESTEP_TOL
+    assert rel(px[::st], e[name + "_px"]) < ESTEP_TOL
+    # cpu-slam sums the 14 904 logs sequentially in fp32 (cpdutils.cpp:69-71): its own rounding is ~1e-5 of the sum; ours is fp64
+    assert abs(L - c["L"]) < 1e-4 * abs(c["L"])
+    assert abs(float(p1.astype(np.float64).sum()) - c["p1_sum"]) < 1e-5 * c["p1_sum"]
+
+
+@pytest.mark.parametrize("seed,m,n,s2", [(0, 400, 500, 2.0), (1, 700, 300, 0.05), (2, 3000, 2000, 0.02)])
+def test_truncated_estep_matches_oracle(ctx, oracle, seed, m, n, s2):
+    y, x = pair(seed, m, n)
+    c = oracle.cpd_constant(4.0, 0.3, m, n)
+    want = oracle.cpd_estep_truncated(y, x, c, s2, 1e-3)
+    got = ctx.cpd_estep_truncated(y, x, c, s2, 1e-3)
+    # an affinity within an ulp of the cut (exp(index) vs 1e-3) may fall on the other side: each costs <= 1e-3/den of one entry
+    for g, w in zip(got[:3], want[:3]):
+        assert rel(g, w) < 2e-4
+    assert abs(got[3] - want[3]) < 1e-5 * abs(want[3]) + 1e-3
+
+
+def test_bunny_truncated_estep_golden(ctx, golden, bunny):
+    before, after = bunny
+    g = golden.json("bunny_fgt.json")
+    e = golden.npz("bunny_fgt_estep.npz")
+    t = g["truncated"]
+    st = g["stride"]
+    p1, pt1, px, L = ctx.cpd_estep_truncated(before, after, g["constant"], t["sigma2"], t["truncate"])
+    assert rel(p1[::st], e["trunc_p1"]) < 2e-4 and rel(pt1[::st], e["trunc_pt1"]) < 2e-4 and rel(px[::st], e["trunc_px"]) < 2e-4
+    assert abs(L - t["L"]) < 1e-4 * abs(t["L"])              # sequential fp32 log sum there, fp64 here
+
+
+def test_estep_primitives_reject_bad_arguments(ctx, capi):
+    y, x = pair(0, 50, 60)
+    with pytest.raises(capi.MiSlamError):
+        ctx.cpd_estep_fgt(y, x, 0.3, 1.0, 4.0, 10.0, 0)          # order of truncation
+    with pytest.raises(capi.MiSlamError):
+        ctx.cpd_estep_fgt(y, x, 0.3, 1.0, 4.0, 10.0, 17)
+    with pytest.raises(capi.MiSlamError):
+        ctx.cpd_estep_fgt(y[:1], x, 0.3, 1.0, 4.0, 10.0, 8)      # one point
+    with pytest.raises(capi.MiSlamError):
+        ctx.cpd_estep_fgt(y, x, 0.3, 0.0, 4.0, 10.0, 8)
+    with pytest.raises(capi.MiSlamError):
+        ctx.cpd_estep_truncated(y, x, 1.0, 1.0, 0.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# full runs
+# ---------------------------------------------------------------------------------------------------------------------
+def test_bunny_hybrid_run_matches_cpu_slam(ctx, capi, golden, bunny):
+    # cfg: cpd with the parser's default approximation type.  north_star bar: R|t within 1e-4 (Frobenius) of cpu-slam
+    before, after = bunny
+    g = golden.json("bunny_fgt.json")
+    r = g["runs"]["hybrid"]
+    p = capi.cpd_params(max_iterations=r["max_iterations"], sigma2_init=g["sigma2_init"], approximation=capi.CPD_APPROX_HYBRID)
+    sR, t, sc, it, err = ctx.cpd_register(before, after, p)
+    assert it == r["iterations"] == 23
+    assert frob(sR, t, np.array(r["R"]), np.array(r["t"])) < 1e-4
+    assert err < 1e-3
+
+
+@pytest.mark.parametrize("cap", [5, 17])
+def test_bunny_full_mode_capped_matches_cpu_slam(ctx, capi, golden, bunny, cap):
+    before, after = bunny
+    g = golden.json("bunny_fgt.json")
+    r = g["runs"]["full_cap%d" % cap]
+    p = capi.cpd_params(max_iterations=cap, sigma2_init=g["sigma2_init"], approximation=capi.CPD_APPROX_FULL)
+    sR, t, sc, it, err = ctx.cpd_register(before, after, p)
+    assert it == cap
+    assert frob(sR, t, np.array(r["R"]), np.array(r["t"])) < 1e-4
+    assert abs(err - r["error"]) < 5e-4 * r["error"]
+
+
+@pytest.mark.parametrize("approx", [1, 2])
+def test_small_runs_match_oracle(ctx, capi, oracle, approx):
+    rng = np.random.default_rng(11)
+    b = (rng.normal(size=(2000, 3)) * 2).astype(np.float32)
+    ang = 0.3
+    Rz = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    a = (b[rng.permutation(2000)[:1500]] @ Rz.T + np.array([0.4, -0.2, 0.1])).astype(np.float32)
+    cap = 15
+    Ro, to, ito, eo = oracle.cpd_approx(b, a, approx, max_iterations=cap)
+    p = capi.cpd_params(max_iterations=cap, sigma2_init=oracle.cpd_sigma_squared(b, a), approximation=approx)
+    sR, t, sc, it, err = ctx.cpd_register(b, a, p)
+    assert it == ito
+    assert frob(sR, t, Ro, to) < 1e-4
+    assert abs(err - eo) < 2e-3 * max(eo, 1e-3)
+
+
+def test_full_mode_clamps_sigma(ctx, capi, oracle):
+    # approximation "full": sigma^2 never enters an E-step below 0.05 (coherentpointdrift.cpp:154-155).  On nearly aligned clouds the
+    # first M-step already lands below that, so every later E-step runs at the clamp; the run must retrace the restatement's.
+    b = cloud(2, 800, spread=0.15)                           # sigma^2_init = 0.046: clamped from the first E-step on
+    a = (b + np.array([0.05, 0.0, -0.02])).astype(np.float32)
+    cap = 6
+    Ro, to, ito, eo, trace = oracle.cpd_approx(b, a, oracle.APPROX_FULL, max_iterations=cap, tolerance=1e-9, trace_cap=cap)
+    p = capi.cpd_params(max_iterations=cap, tolerance=1e-9, sigma2_init=oracle.cpd_sigma_squared(b, a), approximation=capi.CPD_APPROX_FULL)
+    sR, t, sc, it, err = ctx.cpd_register(b, a, p)
+    assert it == ito == cap
+    assert (trace[:, 0] < 0.05).all()                        # every M-step lands below the clamp
+    assert frob(sR, t, Ro, to) < 1e-4
+    assert abs(err - eo) < 1e-3 * eo
+
+
+def test_register_rejects_bad_fgt_parameters(ctx, capi):
+    b = cloud(0, 100)
+    with pytest.raises(capi.MiSlamError):
+        ctx.cpd_register(b, b, capi.cpd_params(max_iterations=3, approximation=3))
+    with pytest.raises(capi.MiSlamError):
+        ctx.cpd_register(b, b, capi.cpd_params(max_iterations=3, approximation=capi.CPD_APPROX_HYBRID, fgt_order_of_truncation=0))
+    with pytest.raises(capi.MiSlamError):
+        ctx.cpd_register(b[:1], b, capi.cpd_params(max_iterations=3, approximation=capi.CPD_APPROX_FULL))

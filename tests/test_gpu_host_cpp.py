@@ -74,6 +74,25 @@ def test_mi_slam_cpd(tmp_path, capi, ctx):
     assert res["iterations"] == it and np.array_equal(Rc, sR) and np.array_equal(np.array(res["t"], np.float32), t)
 
 
+def test_mi_slam_cpd_default_approximation_is_hybrid(tmp_path, capi, ctx):
+    # no "approximation-type" key: the reference's parser falls back to hybrid (configparser.cpp:221-230) and so does mi-slam
+    make_obj(tmp_path / "model.obj", n_vertices=1500)
+    cfg = {"before-path": "model.obj", "after-path": "model.obj", "method": "cpd", "translation": [0.3, -0.2, 0.1],
+           "rotation": [0.9553365, -0.2955202, 0.0, 0.2955202, 0.9553365, 0.0, 0.0, 0.0, 1.0], "cloud-spread": 10.0,
+           "max-iterations": 40, "random-seed": 7, "cloud-before-resize": 2000, "cloud-after-resize": 2000}
+    r = run_mi_slam(cfg, tmp_path)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Approximation type: hybrid" in r.stdout
+    res = json.loads((tmp_path / "result.json").read_text())
+    before, after = read_dump(tmp_path / "clouds.bin")
+    p = capi.cpd_params(max_iterations=40, approximation=capi.CPD_APPROX_HYBRID)
+    sR, t, sc, it, err = ctx.cpd_register(before, after, p)
+    Rc = np.array(res["R_colmajor"], np.float32).reshape(3, 3).T
+    assert res["iterations"] == it and np.array_equal(Rc, sR) and np.array_equal(np.array(res["t"], np.float32), t)
+    exact = ctx.cpd_register(before, after, capi.cpd_params(max_iterations=40))
+    assert not np.array_equal(exact[0], sR)                # the approximation really ran
+
+
 def test_mi_slam_reports_unsupported_method(tmp_path):
     make_obj(tmp_path / "model.obj", n_vertices=300)
     cfg = {"before-path": "model.obj", "after-path": "model.obj", "method": "nicp", "translation": [0, 0, 0],

@@ -47,6 +47,21 @@ def main():
                               "K8_mstep_ms": prof["cpd_mstep"][0] / max(prof["cpd_mstep"][1], 1),
                               "K7a_pairs_per_s": pairs / (den_ms * 1e-3), "K7b_pairs_per_s": pairs / (con_ms * 1e-3),
                               "t": [float(x) for x in t], "sigma2": err}), flush=True)
+        # the reference's approximate modes (K9: FGT E-step on the device), same clouds
+        os.environ["MISLAM_CPD_MFMA"] = "1"
+        for approx, label in ((capi.CPD_APPROX_HYBRID, "hybrid"), (capi.CPD_APPROX_FULL, "full")):
+            p = capi.cpd_params(max_iterations=50 if label == "hybrid" else 17, const_scale=0, sigma2_init=s2, approximation=approx)
+            ctx.cpd_register(before, after, p)
+            ctx.profile_enable(True)
+            ctx.profile_reset()
+            t0 = time.perf_counter()
+            sR, t, scale, it, err = ctx.cpd_register(before, after, p)
+            wall = time.perf_counter() - t0
+            fgt_ms, fgt_n = ctx.profile_get(capi.KERNEL_CPD_FGT)
+            ctx.profile_enable(False)
+            print(json.dumps({"case": name, "approximation": label, "iterations": it, "wall_ms_total": wall * 1e3,
+                              "ms_per_em_iteration": wall * 1e3 / max(it, 1), "fgt_esteps": fgt_n,
+                              "K9_fgt_estep_ms": fgt_ms / max(fgt_n, 1), "t": [float(x) for x in t], "sigma2": err}), flush=True)
     ctx.close()
 
 
