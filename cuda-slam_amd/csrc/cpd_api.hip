@@ -23,14 +23,15 @@ struct FgtSide {
     DevBuf<int> indx, iota, memb, off;
     DevBuf<unsigned int> keys;
     int iota_n = 0;
-    void release() { dist.release(); xc.release(); indx.release(); iota.release(); memb.release(); off.release(); keys.release(); iota_n = 0; }
+    int swept_K = 0;            // the fixed cloud only: centres of the sweep dist/indx currently hold (0 = none); see fgt_kcenter_kernel
+    void release() { dist.release(); xc.release(); indx.release(); iota.release(); memb.release(); off.release(); keys.release(); iota_n = 0; swept_K = 0; }
 };
 
 // Fast-Gauss-Transform E-step workspace ("approximation-type" full / hybrid)
 struct FgtWork {
     FgtSide y, a;
     DevBuf<float> By, Ba;                // coefficients: [1][K][pd] (moving cloud as sources), [4][K][pd] (fixed cloud as sources)
-    DevBuf<float> kt1, v4;               // transform outputs: [n], [4][m]
+    DevBuf<float> kt1, v4;               // transform outputs, per split of the cells: [S][n], [S][4][m]
     DevBuf<unsigned char> sort_temp;
     DevBuf<unsigned int> mono;
     DevBuf<float> ck;
@@ -98,6 +99,7 @@ static void plan_chunks(const mi_ctx* c, int owners, int owner_r, int stream_len
 static int cpd_load(mi_ctx* c, CpdWorkspace* w, const float* before_xyz, int m, const float* after_xyz, int n)
 {
     c->icp_loaded = false;   // the moving-cloud buffers are shared with the ICP driver
+    w->fgt.a.swept_K = 0;    // a new fixed cloud: its clustering starts over
     w->m = m; w->n = n;
     w->m_pad = round_up_i(m, NN_SRC_PAD);
     w->n_pad = round_up_i(n, NN_SRC_PAD);
@@ -250,7 +252,7 @@ static int fgt_side(mi_ctx* c, FgtWork* f, FgtSide* sd, const float* x, const fl
     MI_TRY(sd->keys.reserve(n)); MI_TRY(sd->off.reserve((size_t)K + 1)); MI_TRY(sd->xc.reserve(3 * (size_t)K));
     if (sd->iota_n < n) { MI_HIP(fgt_fill_iota(sd->iota.p, n, c->stream)); sd->iota_n = n; }
     MI_TRY(f->sort_temp.reserve(std::max<size_t>(fgt_sort_temp_bytes(n), 16)));
-    out->x = x; out->y = y; out->z = z; out->n = n; out->K = K;
+    out->x = x; out->y = y; out->z = z; out->n = n; out->K = K; out->k_done = 0;
     out->dist = sd->dist.p; out->indx = sd->indx.p; out->iota = sd->iota.p; out->keys_sorted = sd->keys.p;
     out->memb = sd->memb.p; out->off = sd->off.p; out->xc = sd->xc.p;
     return MI_OK;
@@ -285,19 +287,28 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
     MI_TRY(fgt_side(c, f, &f->y, v.yx, v.yy, v.yz, w->m, K, &cy));
     MI_TRY(fgt_side(c, f, &f->a, v.ax, v.ay, v.az, w->n, K, &ca));
     MI_TRY(f->By.reserve((size_t)K * t.pd)); MI_TRY(f->Ba.reserve(4 * (size_t)K * t.pd));
-    MI_TRY(f->kt1.reserve(w->n)); MI_TRY(f->v4.reserve(4 * (size_t)w->m));
+    const int Sa = fgt_predict_splits(w->n, K), Sy = fgt_predict_splits(w->m, K);
+    MI_TRY(f->kt1.reserve((size_t)Sa * w->n)); MI_TRY(f->v4.reserve(4 * (size_t)Sy * w->m));
     const size_t temp = f->sort_temp.cap;
     // Kt1 = K^T 1: sources = moving cloud, unit weights, queried at the fixed cloud   (cpdutils.cpp:42-43)
     MI_HIP(fgt_cluster(cy, f->sort_temp.p, temp, c->stream));
     MI_HIP(fgt_model(cy, nullptr, hsigma, t, f->By.p, c->stream));
-    MI_HIP(fgt_predict(v.ax, v.ay, v.az, w->n, cy.xc, f->By.p, K, 1, hsigma, ratio_of_far_field, t, f->kt1.p, c->stream));
-    MI_HIP(fgt_post_kt1(f->kt1.p, v.ax, v.ay, v.az, w->n, ndi, v.pt1, v.xw4, c->stream));
+    MI_HIP(fgt_predict(v.ax, v.ay, v.az, w->n, cy.xc, f->By.p, K, 1, hsigma, ratio_of_far_field, t, Sa, f->kt1.p, c->stream));
+    MI_HIP(fgt_post_kt1(f->kt1.p, Sa, v.ax, v.ay, v.az, w->n, ndi, v.pt1, v.xw4, c->stream));
     // P1 and PX: sources = fixed cloud weighted by 1/den and x/den, queried at the moving cloud   (:54-66; the reference
     // clusters the fixed cloud four times with the same result -- once is enough)
-    MI_HIP(fgt_cluster(ca, f->sort_temp.p, temp, c->stream));
+    // the fixed cloud does not move: the same K needs no new clustering at all, a larger K only the additional centres
+    // (MISLAM_FGT_RESUME=0 re-clusters from scratch every time; the results must not change by a bit -- tests/test_gpu_fgt.py)
+    const char* resume_env = getenv("MISLAM_FGT_RESUME");
+    const bool resume = !(resume_env && *resume_env == '0');
+    if (!resume || f->a.swept_K != K) {
+        ca.k_done = resume && f->a.swept_K < K ? f->a.swept_K : 0;
+        MI_HIP(fgt_cluster(ca, f->sort_temp.p, temp, c->stream));
+        f->a.swept_K = K;
+    }
     MI_HIP(fgt_model(ca, v.xw4, hsigma, t, f->Ba.p, c->stream));
-    MI_HIP(fgt_predict(v.yx, v.yy, v.yz, w->m, ca.xc, f->Ba.p, K, 4, hsigma, ratio_of_far_field, t, f->v4.p, c->stream));
-    MI_HIP(fgt_post_px(f->v4.p, w->m, v.p1, v.px, c->stream));
+    MI_HIP(fgt_predict(v.yx, v.yy, v.yz, w->m, ca.xc, f->Ba.p, K, 4, hsigma, ratio_of_far_field, t, Sy, f->v4.p, c->stream));
+    MI_HIP(fgt_post_px(f->v4.p, Sy, w->m, v.p1, v.px, c->stream));
     return MI_OK;
 }
 

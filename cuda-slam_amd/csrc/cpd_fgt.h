@@ -22,7 +22,8 @@ struct FgtTables {
 struct FgtClusters {
     const float *x, *y, *z;     // the cloud, SoA
     int n, K;
-    float* dist;                // [n]   scratch: squared distance to the nearest centre so far
+    int k_done;                 // > 0: dist/indx hold a finished sweep of this cloud with k_done < K centres -- resume it
+    float* dist;                // [n]   squared distance to the nearest centre so far (kept: the sweep can be resumed)
     int* indx;                  // [n]   cluster of each point
     int* iota;                  // [n]   0..n-1 (sort values in)
     unsigned int* keys_sorted;  // [n]
@@ -38,13 +39,15 @@ hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_b
 // coefficients B[w][k][hpos] = C_k * sum_{i in cluster k} weight_w(i) exp(-|dx|^2) dx^alpha, dx = (pt - xc_k) / sigma.
 // w4 == nullptr: one weight set of ones (W = 1); else four: (w4.x, w4.y, w4.z, w4.w) (W = 4).
 hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const FgtTables& t, float* B, hipStream_t s);
-// v[w][i] = sum_k [ |dy|^2 <= e ] exp(-|dy|^2) sum_alpha B[w][k][alpha] dy^alpha, dy = (q_i - xc_k) / sigma   (fgt.cpp:88-150)
+// v[split][w][i] = sum_{k in split} [ |dy|^2 <= e ] exp(-|dy|^2) sum_alpha B[w][k][alpha] dy^alpha, dy = (q_i - xc_k) / sigma
+// (fgt.cpp:88-150); the S = fgt_predict_splits(nq, K) partial sums are added in split order by the post kernels
+int fgt_predict_splits(int nq, int K);
 hipError_t fgt_predict(const float* qx, const float* qy, const float* qz, int nq, const float* xc, const float* B, int K, int W,
-                       float sigma, float e_param, const FgtTables& t, float* v, hipStream_t s);
+                       float sigma, float e_param, const FgtTables& t, int S, float* v, hipStream_t s);
 // Kt1 -> 1/denominator, Pt1 and the four weight sets of the second transform (cpdutils.cpp:45-52, :79-99)
-hipError_t fgt_post_kt1(const float* kt1, const float* ax, const float* ay, const float* az, int n, float ndi, float* pt1,
+hipError_t fgt_post_kt1(const float* kt1_parts, int S, const float* ax, const float* ay, const float* az, int n, float ndi, float* pt1,
                         float4* xw4, hipStream_t s);
-// v[4][m] -> P1[m], PX[m][3]
-hipError_t fgt_post_px(const float* v, int m, float* p1, float* px, hipStream_t s);
+// v[S][4][m] -> P1[m], PX[m][3]
+hipError_t fgt_post_px(const float* v_parts, int S, int m, float* p1, float* px, hipStream_t s);
 
 }  // namespace mislam

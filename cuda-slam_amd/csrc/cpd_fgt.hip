@@ -56,27 +56,54 @@ __device__ __forceinline__ ArgMax wave_argmax(ArgMax a)
 
 // PER > 0: every lane keeps its PER points (id = lane + r * 1024), their distances and labels in registers.
 // PER == 0: any n; distances and labels stay in global memory (each lane only ever touches its own entries).
+// The sweep is prefix-stable (the first k centres do not depend on K), so a finished sweep can be RESUMED: with start > 0 the
+// kernel picks up the distances and labels steps 0..start-1 left in dist/indx and runs steps start..K-1 only.  The fixed cloud
+// of a CPD run is clustered this way: K grows as sigma^2 shrinks, and each new E-step only adds the missing centres.
 template <int PER>
 __global__ __launch_bounds__(1024) void fgt_kcenter_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                           const float* __restrict__ z, int n, int K, float* __restrict__ dist,
-                                                           int* __restrict__ indx)
+                                                           const float* __restrict__ z, int n, int start, int K,
+                                                           float* __restrict__ dist, int* __restrict__ indx)
 {
     __shared__ ArgMax s_best[2][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NR = PER > 0 ? PER : 1;
     float px[NR], py[NR], pz[NR], pd[NR];
     int pc[NR];
+    ArgMax best = {-1.f, 0x7fffffff, 0.f, 0.f, 0.f};
     if (PER > 0) {
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            const int j = min(tid + r * 1024, n - 1);
-            px[r] = x[j]; py[r] = y[j]; pz[r] = z[j];
+            const int j = tid + r * 1024, jc = min(j, n - 1);
+            px[r] = x[jc]; py[r] = y[jc]; pz[r] = z[jc];
             pd[r] = 0.f; pc[r] = 0;
+            if (start > 0) {
+                pd[r] = dist[jc]; pc[r] = indx[jc];
+                if (j < n && pd[r] > best.v) best = {pd[r], j, px[r], py[r], pz[r]};
+            }
+        }
+    } else if (start > 0) {
+        for (int j = tid; j < n; j += 1024) {
+            const float cur = dist[j];
+            if (cur > best.v) best = {cur, j, x[j], y[j], z[j]};
         }
     }
     float cx = x[1], cy = y[1], cz = z[1];          // the first centre is point 1 (fgt.cpp:162)
-    for (int step = 0; step < K; step++) {
-        ArgMax best = {-1.f, 0x7fffffff, 0.f, 0.f, 0.f};
+    for (int step = start; step < K; step++) {
+        if (step > 0) {
+            // this step's centre = FIRST maximum of the distance array (std::max_element, fgt.cpp:179)
+            best = wave_argmax(best);
+            const int buf = step & 1;   // double-buffered: a wave can run at most one barrier ahead of the slowest reader
+            if (lane == 0) s_best[buf][wave] = best;
+            __syncthreads();
+            ArgMax w = s_best[buf][0];
+#pragma unroll
+            for (int q = 1; q < 16; q++) {
+                const ArgMax o = s_best[buf][q];
+                if (beats(o.v, o.i, w.v, w.i)) w = o;
+            }
+            cx = w.x; cy = w.y; cz = w.z;
+        }
+        best = {-1.f, 0x7fffffff, 0.f, 0.f, 0.f};
         if (PER > 0) {
 #pragma unroll
             for (int r = 0; r < NR; r++) {
@@ -103,28 +130,14 @@ __global__ __launch_bounds__(1024) void fgt_kcenter_kernel(const float* __restri
                 if (cur > best.v) best = {cur, j, qx, qy, qz};
             }
         }
-        if (step == K - 1) break;
-        // next centre = FIRST maximum of the distance array (std::max_element, fgt.cpp:179)
-        best = wave_argmax(best);
-        const int buf = step & 1;       // double-buffered: a wave can run at most one barrier ahead of the slowest reader
-        if (lane == 0) s_best[buf][wave] = best;
-        __syncthreads();
-        ArgMax w = s_best[buf][0];
-#pragma unroll
-        for (int q = 1; q < 16; q++) {
-            const ArgMax o = s_best[buf][q];
-            if (beats(o.v, o.i, w.v, w.i)) w = o;
-        }
-        cx = w.x; cy = w.y; cz = w.z;
     }
     if (PER > 0) {
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             const int j = tid + r * 1024;
-            if (j < n) indx[j] = pc[r];
+            if (j < n) { indx[j] = pc[r]; dist[j] = pd[r]; }
         }
     }
-    (void)dist;
 }
 
 __global__ __launch_bounds__(256) void fgt_iota_kernel(int* __restrict__ iota, int n)
@@ -146,55 +159,97 @@ __global__ __launch_bounds__(256) void fgt_offsets_kernel(const unsigned int* __
     off[k] = lo;
 }
 
-// Cell means: sequential fp32 sums in ascending point order, then * (1.0f / count)   (fgt.cpp:195-210)
-__global__ __launch_bounds__(64) void fgt_centers_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                         const float* __restrict__ z, const int* __restrict__ memb,
-                                                         const int* __restrict__ off, int K, float* __restrict__ xc)
+constexpr int FGT_TILE = 128;   // members staged through LDS per step of the centre / model kernels (= their block size)
+
+// Cell means: sequential fp32 sums in ascending point order, then * (1.0f / count)   (fgt.cpp:195-210).  One workgroup per
+// cell: the members' coordinates are gathered 128 at a time (coalesced index reads, one gather per lane) into LDS, and lanes
+// 0..2 run the three serial sums out of LDS -- the chain of dependent adds is the only serial part left.
+__global__ __launch_bounds__(FGT_TILE) void fgt_centers_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                               const float* __restrict__ z, const int* __restrict__ memb,
+                                                               const int* __restrict__ off, int K, float* __restrict__ xc)
 {
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= K) return;
+    __shared__ float s[3][FGT_TILE];
+    const int k = blockIdx.x, tid = threadIdx.x;
     const int j0 = off[k], j1 = off[k + 1];
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int j = j0; j < j1; j++) {
-        const int i = memb[j];
-        sx += x[i]; sy += y[i]; sz += z[i];
+    float sum = 0.f;
+    for (int base = j0; base < j1; base += FGT_TILE) {
+        const int cnt = min(FGT_TILE, j1 - base);
+        if (tid < cnt) {
+            const int i = memb[base + tid];
+            s[0][tid] = x[i]; s[1][tid] = y[i]; s[2][tid] = z[i];
+        }
+        __syncthreads();
+        if (tid < 3) {
+#pragma unroll 8
+            for (int q = 0; q < cnt; q++) sum += s[tid][q];
+        }
+        __syncthreads();
     }
-    const float inv = 1.0f / (float)(j1 - j0);     // an empty cell gives 0 * inf = NaN, exactly as the reference
-    xc[3 * k] = sx * inv; xc[3 * k + 1] = sy * inv; xc[3 * k + 2] = sz * inv;
+    // an empty cell gives 0 * inf = NaN, exactly as the reference
+    if (tid < 3) xc[3 * k + tid] = sum * (1.0f / (float)(j1 - j0));
+    (void)K;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// ComputeA_k (fgt.cpp:246-302): lane (k, t) accumulates its monomial over the members of cell k in the reference's order.
-// The monomial of exponents (a, b, c) is built the way the recursion builds it: the seed exp(-|dx|^2) times z c times, then
-// y b times, then x a times (prods[t] = val * prods[parent]).
+// ComputeA_k (fgt.cpp:246-302): workgroup = one cell, lane t = one monomial, accumulated over the members of the cell in the
+// reference's order.  Per tile of 128 members each lane prepares ONE member (powers of its scaled offset, exp(-|dx|^2),
+// weights) in LDS; all lanes then walk the tile: three power look-ups, three multiplies and W multiply-adds per member.
 // ---------------------------------------------------------------------------------------------------------------
 template <int W>
-__global__ __launch_bounds__(128) void fgt_model_kernel(FgtClusters c, const float4* __restrict__ w4, float inv_sigma, FgtTables t,
-                                                        float* __restrict__ B)
+__global__ __launch_bounds__(FGT_TILE) void fgt_model_kernel(FgtClusters c, const float4* __restrict__ w4, float inv_sigma, FgtTables t,
+                                                             float* __restrict__ B)
 {
-    const int k = blockIdx.x;
-    const int m = blockIdx.y * 128 + threadIdx.x;
-    if (m >= t.pd) return;
-    const unsigned int e = t.mono[m];
+    // powers d^0..d^(p-1) of the three scaled offsets of every member of the tile; rows padded by one word so that lanes
+    // reading different powers of the same member fall into different LDS banks
+    __shared__ float sp[3][FGT_MAX_ORDER][FGT_TILE + 1];
+    __shared__ float se[FGT_TILE];
+    __shared__ float sw[W][FGT_TILE];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int m = blockIdx.y * FGT_TILE + tid;
+    const bool live = m < t.pd;
+    const unsigned int e = t.mono[live ? m : 0];
     const int ea = e & 0xff, eb = (e >> 8) & 0xff, ec = (e >> 16) & 0xff;
     const float cx = c.xc[3 * k], cy = c.xc[3 * k + 1], cz = c.xc[3 * k + 2];
     float acc[W];
 #pragma unroll
     for (int w = 0; w < W; w++) acc[w] = 0.f;
     const int j0 = c.off[k], j1 = c.off[k + 1];
-    for (int j = j0; j < j1; j++) {
-        const int i = c.memb[j];
-        const float dx = (c.x[i] - cx) * inv_sigma, dy = (c.y[i] - cy) * inv_sigma, dz = (c.z[i] - cz) * inv_sigma;
-        float pr = expf(-len2(dx, dy, dz));
-        for (int q = 0; q < ec; q++) pr = dz * pr;
-        for (int q = 0; q < eb; q++) pr = dy * pr;
-        for (int q = 0; q < ea; q++) pr = dx * pr;
-        if (W == 1) acc[0] += pr;                                  // weights of ones (cpdutils.cpp:42)
-        else {
-            const float4 w = w4[i];
-            acc[0] += w.x * pr; acc[1 % W] += w.y * pr; acc[2 % W] += w.z * pr; acc[3 % W] += w.w * pr;
+    for (int base = j0; base < j1; base += FGT_TILE) {
+        const int cnt = min(FGT_TILE, j1 - base);
+        if (tid < cnt) {
+            const int i = c.memb[base + tid];
+            const float d[3] = {(c.x[i] - cx) * inv_sigma, (c.y[i] - cy) * inv_sigma, (c.z[i] - cz) * inv_sigma};
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                float pw = 1.0f;
+                for (int r = 0; r < t.p; r++) { sp[a][r][tid] = pw; pw = d[a] * pw; }
+            }
+            se[tid] = expf(-len2(d[0], d[1], d[2]));
+            if (W == 4) {
+                const float4 w = w4[i];
+                sw[0][tid] = w.x; sw[1 % W][tid] = w.y; sw[2 % W][tid] = w.z; sw[3 % W][tid] = w.w;
+            }
         }
+        __syncthreads();
+        if (live) {
+            const float* __restrict__ pz = sp[2][ec];
+            const float* __restrict__ py = sp[1][eb];
+            const float* __restrict__ px = sp[0][ea];
+#pragma unroll 4
+            for (int q = 0; q < cnt; q++) {
+                // exp(-|d|^2) z^c y^b x^a, the factors applied in the recursion's order (z, then y, then x); the powers
+                // themselves are formed first, which moves the last bit only
+                const float pr = ((se[q] * pz[q]) * py[q]) * px[q];
+                if (W == 1) acc[0] += pr;                          // weights of ones (cpdutils.cpp:42)
+                else {
+#pragma unroll
+                    for (int w = 0; w < W; w++) acc[w] += sw[w][q] * pr;
+                }
+            }
+        }
+        __syncthreads();
     }
+    if (!live) return;
     const float ck = t.ck[m];
     const int h = t.hpos[m];
 #pragma unroll
@@ -257,19 +312,23 @@ struct Horner<W, 0> {
 };
 
 template <int W, int P>
-__global__ __launch_bounds__(256) void fgt_predict_kernel(const float* __restrict__ qx, const float* __restrict__ qy,
+__global__ __launch_bounds__(64) void fgt_predict_kernel(const float* __restrict__ qx, const float* __restrict__ qy,
                                                           const float* __restrict__ qz, int nq, const float* __restrict__ xc,
                                                           const float* __restrict__ B, int K, int pd, int p_runtime, float inv_sigma,
                                                           float e_param, float* __restrict__ v)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // grid = (queries / 64, S): one wave per workgroup, and the cells are split S ways (partial sums, added in a fixed order by
+    // the post kernels), so that bunny-sized clouds still put several waves on every SIMD
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int S = gridDim.y, split = blockIdx.y;
+    const int k_begin = (int)((long long)K * split / S), k_end = (int)((long long)K * (split + 1) / S);
     const int ic = min(i, nq - 1);
     const float x = qx[ic], y = qy[ic], z = qz[ic];
     float cell[W];
 #pragma unroll
     for (int w = 0; w < W; w++) cell[w] = 0.f;
     const size_t wstride = (size_t)K * pd;
-    for (int k = 0; k < K; k++) {
+    for (int k = k_begin; k < k_end; k++) {
         const float dx = (x - xc[3 * k]) * inv_sigma, dy = (y - xc[3 * k + 1]) * inv_sigma, dz = (z - xc[3 * k + 2]) * inv_sigma;
         const float sum = len2(dx, dy, dz);
         if (sum > e_param) continue;                               // fgt.cpp:120 (a NaN cell is not skipped there either)
@@ -283,29 +342,35 @@ __global__ __launch_bounds__(256) void fgt_predict_kernel(const float* __restric
     }
     if (i < nq) {
 #pragma unroll
-        for (int w = 0; w < W; w++) v[(size_t)w * nq + i] = cell[w];
+        for (int w = 0; w < W; w++) v[((size_t)split * W + w) * nq + i] = cell[w];
     }
 }
 
-__global__ __launch_bounds__(256) void fgt_post_kt1_kernel(const float* __restrict__ kt1, const float* __restrict__ ax,
+__global__ __launch_bounds__(256) void fgt_post_kt1_kernel(const float* __restrict__ kt1_parts, int S, const float* __restrict__ ax,
                                                            const float* __restrict__ ay, const float* __restrict__ az, int n, float ndi,
                                                            float* __restrict__ pt1, float4* __restrict__ xw4)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float inv = 1.0f / (kt1[i] + ndi);                       // cpdutils.cpp:49
+    float kt1 = 0.f;
+    for (int sp = 0; sp < S; sp++) kt1 += kt1_parts[(size_t)sp * n + i];
+    const float inv = 1.0f / (kt1 + ndi);                          // cpdutils.cpp:49
     pt1[i] = 1.0f - ndi * inv;                                     // CalculatePt1, cpdutils.cpp:79-88
     xw4[i] = make_float4(ax[i] * inv, ay[i] * inv, az[i] * inv, inv);   // CalculateWeightsForPX :90-99; .w doubles as 1/denominator
 }
 
-__global__ __launch_bounds__(256) void fgt_post_px_kernel(const float* __restrict__ v, int m, float* __restrict__ p1, float* __restrict__ px)
+__global__ __launch_bounds__(256) void fgt_post_px_kernel(const float* __restrict__ v_parts, int S, int m, float* __restrict__ p1,
+                                                          float* __restrict__ px)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= m) return;
-    px[3 * (size_t)k] = v[k];
-    px[3 * (size_t)k + 1] = v[(size_t)m + k];
-    px[3 * (size_t)k + 2] = v[2 * (size_t)m + k];
-    p1[k] = v[3 * (size_t)m + k];
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < S; sp++)
+        for (int w = 0; w < 4; w++) a[w] += v_parts[((size_t)sp * 4 + w) * m + k];
+    px[3 * (size_t)k] = a[0];
+    px[3 * (size_t)k + 1] = a[1];
+    px[3 * (size_t)k + 2] = a[2];
+    p1[k] = a[3];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -328,9 +393,10 @@ hipError_t fgt_fill_iota(int* iota, int n, hipStream_t s)
 
 hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_bytes, hipStream_t s)
 {
-    if (c.n <= 4 * 1024) hipLaunchKernelGGL(fgt_kcenter_kernel<4>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, c.K, c.dist, c.indx);
-    else if (c.n <= 16 * 1024) hipLaunchKernelGGL(fgt_kcenter_kernel<16>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, c.K, c.dist, c.indx);
-    else hipLaunchKernelGGL(fgt_kcenter_kernel<0>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, c.K, c.dist, c.indx);
+    const int start = c.k_done > 0 && c.k_done < c.K ? c.k_done : 0;
+    if (c.n <= 4 * 1024) hipLaunchKernelGGL(fgt_kcenter_kernel<4>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, c.K, c.dist, c.indx);
+    else if (c.n <= 16 * 1024) hipLaunchKernelGGL(fgt_kcenter_kernel<16>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, c.K, c.dist, c.indx);
+    else hipLaunchKernelGGL(fgt_kcenter_kernel<0>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, c.K, c.dist, c.indx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     size_t temp = sort_temp_bytes;
@@ -338,42 +404,52 @@ hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_b
                                   (size_t)c.n, 0u, (unsigned)FGT_KEY_BITS, s, false);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fgt_offsets_kernel, dim3((c.K + 1 + 255) / 256), dim3(256), 0, s, c.keys_sorted, c.n, c.K, c.off);
-    hipLaunchKernelGGL(fgt_centers_kernel, dim3((c.K + 63) / 64), dim3(64), 0, s, c.x, c.y, c.z, c.memb, c.off, c.K, c.xc);
+    hipLaunchKernelGGL(fgt_centers_kernel, dim3(c.K), dim3(FGT_TILE), 0, s, c.x, c.y, c.z, c.memb, c.off, c.K, c.xc);
     return hipGetLastError();
 }
 
 hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const FgtTables& t, float* B, hipStream_t s)
 {
     const float inv = 1.0f / sigma;                                // fgt.cpp:260
-    const dim3 grid(c.K, (t.pd + 127) / 128);
-    if (w4) hipLaunchKernelGGL(fgt_model_kernel<4>, grid, dim3(128), 0, s, c, w4, inv, t, B);
-    else hipLaunchKernelGGL(fgt_model_kernel<1>, grid, dim3(128), 0, s, c, w4, inv, t, B);
+    const dim3 grid(c.K, (t.pd + FGT_TILE - 1) / FGT_TILE);
+    if (w4) hipLaunchKernelGGL(fgt_model_kernel<4>, grid, dim3(FGT_TILE), 0, s, c, w4, inv, t, B);
+    else hipLaunchKernelGGL(fgt_model_kernel<1>, grid, dim3(FGT_TILE), 0, s, c, w4, inv, t, B);
     return hipGetLastError();
 }
 
+// ways to split the cells of one transform: enough waves for ~4 per SIMD, at most 16 and at most one cell per split
+int fgt_predict_splits(int nq, int K)
+{
+    const int waves = (nq + 63) / 64;
+    int S = (4096 + waves - 1) / waves;
+    if (S > 16) S = 16;
+    if (S > K) S = K;
+    return S < 1 ? 1 : S;
+}
+
 hipError_t fgt_predict(const float* qx, const float* qy, const float* qz, int nq, const float* xc, const float* B, int K, int W,
-                       float sigma, float e_param, const FgtTables& t, float* v, hipStream_t s)
+                       float sigma, float e_param, const FgtTables& t, int S, float* v, hipStream_t s)
 {
     const float inv = 1.0f / sigma;                                // fgt.cpp:98
-    const dim3 grid((nq + 255) / 256);
+    const dim3 grid((nq + 63) / 64, S);
 #define MISLAM_PREDICT(WW, PP) \
-    hipLaunchKernelGGL((fgt_predict_kernel<WW, PP>), grid, dim3(256), 0, s, qx, qy, qz, nq, xc, B, K, t.pd, t.p, inv, e_param, v)
+    hipLaunchKernelGGL((fgt_predict_kernel<WW, PP>), grid, dim3(64), 0, s, qx, qy, qz, nq, xc, B, K, t.pd, t.p, inv, e_param, v)
     if (t.p == 8) { if (W == 4) MISLAM_PREDICT(4, 8); else MISLAM_PREDICT(1, 8); }
     else { if (W == 4) MISLAM_PREDICT(4, 0); else MISLAM_PREDICT(1, 0); }
 #undef MISLAM_PREDICT
     return hipGetLastError();
 }
 
-hipError_t fgt_post_kt1(const float* kt1, const float* ax, const float* ay, const float* az, int n, float ndi, float* pt1,
+hipError_t fgt_post_kt1(const float* kt1_parts, int S, const float* ax, const float* ay, const float* az, int n, float ndi, float* pt1,
                         float4* xw4, hipStream_t s)
 {
-    hipLaunchKernelGGL(fgt_post_kt1_kernel, dim3((n + 255) / 256), dim3(256), 0, s, kt1, ax, ay, az, n, ndi, pt1, xw4);
+    hipLaunchKernelGGL(fgt_post_kt1_kernel, dim3((n + 255) / 256), dim3(256), 0, s, kt1_parts, S, ax, ay, az, n, ndi, pt1, xw4);
     return hipGetLastError();
 }
 
-hipError_t fgt_post_px(const float* v, int m, float* p1, float* px, hipStream_t s)
+hipError_t fgt_post_px(const float* v_parts, int S, int m, float* p1, float* px, hipStream_t s)
 {
-    hipLaunchKernelGGL(fgt_post_px_kernel, dim3((m + 255) / 256), dim3(256), 0, s, v, m, p1, px);
+    hipLaunchKernelGGL(fgt_post_px_kernel, dim3((m + 255) / 256), dim3(256), 0, s, v_parts, S, m, p1, px);
     return hipGetLastError();
 }
 

@@ -159,6 +159,25 @@ def test_bunny_hybrid_run_matches_cpu_slam(ctx, capi, golden, bunny):
     assert err < 1e-3
 
 
+def test_resumed_clustering_changes_nothing(ctx, capi, golden, bunny, monkeypatch):
+    # the fixed cloud's K-centre sweep is resumed from one E-step to the next (K only grows as sigma^2 shrinks); switching that
+    # off re-clusters from scratch every time and must give the same bits
+    before, after = bunny
+    g = golden.json("bunny_fgt.json")
+    p = capi.cpd_params(max_iterations=50, sigma2_init=g["sigma2_init"], approximation=capi.CPD_APPROX_HYBRID)
+    a = ctx.cpd_register(before, after, p)
+    monkeypatch.setenv("MISLAM_FGT_RESUME", "0")
+    b = ctx.cpd_register(before, after, p)
+    assert a[3] == b[3] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[4] == b[4]
+    # full mode: sigma^2 (hence K) also moves down again once the clamp kicks in -- the sweep restarts there
+    monkeypatch.delenv("MISLAM_FGT_RESUME")
+    p = capi.cpd_params(max_iterations=24, sigma2_init=g["sigma2_init"], approximation=capi.CPD_APPROX_FULL)
+    a = ctx.cpd_register(before, after, p)
+    monkeypatch.setenv("MISLAM_FGT_RESUME", "0")
+    b = ctx.cpd_register(before, after, p)
+    assert a[3] == b[3] == 24 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[4] == b[4]
+
+
 @pytest.mark.parametrize("cap", [5, 17])
 def test_bunny_full_mode_capped_matches_cpu_slam(ctx, capi, golden, bunny, cap):
     before, after = bunny
