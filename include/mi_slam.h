@@ -204,7 +204,7 @@ int mi_transform_mse(mi_ctx* ctx, const float* src_xyz, int n, const float R9[9]
                      float* out_xyz, float* mse);
 
 /* ----------------------------------------------------------------------------------------------------------------
- * Rigid CPD with the exact Gaussian P ("approximation-type": "none") -- replaces GetCudaCpdTransformationMatrix
+ * Rigid CPD, "approximation-type" none (exact Gaussian P), full or hybrid -- replaces GetCudaCpdTransformationMatrix
  * (source/cuda-slam/cpdcuda.cuh:5-17, cpdcuda.cu:302-386); oracle CoherentPointDrift::GetRigidCPDTransformationMatrix
  * (source/cpu-slam/coherentpointdrift.cpp:69-124).  CPD naming follows the reference: M = |before| (index k),
  * N = |after| (index x).
