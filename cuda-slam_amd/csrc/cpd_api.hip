@@ -52,7 +52,8 @@ struct CpdWorkspace {
     DevBuf<double> part_x, part_k, part_init;
     CpdState* d_state = nullptr;
     CpdState* h_state = nullptr;
-    int m = 0, n = 0, m_pad = 0, n_pad = 0;
+    int m = 0, n = 0, m_pad = 0, n_pad = 0;   // n = this rank's share of the fixed cloud
+    int n_total = 0;                          // |after| over all ranks
     int k_chunks = 1, k_chunk_len = 0, x_chunks = 1, x_chunk_len = 0;
     mi_cpd_params params{};
 };
@@ -100,7 +101,7 @@ static int cpd_load(mi_ctx* c, CpdWorkspace* w, const float* before_xyz, int m, 
 {
     c->icp_loaded = false;   // the moving-cloud buffers are shared with the ICP driver
     w->fgt.a.swept_K = 0;    // a new fixed cloud: its clustering starts over
-    w->m = m; w->n = n;
+    w->m = m; w->n = n; w->n_total = n;
     w->m_pad = round_up_i(m, NN_SRC_PAD);
     w->n_pad = round_up_i(n, NN_SRC_PAD);
     const size_t mp = (size_t)w->m_pad, np = (size_t)w->n_pad;
@@ -155,7 +156,7 @@ static CpdRules cpd_rules(const CpdWorkspace* w, const mi_cpd_params* p)
     r.tolerance = p->tolerance;
     r.const_scale = p->const_scale;
     r.max_iterations = p->max_iterations;
-    r.m = w->m; r.n = w->n;
+    r.m = w->m; r.n = w->n_total;
     return r;
 }
 
@@ -181,7 +182,17 @@ static int cpd_mstep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const
     ProfScope ps(c, MI_KERNEL_CPD_MSTEP);
     MI_HIP(cpd_xsums(v, w->part_x.p, nxb, c->stream));
     MI_HIP(cpd_ksums(v, w->part_k.p, nkb, c->stream));
-    MI_HIP(cpd_solve(w->d_state, w->part_x.p, nxb, w->part_k.p, nkb, rules, update_loop_state, c->stream));
+    if (!c->comm) {
+        MI_HIP(cpd_solve(w->d_state, w->part_x.p, nxb, w->part_k.p, nkb, rules, update_loop_state, c->stream));
+        return MI_OK;
+    }
+    // Fixed cloud sharded over the ranks (C2): the x-sums cover this rank's fixed points, the k-sums are linear
+    // in this rank's share of P1/PX -- ONE all-reduce of the 24 doubles gives every rank the full moments; the per-point P1/PX
+    // never travel.  Every rank then runs the same solve.
+    static_assert(offsetof(CpdState, ks) == offsetof(CpdState, xs) + sizeof(double) * CPD_XSUMS, "xs and ks must be contiguous");
+    MI_HIP(cpd_reduce_sums(w->d_state, w->part_x.p, nxb, w->part_k.p, nkb, c->stream));
+    MI_NCCL(ncclAllReduce(w->d_state->xs, w->d_state->xs, (size_t)(CPD_XSUMS + CPD_KSUMS), ncclDouble, ncclSum, c->comm, c->stream));
+    MI_HIP(cpd_solve(w->d_state, nullptr, 0, nullptr, 0, rules, update_loop_state, c->stream));
     return MI_OK;
 }
 
@@ -196,7 +207,14 @@ static int cpd_init(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const CpdRules
 {
     const int nb = icp_reduce_blocks(std::max(w->m, w->n));
     MI_HIP(cpd_init_sums(v, w->part_init.p, nb, c->stream));
-    MI_HIP(cpd_init_state(w->d_state, w->part_init.p, nb, rules, sigma2_override, c->stream));
+    if (!c->comm) {
+        MI_HIP(cpd_init_state(w->d_state, w->part_init.p, nb, rules, sigma2_override, c->stream));
+        return MI_OK;
+    }
+    // sharded fixed cloud: its four sums (init[0..3]) are added over the ranks; the moving cloud's (init[4..7]) are replicated
+    MI_HIP(cpd_reduce_init(w->d_state, w->part_init.p, nb, c->stream));
+    MI_NCCL(ncclAllReduce(w->d_state->init, w->d_state->init, 4, ncclDouble, ncclSum, c->comm, c->stream));
+    MI_HIP(cpd_init_state(w->d_state, nullptr, 0, rules, sigma2_override, c->stream));
     return MI_OK;
 }
 
@@ -331,19 +349,24 @@ extern "C" void mi_cpd_params_default(mi_cpd_params* p)
     p->fgt_order_of_truncation = 8;          // "fgt-order-of-truncation"  configparser.cpp:264
 }
 
-static int cpd_check(mi_ctx* c, const float* b, int m, const float* a, int n)
+static int cpd_check(mi_ctx* c, const float* b, int m, const float* a, int n, bool allow_sharded = false)
 {
     if (!c) { set_error("CPD: null context"); return MI_ERR_INVALID_ARG; }
     if (!b || !a || m <= 0 || n <= 0) { set_error("CPD: empty or null cloud (m=%d, n=%d)", m, n); return MI_ERR_INVALID_ARG; }
-    if (c->world != 1) { set_error("CPD: multi-GPU contexts are not supported yet"); return MI_ERR_STATE; }
+    if (c->world != 1 && !allow_sharded) { set_error("CPD primitives run on single-GPU contexts (mi_cpd_register shards)"); return MI_ERR_STATE; }
     return MI_OK;
 }
 
 extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before, const float* after_xyz, int n_after,
                                const mi_cpd_params* params, float out_sR_t[16], float* out_scale, int* iterations, float* error)
 {
-    MI_TRY(cpd_check(c, before_xyz, m_before, after_xyz, n_after));
+    MI_TRY(cpd_check(c, before_xyz, m_before, after_xyz, n_after, true));
     if (!params || !out_sR_t || !iterations || !error) { set_error("mi_cpd_register: null argument"); return MI_ERR_INVALID_ARG; }
+    if (c->world > 1 && params->approximation != MI_CPD_APPROX_NONE) {
+        set_error("mi_cpd_register: the FGT modes run on single-GPU contexts (the exact P shards over the fixed cloud)");
+        return MI_ERR_STATE;
+    }
+    if (n_after < c->world) { set_error("mi_cpd_register: %d fixed points cannot be split over %d ranks", n_after, c->world); return MI_ERR_INVALID_ARG; }
     if (params->approximation < MI_CPD_APPROX_NONE || params->approximation > MI_CPD_APPROX_HYBRID) {
         set_error("mi_cpd_register: unknown approximation %d", params->approximation);
         return MI_ERR_INVALID_ARG;
@@ -357,7 +380,11 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
     CpdWorkspace* w = nullptr;
     MI_TRY(cpd_workspace(c, &w));
     w->params = *params;
-    MI_TRY(cpd_load(c, w, before_xyz, m_before, after_xyz, n_after));
+    // every rank is handed both clouds whole (as mi_icp_register) and keeps fixed points [lo, hi) -- mi_shard_range
+    int lo = 0, hi = n_after;
+    if (c->world > 1) (void)mi_shard_range(n_after, c->rank, c->world, &lo, &hi);
+    MI_TRY(cpd_load(c, w, before_xyz, m_before, after_xyz + 3 * (size_t)lo, hi - lo));
+    w->n_total = n_after;
     const CpdView v = cpd_view(c, w);
     const CpdRules rules = cpd_rules(w, params);
     MI_TRY(cpd_init(c, w, v, rules, params->sigma2_init));

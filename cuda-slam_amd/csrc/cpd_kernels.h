@@ -71,7 +71,10 @@ hipError_t cpd_contract(const CpdView& v, int use_mfma, hipStream_t s);         
 hipError_t cpd_post_contract(const CpdView& v, hipStream_t s);                                 //   P1, PX from chunk partials
 hipError_t cpd_xsums(const CpdView& v, double* partials, int nblocks, hipStream_t s);          // K8 part 1
 hipError_t cpd_ksums(const CpdView& v, double* partials, int nblocks, hipStream_t s);          // K8 part 2
+// multi-GPU: a rank's own sums into state->xs/ks resp. state->init (all-reduced there); cpd_solve / cpd_init_state then take
+// them from the state block when called with zero partial rows
 hipError_t cpd_reduce_sums(CpdState* state, const double* xpart, int nxb, const double* kpart, int nkb, hipStream_t s);
+hipError_t cpd_reduce_init(CpdState* state, const double* partials, int nblocks, hipStream_t s);
 hipError_t cpd_solve(CpdState* state, const double* xpart, int nxb, const double* kpart, int nkb, const CpdRules& rules,
                      int update_loop_state, hipStream_t s);                                    // K8 solve (+ EM bookkeeping)
 hipError_t cpd_transform(const CpdView& v, int m_pad, hipStream_t s);                          // y = s*R*b + t

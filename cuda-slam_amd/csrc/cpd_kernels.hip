@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256) void cpd_init_state_kernel(CpdState* __restric
 {
     __shared__ double lds[256];
     double s[CPD_INIT_SUMS];
-    reduce_partials<CPD_INIT_SUMS>(partials, nblocks, s, lds);
+    // nblocks == 0: the sums are already in st->init (multi-GPU: reduced by cpd_reduce_init_kernel, then all-reduced)
+    if (nblocks > 0) reduce_partials<CPD_INIT_SUMS>(partials, nblocks, s, lds);
+    else for (int i = 0; i < CPD_INIT_SUMS; i++) s[i] = st->init[i];
     if (threadIdx.x != 0) return;
     for (int i = 0; i < CPD_INIT_SUMS; i++) st->init[i] = s[i];
     const double M = rules.m, N = rules.n;
@@ -312,8 +314,14 @@ __global__ __launch_bounds__(256) void cpd_solve_kernel(CpdState* __restrict__ s
     if (st->done != 0) return;
     __shared__ double lds[256];
     double xs[CPD_XSUMS], ks[CPD_KSUMS];
-    reduce_partials<CPD_XSUMS>(xpart, nxb, xs, lds);
-    reduce_partials<CPD_KSUMS>(kpart, nkb, ks, lds);
+    // nxb == 0: the moments are already in st->xs / st->ks (multi-GPU: cpd_reduce_sums_kernel, then one all-reduce of both)
+    if (nxb > 0) {
+        reduce_partials<CPD_XSUMS>(xpart, nxb, xs, lds);
+        reduce_partials<CPD_KSUMS>(kpart, nkb, ks, lds);
+    } else {
+        for (int i = 0; i < CPD_XSUMS; i++) xs[i] = st->xs[i];
+        for (int i = 0; i < CPD_KSUMS; i++) ks[i] = st->ks[i];
+    }
     if (threadIdx.x != 0) return;
     for (int i = 0; i < CPD_XSUMS; i++) st->xs[i] = xs[i];
     for (int i = 0; i < CPD_KSUMS; i++) st->ks[i] = ks[i];
@@ -454,6 +462,41 @@ hipError_t cpd_solve(CpdState* state, const double* xpart, int nxb, const double
 hipError_t cpd_transform(const CpdView& v, int m_pad, hipStream_t s)
 {
     hipLaunchKernelGGL(cpd_transform_kernel, dim3((m_pad + 255) / 256), dim3(256), 0, s, v, m_pad);
+    return hipGetLastError();
+}
+
+// Multi-GPU: a rank's own sums land in the state block, where one in-stream all-reduce adds the ranks' shares
+__global__ __launch_bounds__(256) void cpd_reduce_sums_kernel(CpdState* __restrict__ st, const double* __restrict__ xpart, int nxb,
+                                                              const double* __restrict__ kpart, int nkb)
+{
+    if (st->done != 0) return;
+    __shared__ double lds[256];
+    double xs[CPD_XSUMS], ks[CPD_KSUMS];
+    reduce_partials<CPD_XSUMS>(xpart, nxb, xs, lds);
+    reduce_partials<CPD_KSUMS>(kpart, nkb, ks, lds);
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < CPD_XSUMS; i++) st->xs[i] = xs[i];
+    for (int i = 0; i < CPD_KSUMS; i++) st->ks[i] = ks[i];
+}
+
+__global__ __launch_bounds__(256) void cpd_reduce_init_kernel(CpdState* __restrict__ st, const double* __restrict__ partials, int nblocks)
+{
+    __shared__ double lds[256];
+    double s[CPD_INIT_SUMS];
+    reduce_partials<CPD_INIT_SUMS>(partials, nblocks, s, lds);
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < CPD_INIT_SUMS; i++) st->init[i] = s[i];
+}
+
+hipError_t cpd_reduce_sums(CpdState* state, const double* xpart, int nxb, const double* kpart, int nkb, hipStream_t s)
+{
+    hipLaunchKernelGGL(cpd_reduce_sums_kernel, dim3(1), dim3(256), 0, s, state, xpart, nxb, kpart, nkb);
+    return hipGetLastError();
+}
+
+hipError_t cpd_reduce_init(CpdState* state, const double* partials, int nblocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(cpd_reduce_init_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks);
     return hipGetLastError();
 }
 

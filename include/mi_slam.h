@@ -236,7 +236,10 @@ enum { MI_CPD_APPROX_NONE = 0, MI_CPD_APPROX_FULL = 1, MI_CPD_APPROX_HYBRID = 2 
 
 void mi_cpd_params_default(mi_cpd_params* p);
 
-/* out_sR_t: column-major 4x4 holding scale*R (cpdcuda.cu:360) and t; out_scale may be NULL. */
+/* out_sR_t: column-major 4x4 holding scale*R (cpdcuda.cu:360) and t; out_scale may be NULL.
+ * On a multi-GPU context (mi_ctx_create_dist) every rank passes both clouds whole and keeps fixed points mi_shard_range(n_after);
+ * one all-reduce of 24 doubles per EM iteration merges the M-step moments, every rank returns the same result.  The FGT modes
+ * (approximation != MI_CPD_APPROX_NONE) need a single-rank context. */
 int mi_cpd_register(mi_ctx* ctx, const float* before_xyz, int m_before, const float* after_xyz, int n_after,
                     const mi_cpd_params* params, float out_sR_t[16], float* out_scale, int* iterations, float* error);
 

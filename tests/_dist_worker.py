@@ -85,6 +85,49 @@ def main():
     dist.all_reduce(tse, op=dist.ReduceOp.SUM)
     assert abs(tse[0].item() - (dfull ** 2).sum()) < 1e-9 * max(1.0, (dfull ** 2).sum()) and tse[1].item() == kept.sum()
 
+    # C2 -- rigid CPD with the FIXED cloud sharded (mi_cpd_register on a multi-GPU context): rank r owns fixed points
+    # [N*r/W, N*(r+1)/W) and the whole moving cloud.  The denominators and Pt1 of its fixed points are local; its P1/PX hold only
+    # its fixed points' share, but the M-step moments are linear in them, so ONE sum all-reduce of 8 + 16 doubles (the x-sums
+    # and the k-sums, same layout as CpdState::xs/ks) reproduces the unsharded M-step.  Sigma^2_0 needs the fixed cloud's four
+    # sums added over the ranks (the moving cloud's are replicated).
+    y = (src * 0.9 + 0.2).astype(np.float32)        # "transformed" moving cloud
+    sigma2, weight = 1.7, 0.3
+    constant = O.cpd_constant(sigma2, weight, n, m)
+    lo, hi = capi.shard_range(m, rank, world)
+    p1, pt1, px, L = O.cpd_estep(y, tgt[lo:hi], constant, sigma2)       # this rank's share: sums over x in [lo, hi)
+    den_log = -(L - np.float32(3 * (hi - lo)) * np.log(np.float32(sigma2)) / np.float32(2.0))   # sum of log den over the shard
+    a64, b64 = tgt[lo:hi].astype(np.float64), src.astype(np.float64)
+    xs = np.zeros(8)
+    xs[0] = den_log
+    xs[1:4] = (a64 * pt1[:, None]).sum(0)
+    xs[4] = ((a64 ** 2) * pt1[:, None]).sum()
+    ks = np.zeros(16)
+    ks[0] = p1.astype(np.float64).sum()
+    ks[1:4] = (b64 * p1[:, None]).sum(0)
+    ks[4:13] = (b64[:, :, None] * px.astype(np.float64)[:, None, :]).sum(0).reshape(9)
+    ks[13] = ((b64 ** 2) * p1[:, None]).sum()
+    tc = torch.from_numpy(np.concatenate([xs, ks]))
+    dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+    f1, ft1, fx, fL = O.cpd_estep(y, tgt, constant, sigma2)             # unsharded
+    A64 = tgt.astype(np.float64)
+    want = np.zeros(24)
+    want[0] = -(fL - np.float32(3 * m) * np.log(np.float32(sigma2)) / np.float32(2.0))
+    want[1:4] = (A64 * ft1[:, None]).sum(0)
+    want[4] = ((A64 ** 2) * ft1[:, None]).sum()
+    want[8] = f1.astype(np.float64).sum()
+    want[9:12] = (b64 * f1[:, None]).sum(0)
+    want[12:21] = (b64[:, :, None] * fx.astype(np.float64)[:, None, :]).sum(0).reshape(9)
+    want[21] = ((b64 ** 2) * f1[:, None]).sum()
+    # the per-point P1/PX are fp32 sums in a different order when sharded: 1e-5 relative on the moments is their rounding
+    assert np.allclose(tc.numpy(), want, rtol=2e-5, atol=1e-4), (tc.numpy(), want)
+    assert np.array_equal(pt1, ft1[lo:hi])                              # Pt1 is shard-local, bit for bit
+    init = torch.tensor([*a64.sum(0), (a64 ** 2).sum()], dtype=torch.float64)
+    dist.all_reduce(init, op=dist.ReduceOp.SUM)
+    sb, sbb = b64.sum(0), (b64 ** 2).sum()
+    total = m * sbb + n * init[3].item() - 2.0 * float(init[:3].numpy() @ sb)
+    exact = ((b64[:, None, :] - A64[None, :, :]) ** 2).sum()
+    assert abs(total - exact) < 1e-9 * exact
+
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:

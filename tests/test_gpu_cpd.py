@@ -119,3 +119,23 @@ def test_cpd_loop_quirks(ctx, capi, bunny):
     assert it >= 1 and np.abs(sR - np.eye(3)).max() < 1e-2 and np.abs(t).max() < 1e-2
     with pytest.raises(capi.MiSlamError):
         ctx.cpd_register(before[:0], after, capi.cpd_params(max_iterations=3))
+
+
+def test_world1_rccl_context_runs_the_sharded_cpd_path(capi, golden, bunny):
+    # the multi-GPU CPD path (fixed cloud sharded, sigma^2_0 sums and the 24 M-step doubles all-reduced in-stream, solve from the
+    # state block) with one rank: same bits as the plain context; the FGT modes and the primitives stay single-GPU
+    before, after = bunny
+    g = golden.json("bunny_cpd.json")
+    uid = capi.dist_unique_id()
+    with capi.Context(0, 0, 1, uid) as dctx, capi.Context(0) as sctx:
+        for kw in (dict(max_iterations=50, sigma2_init=g["sigma2_init"]), dict(max_iterations=12), dict(max_iterations=9, const_scale=1)):
+            a = dctx.cpd_register(before, after, capi.cpd_params(**kw))
+            b = sctx.cpd_register(before, after, capi.cpd_params(**kw))
+            assert a[3] == b[3] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[4] == b[4], kw
+        a = dctx.cpd_register(before, after, capi.cpd_params(max_iterations=50, sigma2_init=g["sigma2_init"]))
+        f = g["final_scale_free"]
+        assert a[3] == f["iterations"] and frob(a[0], a[1], f["sR"], f["t"]) < 1e-4        # and it is cpu-slam's result
+        # the FGT modes are refused only when there really is more than one rank; with one they take the same M-step route
+        p = capi.cpd_params(max_iterations=20, sigma2_init=g["sigma2_init"], approximation=capi.CPD_APPROX_HYBRID)
+        a, b = dctx.cpd_register(before, after, p), sctx.cpd_register(before, after, p)
+        assert a[3] == b[3] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
