@@ -84,6 +84,38 @@ def cpu_baseline(np, before, after, target_seconds=15.0):
             "pairs_per_s": rows * m / dt}
 
 
+def cpd_bunny(np, capi, ctx, world):
+    """cfg 4 (bunny 14 904 x 14 904, cpd-weight .3, scale free) through mi_cpd_register: exact P, and hybrid where one rank runs."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    z = np.load(os.path.join(gold, "bunny_clouds.npz"))
+    g = json.load(open(os.path.join(gold, "bunny_cpd.json")))
+    before, after = z["before"], z["after"]
+    pairs = float(len(before)) * len(after)
+    out = {"workload": "cpd_bunny_14904", "n_gpus": world}
+    modes = [("exact", capi.CPD_APPROX_NONE)] + ([("hybrid", capi.CPD_APPROX_HYBRID)] if world == 1 else [])
+    for label, approx in modes:
+        p = capi.cpd_params(max_iterations=50, sigma2_init=g["sigma2_init"], approximation=approx)
+        ctx.cpd_register(before, after, p)                       # warm-up: allocations, code load
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        t0 = time.perf_counter()
+        sR, t, scale, it, err = ctx.cpd_register(before, after, p)
+        wall = time.perf_counter() - t0                          # host buffers in, result out: upload included
+        prof = {capi.KERNEL_NAMES[k]: ctx.profile_get(k) for k in range(len(capi.KERNEL_NAMES))}
+        ctx.profile_enable(False)
+        leg = {"iterations": it, "ms_total": wall * 1e3, "ms_per_em_iteration": wall * 1e3 / max(it, 1),
+               "kernels_ms_per_launch": {k: v[0] / v[1] for k, v in prof.items() if v[1] > 0}}
+        if label == "exact":
+            f = g["final_scale_free"]
+            leg["frobenius_vs_cpu_slam"] = float(np.sqrt(((sR - np.array(f["sR"])) ** 2).sum() + ((t - np.array(f["t"])) ** 2).sum()))
+            leg["iterations_cpu_slam"] = f["iterations"]
+            den = prof["cpd_denom"]
+            if den[1] > 0:
+                leg["estep_pairs_per_s"] = pairs / world / (den[0] / den[1] * 1e-3)   # K7a: this rank's share of the N*M affinities
+        out[label] = leg
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,6 +218,13 @@ def main():
         brute_prof = ctx.profile_get(capi.KERNEL_NN)
     ctx.profile_enable(False)
 
+    # Outside the timed region as well: the CPD leg of BASELINE.json's metric ("CPD E-step on bunny"), cfg 4 on the committed
+    # bunny clouds from cpu-slam's own sigma^2_0 -- exact P and the parser's default hybrid mode.  One GPU by default; with
+    # MISLAM_BENCH_CPD=1 also on N > 1 (fixed cloud sharded, one 24-double all-reduce per EM iteration).
+    cpd = None
+    if world == 1 or os.environ.get("MISLAM_BENCH_CPD") == "1":
+        cpd = cpd_bunny(np, capi, ctx, world)
+
     def nn_figures(nn_ms, nn_n, brute):
         nn_avg_s = nn_ms / max(nn_n, 1) * 1e-3
         alg_bytes = 20.0 * n_local + 12.0 * m_local    # this rank: 12 B source xyz + 8 B packed key per moving point, 12 B per fixed point
@@ -226,6 +265,8 @@ def main():
         }
         if brute_prof is not None:
             out["bruteforce_nn"] = nn_figures(brute_prof[0], brute_prof[1], True)
+        if cpd is not None:
+            out["cpd_bunny"] = cpd
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, before, after)
         print(json.dumps(out), flush=True)
