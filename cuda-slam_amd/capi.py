@@ -32,7 +32,7 @@ EXPORTS = [
     "mi_ctx_rank", "mi_shard_range", "mi_pack_key", "mi_unpack_key", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_icp_params_default", "mi_icp_params_cuda_slam",
     "mi_icp_register", "mi_icp_load", "mi_icp_reset", "mi_icp_run", "mi_icp_result", "mi_nn_search", "mi_nn_search_ex", "mi_kabsch",
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_estep",
-    "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_tables",
+    "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
     "mi_cpd_mstep", "mi_profile_enable", "mi_profile_reset", "mi_profile_get",
 ]
 
@@ -49,6 +49,11 @@ class CpdParams(C.Structure):
                 ("tolerance", C.c_float), ("sigma2_init", C.c_float), ("sync_every", C.c_int), ("verbose", C.c_int),
                 ("approximation", C.c_int), ("fgt_ratio_of_far_field", C.c_float), ("fgt_order_of_truncation", C.c_int),
                 ("reserved", C.c_int * 5)]
+
+
+class NicpParams(C.Structure):
+    _fields_ = [("eps", C.c_float), ("max_repetitions", C.c_int), ("approximation", C.c_int), ("verbose", C.c_int),
+                ("reserved", C.c_int * 4)]
 
 
 class MiSlamError(RuntimeError):
@@ -115,6 +120,17 @@ def icp_params(cuda_slam=False, **kw):
 def cpd_params(**kw):
     p = CpdParams()
     lib().mi_cpd_params_default(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def nicp_params(**kw):
+    p = NicpParams()
+    lib().mi_nicp_params_default.restype = None
+    lib().mi_nicp_params_default(C.byref(p))
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)
@@ -331,6 +347,25 @@ class Context:
         _check(lib().mi_cpd_mstep(self._h, _fp(before), before.shape[0], _fp(after), after.shape[0], _fp(p1), _fp(pt1), _fp(px),
                                   1 if const_scale else 0, R9, t3, C.byref(s), C.byref(s2)))
         return np.array(R9, np.float32).reshape(3, 3).T.copy(), np.array(t3, np.float32), s.value, s2.value
+
+    # ---- NICP
+    def nicp_register(self, before, after, params, order_heads, subcloud_idx=None):
+        """order_heads: [repetitions, 3] int32 (first three entries of each repetition's permutation); subcloud_idx None = whole cloud."""
+        before, after = _cloud(before), _cloud(after)
+        heads = np.ascontiguousarray(order_heads, np.int32)
+        reps = 20 if params.max_repetitions == -1 else params.max_repetitions
+        if heads.shape != (reps, 3):
+            raise ValueError("order_heads must be [%d, 3]" % reps)
+        if subcloud_idx is not None:
+            subcloud_idx = np.ascontiguousarray(subcloud_idx, np.int32)
+        sn = before.shape[0] if subcloud_idx is None else len(subcloud_idx)
+        T = (C.c_float * 16)()
+        it, err = C.c_int(0), C.c_float(0)
+        _check(lib().mi_nicp_register(self._h, _fp(before), before.shape[0], _fp(after), after.shape[0], C.byref(params),
+                                      heads.ctypes.data_as(_i), subcloud_idx.ctypes.data_as(_i) if subcloud_idx is not None else None,
+                                      sn, T, C.byref(it), C.byref(err)))
+        R, t = _T_to_Rt(T)
+        return R, t, it.value, err.value
 
     # ---- profiling
     def profile_enable(self, on=True):

@@ -147,5 +147,10 @@ size_t target_alloc_len(int m_local);
 
 // Upload an AoS host cloud into SoA device arrays of n_pad entries (tail = copies of the last point).
 int upload_soa(mi_ctx* ctx, const float* host_aos, int n, int n_pad, float* x, float* y, float* z, float4* packed);
+// Uploads this rank's shard of the fixed cloud (SoA streams for K1 + float4 for gathers); invalidates the box hierarchy.
+int upload_target_shard(mi_ctx* ctx, const float* after_xyz, int m_total, bool replicate = false);
+// Correspondence search of n moving points (SoA, padded) against the loaded fixed-cloud shard into ctx->keys (K1 or K1t).
+int launch_nn(mi_ctx* ctx, const float* sx, const float* sy, const float* sz, int n, int m_local, int index_base, int fma,
+              const int* done_flag, int nn_mode);
 
 }  // namespace mislam

@@ -353,8 +353,8 @@ static int resolve_nn_mode(int nn_mode, int m_local)
     return m_local >= 32768 ? MI_NN_TREE : MI_NN_BRUTEFORCE;
 }
 
-static int launch_nn(mi_ctx* c, const float* sx, const float* sy, const float* sz, int n, int m_local, int index_base, int fma,
-                     const int* done_flag, int nn_mode)
+int mislam::launch_nn(mi_ctx* c, const float* sx, const float* sy, const float* sz, int n, int m_local, int index_base, int fma,
+                      const int* done_flag, int nn_mode)
 {
     if (resolve_nn_mode(nn_mode, m_local) == MI_NN_TREE) {
         MI_TRY(ensure_tree(c, m_local, index_base));
@@ -400,7 +400,7 @@ static int allreduce_doubles(mi_ctx* c, double* dev_ptr, int count)
 static void shard_range(int m_total, int rank, int world, int* lo, int* hi) { (void)mi_shard_range(m_total, rank, world, lo, hi); }
 
 // Uploads this rank's shard of the fixed cloud (SoA streams for K1 + float4 for gathers).
-static int upload_target_shard(mi_ctx* c, const float* after_xyz, int m_total, bool replicate = false)
+int mislam::upload_target_shard(mi_ctx* c, const float* after_xyz, int m_total, bool replicate)
 {
     c->m_total = m_total;
     c->tree_valid = false;   // the hierarchy indexes the previous shard

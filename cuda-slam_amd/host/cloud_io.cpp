@@ -197,4 +197,6 @@ std::pair<CpuCloud, CpuCloud> GetCloudsFromConfig(const Configuration& config)
     return {before, after};
 }
 
+std::vector<int> GetRandomPermutationVector(int size) { return random_permutation(size); }
+
 }  // namespace Common

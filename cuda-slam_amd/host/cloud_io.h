@@ -3,6 +3,7 @@
 #pragma once
 #include <string>
 #include <utility>
+#include <vector>
 
 #include "configuration.h"
 #include "slam_types.h"
@@ -20,5 +21,9 @@ CpuCloud GetTransformedCloud(const CpuCloud& cloud, const Mat3& R, const Vec3& t
 // Load, optional resize, normalise to "cloud-spread", shuffle with mt19937("random-seed"), optional noise / outliers,
 // apply the configured transform to `after` (common.cpp:134-210).  Returns (before, after).
 std::pair<CpuCloud, CpuCloud> GetCloudsFromConfig(const Configuration& config);
+
+// iota + std::shuffle on the program's generator (the one "random-seed" seeds and the cloud stage has already drawn from), as
+// Common::GetRandomPermutationVector does on Common::mtRandom (common.cpp:554-560)
+std::vector<int> GetRandomPermutationVector(int size);
 
 }  // namespace Common

@@ -4,7 +4,10 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <algorithm>
+
 #include "../../include/mi_slam.h"
+#include "cloud_io.h"
 
 using namespace Common;
 
@@ -93,6 +96,42 @@ std::pair<Mat3, Vec3> GetCudaCpdTransformationMatrix(const std::vector<Point_f>&
     return split(T);
 }
 
+std::pair<Mat3, Vec3> GetCudaNicpTransformationMatrix(const std::vector<Point_f>& before, const std::vector<Point_f>& after, float eps,
+                                                     int maxRepetitions, int batchSize, ApproximationType approximationType,
+                                                     const int subcloudSize, int* repetitions, float* error)
+{
+    (void)batchSize;
+    mi_nicp_params p;
+    mi_nicp_params_default(&p);
+    p.eps = eps;
+    p.max_repetitions = maxRepetitions;
+    p.approximation = approximationType == ApproximationType::Full ? MI_CPD_APPROX_FULL
+                    : approximationType == ApproximationType::Hybrid ? MI_CPD_APPROX_HYBRID : MI_CPD_APPROX_NONE;
+    p.verbose = 1;
+    // The random draws, in the reference's order (noniterative.cpp:213-222): first the comparison subcloud -- a permutation of
+    // |before| cut to subcloudSize, or nothing at all when the subcloud is the whole cloud (common.cpp:25-37) -- then one
+    // permutation of min(|before|, |after|) per repetition, of which the registration needs the first three entries only.
+    std::vector<int> subcloud;
+    if (subcloudSize < (int)before.size()) {
+        subcloud = GetRandomPermutationVector((int)before.size());
+        subcloud.resize((size_t)std::max(subcloudSize, 0));
+    }
+    const int reps = maxRepetitions == -1 ? 20 : std::max(maxRepetitions, 0);
+    const int size = (int)std::min(before.size(), after.size());
+    std::vector<int> heads(3 * (size_t)reps);
+    for (int r = 0; r < reps; r++) {
+        const std::vector<int> perm = GetRandomPermutationVector(size);
+        for (int k = 0; k < 3 && k < size; k++) heads[3 * (size_t)r + k] = perm[(size_t)k];
+    }
+    float T[16];
+    check(mi_nicp_register(context(), reinterpret_cast<const float*>(before.data()), (int)before.size(),
+                           reinterpret_cast<const float*>(after.data()), (int)after.size(), &p, heads.data(),
+                           subcloud.empty() ? nullptr : subcloud.data(), subcloud.empty() ? (int)before.size() : (int)subcloud.size(), T,
+                           repetitions, error),
+          "mi_nicp_register");
+    return split(T);
+}
+
 std::pair<Mat3, Vec3> GetGpuSlamResult(const CpuCloud& before, const CpuCloud& after, Configuration configuration, int* iterations,
                                       float* error)
 {
@@ -104,8 +143,9 @@ std::pair<Mat3, Vec3> GetGpuSlamResult(const CpuCloud& before, const CpuCloud& a
                                               configuration.ApproximationType_, iterations, error, configuration.RatioOfFarField,
                                               (float)configuration.OrderOfTruncation);
     case ComputationMethod::NoniterativeIcp:
-        fprintf(stderr, "method nicp is outside the accelerated path of this build (icp and cpd are)\n");
-        exit(EXIT_FAILURE);
+        return GetCudaNicpTransformationMatrix(before, after, configuration.ConvergenceEpsilon, configuration.NicpIterations,
+                                               configuration.NicpBatchSize, configuration.ApproximationType_,
+                                               configuration.NicpSubcloudSize, iterations, error);
     case ComputationMethod::Icp:
     default:
         return GetCudaIcpTransformationMatrix(before, after, configuration.ConvergenceEpsilon, maxIterations, iterations, error);

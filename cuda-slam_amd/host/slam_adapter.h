@@ -35,5 +35,12 @@ std::pair<Common::Mat3, Common::Vec3> GetCudaCpdTransformationMatrix(const std::
                                                                     Common::ApproximationType fgt, int* iterations, float* error,
                                                                     const float& ratioOfFarField, const float& orderOfTruncation);
 
+// nicpcuda.cuh:5-15.  batchSize only shapes the reference's thread batches; the sequential policy's semantics apply here.
+std::pair<Common::Mat3, Common::Vec3> GetCudaNicpTransformationMatrix(const std::vector<Common::Point_f>& before,
+                                                                     const std::vector<Common::Point_f>& after, float eps,
+                                                                     int maxRepetitions, int batchSize,
+                                                                     Common::ApproximationType approximationType, const int subcloudSize,
+                                                                     int* repetitions, float* error);
+
 std::pair<Common::Mat3, Common::Vec3> GetGpuSlamResult(const Common::CpuCloud& before, const Common::CpuCloud& after,
                                                       Common::Configuration configuration, int* iterations, float* error);

@@ -279,6 +279,36 @@ int mi_cpd_mstep(mi_ctx* ctx, const float* before_xyz, int m, const float* after
                  float* sigma2);
 
 /* ----------------------------------------------------------------------------------------------------------------
+ * Non-iterative registration, "method": "nicp" -- replaces GetCudaNicpTransformationMatrix (source/cuda-slam/nicpcuda.cuh:5-15,
+ * nicpcuda.cu:70-184); oracle NonIterative::GetNonIterativeTransformationMatrix with the sequential policy
+ * (source/cpu-slam/noniterative.cpp:204-282; the parallel policy races on the shared random generator, :84-101).
+ * Each repetition aligns the principal axes of the two clouds, U_after * U_before^T, with the column signs an Eigen::JacobiSVD
+ * of the randomly permuted 3 x N matrices would produce (they depend on the first three points only -- nicp_api.hip), and
+ * the candidate with the smallest error wins:
+ *   MI_CPD_APPROX_NONE    every candidate is scored on the comparison subcloud (exact nearest neighbours), early exit at eps;
+ *   MI_CPD_APPROX_FULL    candidates ranked by the index-wise "approximated" error, the best one scored on the subcloud;
+ *   MI_CPD_APPROX_HYBRID  the best five are scored on the subcloud (the parser's default).
+ * The random choices stay with the caller, who draws them like the reference (std::mt19937 + std::shuffle,
+ * GetRandomPermutationVector, common.cpp:554-560): order_heads[3*r .. 3*r+2] are the first three entries of repetition r's
+ * permutation of 0..min(m,n)-1 (max_repetitions of them; -1 means 20), subcloud_idx the first subcloud_n entries of the
+ * permutation GetSubcloud draws BEFORE them (common.cpp:25-37), or NULL with subcloud_n = m_before for the whole cloud.
+ * -------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    float eps;              /* "convergence-epsilon" */
+    int   max_repetitions;  /* "nicp-iterations" (default 32); -1 = 20 (noniterative.cpp:207-208) */
+    int   approximation;    /* MI_CPD_APPROX_* ("approximation-type") */
+    int   verbose;
+    int   reserved[4];
+} mi_nicp_params;
+
+void mi_nicp_params_default(mi_nicp_params* p);
+
+/* out_T: column-major 4x4 (R | t).  *repetitions and *error as the reference leaves them. */
+int mi_nicp_register(mi_ctx* ctx, const float* before_xyz, int m_before, const float* after_xyz, int n_after,
+                     const mi_nicp_params* params, const int* order_heads, const int* subcloud_idx, int subcloud_n,
+                     float out_T[16], int* repetitions, float* error);
+
+/* ----------------------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): per-kernel HIP-event timing on the context's own stream.
  * -------------------------------------------------------------------------------------------------------------- */
 enum {

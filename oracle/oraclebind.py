@@ -192,6 +192,34 @@ def cpd(before, after, eps=1e-3, weight=0.3, const_scale=False, max_iterations=5
     return out
 
 
+# ---- non-iterative registration (oracle/nicp_oracle.c) ----
+def nicp_single(before, after):
+    before, after = _cloud(before), _cloud(after)
+    r = np.empty(9, np.float32)
+    t = np.empty(3, np.float32)
+    e = C.c_float(0)
+    lib().oracle_nicp_single(_fp(before), before.shape[0], _fp(after), after.shape[0], _fp(r), _fp(t), C.byref(e))
+    return _from_col9(r), t, e.value
+
+
+def nicp(before, after, perms, subcloud_idx=None, eps=1e-3, max_repetitions=20, approximation=0):
+    """perms: [max_repetitions, min(m, n)] int32, one permutation per repetition; subcloud_idx None = the whole cloud."""
+    before, after = _cloud(before), _cloud(after)
+    perms = np.ascontiguousarray(perms, np.int32)
+    assert perms.shape == (max_repetitions, min(len(before), len(after)))
+    if subcloud_idx is not None:
+        subcloud_idx = np.ascontiguousarray(subcloud_idx, np.int32)
+    sn = len(before) if subcloud_idx is None else len(subcloud_idx)
+    r = np.empty(9, np.float32)
+    t = np.empty(3, np.float32)
+    reps = C.c_int(0)
+    err = C.c_float(0)
+    lib().oracle_nicp(_fp(before), before.shape[0], _fp(after), after.shape[0], C.c_float(eps), max_repetitions, approximation,
+                      _ip(subcloud_idx) if subcloud_idx is not None else None, sn, _ip(perms), _fp(r), _fp(t), C.byref(reps),
+                      C.byref(err))
+    return _from_col9(r), t, reps.value, err.value
+
+
 # ---- Fast Gauss Transform E-step and the full / hybrid drivers (oracle/fgt_oracle.c) ----
 APPROX_NONE, APPROX_FULL, APPROX_HYBRID = 0, 1, 2
 

@@ -18,6 +18,8 @@
 #include "cpdutils.h"
 #include "fgt.h"
 #include "fgt_model.h"
+#include "noniterative.h"
+#include "nicputils.h"
 
 using Common::Point_f;
 
@@ -246,4 +248,40 @@ REF_API void ref_fgt_predict(const float* cloud_xyz, int n, const float* xc, con
     model.Ak = Eigen::Map<const Eigen::MatrixXf>(ak, pd, K);
     auto v = FastGaussTransform::ComputeFGTPredict(to_cloud(cloud_xyz, n), model, sigma, e_param, K, p);
     std::memcpy(v_out, v.data(), sizeof(float) * n);
+}
+
+// NonIterative::GetSingleNonIterativeSlamResult  cpu-slam/noniterative.cpp:25-55 (one PCA alignment of two equally ordered clouds)
+REF_API void ref_nicp_single(const float* before_xyz, int m, const float* after_xyz, int n, float* rot9_colmajor, float* trans3,
+                             float* approximated_error)
+{
+    auto r = NonIterative::GetSingleNonIterativeSlamResult(to_cloud(before_xyz, m), to_cloud(after_xyz, n));
+    from_mat3(r.getRotationMatrix(), rot9_colmajor);
+    const glm::vec3 t = r.getTranslationVector();
+    trans3[0] = t.x; trans3[1] = t.y; trans3[2] = t.z;
+    *approximated_error = r.getApproximatedError();
+}
+
+// NonIterative::GetNonIterativeTransformationMatrix  cpu-slam/noniterative.cpp:284-290, after seeding Common::mtRandom the way
+// clouds-from-config does (common.cpp:136-137).  approximation: 0 none, 1 full, 2 hybrid.  parallel = 0: the sequential policy
+// (:204-282), the only deterministic one (the parallel policy's threads race on the shared generator).
+REF_API void ref_nicp(const float* before_xyz, int m, const float* after_xyz, int n, float eps, int max_repetitions,
+                      int approximation, int parallel, int subcloud_size, unsigned seed, float* rot9_colmajor, float* trans3,
+                      int* repetitions, float* error)
+{
+    Common::mtRandom = std::mt19937{ seed };
+    auto r = NonIterative::GetNonIterativeTransformationMatrix(to_cloud(before_xyz, m), to_cloud(after_xyz, n), repetitions, error,
+                                                               eps, max_repetitions, static_cast<Common::ApproximationType>(approximation),
+                                                               parallel != 0, subcloud_size);
+    from_mat3(r.first, rot9_colmajor);
+    trans3[0] = r.second.x; trans3[1] = r.second.y; trans3[2] = r.second.z;
+}
+
+// Common::GetRandomPermutationVector  common.cpp:554-560 from a freshly seeded generator; `skip` permutations of the same size
+// are drawn and dropped first (the driver draws one for the subcloud before the repetitions start).
+REF_API void ref_random_permutation(unsigned seed, int size, int skip, int* out)
+{
+    Common::mtRandom = std::mt19937{ seed };
+    for (int i = 0; i < skip; i++) (void)Common::GetRandomPermutationVector(size);
+    auto p = Common::GetRandomPermutationVector(size);
+    std::memcpy(out, p.data(), sizeof(int) * size);
 }

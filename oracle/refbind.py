@@ -199,3 +199,29 @@ def fgt_predict(cloud, xc, ak, sigma, e_param, p):
     v = np.empty(cloud.shape[0], np.float32)
     lib().ref_fgt_predict(_fp(cloud), cloud.shape[0], _fp(xc), _fp(ak), pd, C.c_float(sigma), C.c_float(e_param), K, p, _fp(v))
     return v
+
+
+def nicp_single(before, after):
+    before, after = _cloud(before), _cloud(after)
+    r = np.empty(9, np.float32)
+    t = np.empty(3, np.float32)
+    e = C.c_float(0)
+    lib().ref_nicp_single(_fp(before), before.shape[0], _fp(after), after.shape[0], _fp(r), _fp(t), C.byref(e))
+    return r.reshape(3, 3).T.copy(), t, e.value
+
+
+def nicp(before, after, eps=1e-3, max_repetitions=20, approximation=0, parallel=False, subcloud_size=1000, seed=666):
+    before, after = _cloud(before), _cloud(after)
+    r = np.empty(9, np.float32)
+    t = np.empty(3, np.float32)
+    reps = C.c_int(0)
+    err = C.c_float(0)
+    lib().ref_nicp(_fp(before), before.shape[0], _fp(after), after.shape[0], C.c_float(eps), max_repetitions, approximation,
+                   1 if parallel else 0, subcloud_size, C.c_uint(seed), _fp(r), _fp(t), C.byref(reps), C.byref(err))
+    return r.reshape(3, 3).T.copy(), t, reps.value, err.value
+
+
+def random_permutation(seed, size, skip=0):
+    out = np.empty(size, np.int32)
+    lib().ref_random_permutation(C.c_uint(seed), size, skip, out.ctypes.data_as(C.POINTER(C.c_int)))
+    return out

@@ -82,6 +82,14 @@ void  oracle_cpd_approx(const float* before, int m, const float* after, int n, c
                         float ratio_of_far_field, float order_of_truncation, float rot9[9], float trans3[3], int* iterations,
                         float* error, float* trace, int trace_cap, int* trace_len);
 
+/* ---- non-iterative registration, "method": "nicp" (oracle/nicp_oracle.c) ---- */
+void  oracle_nicp_single(const float* before, int m, const float* after, int n, float rot9[9], float trans3[3],
+                         float* approximated_error);
+/* perms: max_repetitions permutations of 0..min(m,n)-1; subcloud_idx NULL = the whole cloud.  approximation: 0 none, 1 full, 2 hybrid. */
+void  oracle_nicp(const float* before, int m, const float* after, int n, float eps, int max_repetitions, int approximation,
+                  const int* subcloud_idx, int subcloud_n, const int* perms, float rot9[9], float trans3[3], int* repetitions,
+                  float* error);
+
 #ifdef __cplusplus
 }
 #endif
