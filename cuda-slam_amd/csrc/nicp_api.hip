@@ -345,12 +345,15 @@ extern "C" int mi_nicp_register(mi_ctx* c, const float* before_xyz, int m_before
     MI_TRY(upload_soa(c, sub.data(), sn, sn_pad, c->bx.p, c->by.p, c->bz.p, nullptr));
     const int eb = icp_reduce_blocks(sn);
     std::vector<double> epart((size_t)eb * 2);
+    // A thousand cold queries are too few to hide the box hierarchy's dependent loads (1.5 ms against 10^6 fixed points); the
+    // every-pair kernel does the same 10^9 pairs in 0.2 ms.  Same neighbours either way.
+    const int nn_mode = (double)sn * (double)n_after < 4e9 ? MI_NN_BRUTEFORCE : MI_NN_AUTO;
     // error of one candidate on the subcloud: transform, exact nearest neighbours in `after`, mean squared distance (:226-230)
     auto exact_error = [&](const Rt& rt, float* out) -> int {
         hipLaunchKernelGGL(nicp_transform_kernel, dim3((sn_pad + 255) / 256), dim3(256), 0, c->stream, c->bx.p, c->by.p, c->bz.p, sn_pad, rt,
                            c->cx.p, c->cy.p, c->cz.p);
         MI_HIP(fill_keys(c->keys.p, sn, c->stream));
-        MI_TRY(launch_nn(c, c->cx.p, c->cy.p, c->cz.p, sn, n_after, 0, 0, nullptr, MI_NN_AUTO));
+        MI_TRY(launch_nn(c, c->cx.p, c->cy.p, c->cz.p, sn, n_after, 0, 0, nullptr, nn_mode));
         hipLaunchKernelGGL(nicp_error_kernel, dim3(eb), dim3(256), 0, c->stream, c->keys.p, sn, 1e6f, c->part_err.p);   // maxDistanceForComparison, :216
         MI_HIP(hipGetLastError());
         MI_HIP(hipMemcpyAsync(epart.data(), c->part_err.p, sizeof(double) * epart.size(), hipMemcpyDeviceToHost, c->stream));

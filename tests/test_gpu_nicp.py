@@ -79,13 +79,15 @@ def test_unequal_sizes_and_default_repetitions(ctx, capi, oracle):
 
 
 def test_large_cloud_uses_the_box_hierarchy_for_the_error(ctx, capi, oracle):
-    # 60 000 fixed points: MI_NN_AUTO scores the subcloud through K1t; same exact neighbours, same error
-    b, a, R0, t0 = rigid_pair(12, 60000, 0.002)
-    perms, sub = draws(3, len(b), 4, 2000)
-    p = capi.nicp_params(eps=1e-9, max_repetitions=4, approximation=0)
+    # small subclouds are scored by the every-pair kernel; from 4e9 pairs on (here the whole 70 000-point cloud against itself)
+    # the box hierarchy takes over: same exact neighbours, same error
+    b, a, R0, t0 = rigid_pair(12, 70000, 0.002)
+    perms, sub = draws(3, len(b), 2, len(b))
+    assert sub is None
+    p = capi.nicp_params(eps=1e-9, max_repetitions=2, approximation=0)
     R, t, nr, err = ctx.nicp_register(b, a, p, perms[:, :3], sub)
-    Ro, to, no, eo = oracle.nicp(b, a, perms, sub, 1e-9, 4, 0)
-    assert nr == no == 4 and frob(R, t, Ro, to) < 1e-4 and abs(err - eo) < 2e-4 * eo
+    Ro, to, no, eo = oracle.nicp(b, a, perms, sub, 1e-9, 2, 0)
+    assert nr == no == 2 and frob(R, t, Ro, to) < 1e-4 and abs(err - eo) < 2e-4 * eo
 
 
 def test_rejects_bad_arguments(ctx, capi):
