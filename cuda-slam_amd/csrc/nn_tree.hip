@@ -394,29 +394,19 @@ __global__ __launch_bounds__(256) void nn_tree_lane_kernel(const float4* __restr
     int node = 0;
     const float root_lb = box_bound<FMA>(tree_boxes[0], tree_boxes[1], p, p);
     bool have = root_lb <= best && root_lb < __builtin_inff();
-    while (true) {
-        if (!have) {
-            bool found = false;
-            while (sp > 0) {
-                sp--;
-                const float lb = st_lb[sp * 256 + threadIdx.x];
-                if (lb <= best) { node = st_node[sp * 256 + threadIdx.x]; found = true; break; }
-            }
-            if (!found) break;
-        }
+    // next pending subtree that can still matter (deepest first), or have = false when the stack runs dry
+    auto pop = [&]() {
         have = false;
-        if (node >= first_leaf) {
-            const float4* __restrict__ lp = tree_pts + (size_t)(node - first_leaf) * TREE_LEAF;
-#pragma unroll
-            for (int k = 0; k < TREE_LEAF; k++) {
-                const float4 q = lp[k];
-                const float d = sq3<FMA>(q.x - p[0], q.y - p[1], q.z - p[2]);
-                const unsigned int j = (unsigned int)__float_as_int(q.w);
-                const bool better = (d < best) | ((d == best) & (j < bidx));
-                best = better ? d : best;
-                bidx = better ? j : bidx;
-            }
-        } else {
+        while (sp > 0) {
+            sp--;
+            const float lb = st_lb[sp * 256 + threadIdx.x];
+            if (lb <= best) { node = st_node[sp * 256 + threadIdx.x]; have = true; break; }
+        }
+    };
+    // "while-while" traversal: every lane first descends to its next leaf, THEN the wave scans leaves together.  With one
+    // node-or-leaf step per trip the two bodies ran back to back under complementary masks on almost every trip.
+    while (have) {
+        while (have && node < first_leaf) {
             const int l = 2 * node + 1;
             const float4* __restrict__ rec = tree_boxes + 2 * (size_t)l;
             const float lbl = box_bound<FMA>(rec[0], rec[1], p, p);
@@ -429,8 +419,21 @@ __global__ __launch_bounds__(256) void nn_tree_lane_kernel(const float4* __restr
                 st_lb[sp * 256 + threadIdx.x] = lbf;
                 sp++;
             }
-            if (lbn <= best && lbn < __builtin_inff()) { node = near; have = true; }
+            if (lbn <= best && lbn < __builtin_inff()) node = near;
+            else pop();
         }
+        if (!have) break;
+        const float4* __restrict__ lp = tree_pts + (size_t)(node - first_leaf) * TREE_LEAF;
+#pragma unroll
+        for (int k = 0; k < TREE_LEAF; k++) {
+            const float4 q = lp[k];
+            const float d = sq3<FMA>(q.x - p[0], q.y - p[1], q.z - p[2]);
+            const unsigned int j = (unsigned int)__float_as_int(q.w);
+            const bool better = (d < best) | ((d == best) & (j < bidx));
+            best = better ? d : best;
+            bidx = better ? j : bidx;
+        }
+        pop();
     }
     if (best < __builtin_inff()) keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
 }
