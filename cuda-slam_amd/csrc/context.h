@@ -102,6 +102,8 @@ struct mi_ctx {
     mislam::DevBuf<float> tbbox;
     mislam::DevBuf<unsigned char> tsort_temp;
     mislam::DevBuf<float4> tpts, tboxes;
+    mislam::DevBuf<float4> tpairs, tleaf;                // compact copies for the per-lane walk (NnTreeView)
+    mislam::DevBuf<int> tidx;
     mislam::NnTreeView tree{};
     bool tree_valid = false;
     mislam::DevBuf<int> sorder;                          // Morton order of the moving cloud (sorted slot -> caller's index)

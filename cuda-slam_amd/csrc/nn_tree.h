@@ -8,7 +8,8 @@ namespace mislam {
 #define MISLAM_TREE_LEAF 16
 #endif
 // points per leaf.  Measured on MI355X (N = M = 1e6, ms per search early / near convergence; 1e7 early):
-//   4: 2.03 / 1.17 / 36.8    8: 1.84 / 1.08 / 33.3    16: 1.68 / 1.04 / 30.0    32: 1.62 / 1.06 / 28.0
+//   float4 leaves, 64-byte node records:  4: 2.03 / 1.17 / 36.8    8: 1.84 / 1.08 / 33.3    16: 1.68 / 1.04 / 30.0    32: 1.62 / 1.06 / 28.0
+//   compact copies (the default walk):    8: 1.50 / 0.92 / 27.6    16: 1.35 / 0.89 / 24.4    32: 1.32 / 0.91 / 23.2
 constexpr int TREE_LEAF = MISLAM_TREE_LEAF;
 constexpr int TREE_MAX_HEIGHT = 24;
 
@@ -18,6 +19,11 @@ struct NnTreeView {
                                       // 2i+2 (adjacent: one 64-byte record), leaves start at n_pad-1
     int n_pad;                        // leaf count padded to a power of two (padding leaves carry empty boxes)
     int height;                       // log2(n_pad)
+    // compact copies read by the default (per-lane) walk: fewer, fuller 16-byte loads per visit
+    const float4* pairs;              // internal node p: the boxes of its two children in 3 float4 (48 B instead of 64):
+                                      //   (l.lo.x l.lo.y l.lo.z l.hi.x) (l.hi.y l.hi.z r.lo.x r.lo.y) (r.lo.z r.hi.x r.hi.y r.hi.z)
+    const float4* leaf_soa;           // leaf f: x[TREE_LEAF], y[TREE_LEAF], z[TREE_LEAF] (3*TREE_LEAF/4 float4; no index word)
+    const int* leaf_idx;              // GLOBAL index of sorted slot s (read only for the winner and on exact ties)
 };
 
 // Morton order of a SoA cloud: order_out[s] = index of the s-th point along the Z-curve of the cloud's bounding box.
@@ -38,6 +44,9 @@ struct TreeBuildArgs {
     int n_leaves, n_pad;
     float4* pts;
     float4* boxes;                    // 2 * (2*n_pad - 1) float4
+    float4* pairs;                    // 3 * (n_pad - 1) float4
+    float4* leaf_soa;                 // n_leaves * 3 * TREE_LEAF / 4 float4
+    int* leaf_idx;                    // n_leaves * TREE_LEAF
 };
 
 size_t tree_sort_temp_bytes(int m);

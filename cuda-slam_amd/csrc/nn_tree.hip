@@ -192,6 +192,30 @@ __global__ __launch_bounds__(256) void tree_level_kernel(int first, int count, f
     boxes[2 * node + 1] = make_float4(fmaxf(c.x, d.x), fmaxf(c.y, d.y), fmaxf(c.z, d.z), 0.f);
 }
 
+// compact copies for the per-lane walk (layouts: NnTreeView)
+__global__ __launch_bounds__(256) void tree_pack_pairs_kernel(const float4* __restrict__ boxes, int n_internal, float4* __restrict__ pairs)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_internal) return;
+    const int l = 2 * p + 1;
+    const float4 llo = boxes[2 * (size_t)l], lhi = boxes[2 * (size_t)l + 1], rlo = boxes[2 * (size_t)l + 2], rhi = boxes[2 * (size_t)l + 3];
+    pairs[3 * (size_t)p] = make_float4(llo.x, llo.y, llo.z, lhi.x);
+    pairs[3 * (size_t)p + 1] = make_float4(lhi.y, lhi.z, rlo.x, rlo.y);
+    pairs[3 * (size_t)p + 2] = make_float4(rlo.z, rhi.x, rhi.y, rhi.z);
+}
+
+__global__ __launch_bounds__(256) void tree_pack_leaves_kernel(const float4* __restrict__ pts, int n_slots, float* __restrict__ soa,
+                                                               int* __restrict__ idx)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_slots) return;
+    const float4 q = pts[s];
+    const int leaf = s / TREE_LEAF, k = s % TREE_LEAF;
+    float* base = soa + (size_t)leaf * 3 * TREE_LEAF;
+    base[k] = q.x; base[TREE_LEAF + k] = q.y; base[2 * TREE_LEAF + k] = q.z;
+    idx[s] = __float_as_int(q.w);
+}
+
 hipError_t tree_build(const TreeBuildArgs& a, hipStream_t s)
 {
     hipError_t e = morton_order(a.morton, s);
@@ -203,6 +227,10 @@ hipError_t tree_build(const TreeBuildArgs& a, hipStream_t s)
     hipLaunchKernelGGL(tree_leaf_box_kernel, dim3((a.n_pad + 255) / 256), dim3(256), 0, s, a.pts, a.n_leaves, a.n_pad, a.boxes);
     for (int count = a.n_pad / 2; count >= 1; count /= 2)   // levels bottom-up: nodes [count-1, 2*count-1)
         hipLaunchKernelGGL(tree_level_kernel, dim3((count + 255) / 256), dim3(256), 0, s, count - 1, count, a.boxes);
+    if (a.n_pad > 1)
+        hipLaunchKernelGGL(tree_pack_pairs_kernel, dim3((a.n_pad - 1 + 255) / 256), dim3(256), 0, s, a.boxes, a.n_pad - 1, a.pairs);
+    hipLaunchKernelGGL(tree_pack_leaves_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, a.pts, n_slots, reinterpret_cast<float*>(a.leaf_soa),
+                       a.leaf_idx);
     return hipGetLastError();
 }
 
@@ -438,6 +466,96 @@ __global__ __launch_bounds__(256) void nn_tree_lane_kernel(const float4* __restr
     if (best < __builtin_inff()) keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
 }
 
+// The same walk over the compact copies (NnTreeView::pairs / leaf_soa / leaf_idx): 3 instead of 4 loads per internal node and
+// 3/4 of the loads per leaf (no index words).  The walk is bound by the number of divergent 16-byte loads the L1 has to serve
+// (counters: ~12 line accesses per load instruction), so fewer loads per visit is what pays.  The winner is
+// tracked by its sorted SLOT; the global index is fetched once at the end -- and on an exact tie, where the lower GLOBAL index
+// must win (rare: duplicates, or the posted starting candidate met again).
+template <bool FMA>
+__global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t, const float* __restrict__ sx, const float* __restrict__ sy,
+                                                                   const float* __restrict__ sz, int n, unsigned long long* __restrict__ keys,
+                                                                   const int* __restrict__ done_flag, int stack_depth)
+{
+    if (done_flag != nullptr && *done_flag != 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* st_node = reinterpret_cast<int*>(smem);
+    float* st_lb = reinterpret_cast<float*>(smem + (size_t)stack_depth * 256 * sizeof(int));
+    const float4* __restrict__ pairs = t.pairs;
+    const float4* __restrict__ leaf_soa = t.leaf_soa;
+    const int* __restrict__ leaf_idx = t.leaf_idx;
+
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float p[3] = {sx[i], sy[i], sz[i]};
+    const unsigned long long k0 = keys[i];
+    const unsigned int hi0 = (unsigned int)(k0 >> 32);
+    float best = hi0 < 0x7f800000u ? __uint_as_float(hi0) : __builtin_inff();
+    unsigned int bidx = hi0 < 0x7f800000u ? (unsigned int)(k0 & 0xffffffffull) : 0u;   // the winner's index while bslot < 0
+    int bslot = -1;
+
+    const int first_leaf = t.n_pad - 1;
+    int sp = 0;
+    int node = 0;
+    const float root_lb = box_bound<FMA>(t.boxes[0], t.boxes[1], p, p);
+    bool have = root_lb <= best && root_lb < __builtin_inff();
+    auto pop = [&]() {
+        have = false;
+        while (sp > 0) {
+            sp--;
+            const float lb = st_lb[sp * 256 + threadIdx.x];
+            if (lb <= best) { node = st_node[sp * 256 + threadIdx.x]; have = true; break; }
+        }
+    };
+    // candidate at sorted slot `slot` with squared distance d: lexicographic (d, global index) minimum
+    auto offer = [&](float d, int slot) {
+        const bool tie = d == best;
+        const bool lt = d < best;
+        best = lt ? d : best;
+        bslot = lt ? slot : bslot;
+        if (tie) {
+            const unsigned int j = (unsigned int)leaf_idx[slot];
+            const unsigned int jb = bslot >= 0 ? (unsigned int)leaf_idx[bslot] : bidx;
+            if (j < jb) bslot = slot;
+        }
+    };
+    while (have) {
+        while (have && node < first_leaf) {
+            const float4* __restrict__ rec = pairs + 3 * (size_t)node;
+            const float4 a = rec[0], b = rec[1], c = rec[2];
+            const float lbl = box_bound<FMA>(make_float4(a.x, a.y, a.z, 0.f), make_float4(a.w, b.x, b.y, 0.f), p, p);
+            const float lbr = box_bound<FMA>(make_float4(b.z, b.w, c.x, 0.f), make_float4(c.y, c.z, c.w, 0.f), p, p);
+            const int l = 2 * node + 1;
+            const bool left_near = lbl <= lbr;
+            const int near = left_near ? l : l + 1, far = left_near ? l + 1 : l;
+            const float lbn = left_near ? lbl : lbr, lbf = left_near ? lbr : lbl;
+            if (lbf <= best && lbf < __builtin_inff()) {
+                st_node[sp * 256 + threadIdx.x] = far;
+                st_lb[sp * 256 + threadIdx.x] = lbf;
+                sp++;
+            }
+            if (lbn <= best && lbn < __builtin_inff()) node = near;
+            else pop();
+        }
+        if (!have) break;
+        const int leaf = node - first_leaf;
+        const int slot0 = leaf * TREE_LEAF;
+        const float4* __restrict__ lp = leaf_soa + (size_t)leaf * (3 * TREE_LEAF / 4);
+#pragma unroll
+        for (int c4 = 0; c4 < TREE_LEAF / 4; c4++) {
+            const float4 X = lp[c4], Y = lp[TREE_LEAF / 4 + c4], Z = lp[2 * (TREE_LEAF / 4) + c4];
+            offer(sq3<FMA>(X.x - p[0], Y.x - p[1], Z.x - p[2]), slot0 + 4 * c4);
+            offer(sq3<FMA>(X.y - p[0], Y.y - p[1], Z.y - p[2]), slot0 + 4 * c4 + 1);
+            offer(sq3<FMA>(X.z - p[0], Y.z - p[1], Z.z - p[2]), slot0 + 4 * c4 + 2);
+            offer(sq3<FMA>(X.w - p[0], Y.w - p[1], Z.w - p[2]), slot0 + 4 * c4 + 3);
+        }
+        pop();
+    }
+    if (best < __builtin_inff()) {
+        const unsigned int j = bslot >= 0 ? (unsigned int)leaf_idx[bslot] : bidx;
+        keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | j;
+    }
+}
+
 // Per-lane form without any stack: the heap numbering makes ancestors and siblings computable, so a 32-bit "trail" (bit l set
 // = the sibling of this lane's level-l ancestor is still to be visited) replaces the LDS stack.  Same visiting order as the
 // stack form (deepest pending sibling first); a pending sibling's bound is re-computed from its box when it comes up
@@ -516,6 +634,12 @@ hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, 
         const int depth = t.height + 2;
         const size_t lds = (size_t)depth * 256 * 8;
         dim3 grid((n + 255) / 256), block(256);
+        static const bool compact = [] { const char* v = getenv("MISLAM_TREE_COMPACT"); return !(v && *v == '0'); }();
+        if (compact && t.pairs != nullptr) {   // same walk over the compact copies (default)
+            if (fma) hipLaunchKernelGGL(nn_tree_lane_compact_kernel<true>, grid, block, lds, s, t, sx, sy, sz, n, keys, done_flag, depth);
+            else hipLaunchKernelGGL(nn_tree_lane_compact_kernel<false>, grid, block, lds, s, t, sx, sy, sz, n, keys, done_flag, depth);
+            return hipGetLastError();
+        }
         if (fma) hipLaunchKernelGGL(nn_tree_lane_kernel<true>, grid, block, lds, s, t.pts, t.boxes, t.n_pad, sx, sy, sz, n, keys, done_flag, depth);
         else hipLaunchKernelGGL(nn_tree_lane_kernel<false>, grid, block, lds, s, t.pts, t.boxes, t.n_pad, sx, sy, sz, n, keys, done_flag, depth);
         return hipGetLastError();
