@@ -230,7 +230,7 @@ def main():
         alg_bytes = 20.0 * n_local + 12.0 * m_local    # this rank: 12 B source xyz + 8 B packed key per moving point, 12 B per fixed point
         achieved_gbs = alg_bytes / nn_avg_s / 1e9
         fig = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-               "traffic": None, "kernel": "nn_bruteforce_kernel" if brute else "nn_tree_lane_kernel",
+               "traffic": None, "kernel": "nn_bruteforce_kernel" if brute else "nn_tree_lane_compact_kernel",
                "avg_launch_ms": nn_avg_s * 1e3, "launches": nn_n, "algorithmic_bytes_per_launch": alg_bytes}
         if world == 1 and args.dist_mode == 0:
             fig["traffic"], fig["traffic_source"] = committed_traffic("icp_synthetic_uniform_n%d" % n, fig["kernel"])
