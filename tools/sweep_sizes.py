@@ -36,8 +36,23 @@ def run_set(ctx, capi, path, method, sizes):
                 R, t, it, err = ctx.icp_register(before, after, p)
                 ms = (time.perf_counter() - t0) * 1e3
                 passes = it + 1 if err < 1e-3 else max(it, 1)
+            elif method.startswith("nicp"):
+                # the reference registers a cloud against its own transformed copy in the SAME point order for this method's sets
+                # (same file before/after, no shuffle between them matters to a principal-axis method); draws from numpy here
+                rng = np.random.default_rng(k)
+                same = (before.astype(np.float64) @ np.array([[np.cos(.2), -np.sin(.2), 0], [np.sin(.2), np.cos(.2), 0], [0, 0, 1]]).T
+                        + 10.0 / np.sqrt(3.0)).astype(np.float32)
+                reps = 64 if method == "nicp-hybrid" else 32                     # testset.cpp:110 / configparser.cpp:234
+                sub = rng.permutation(n)[:1000].astype(np.int32) if n > 1000 else None
+                heads = np.stack([rng.permutation(n)[:3] for _ in range(reps)]).astype(np.int32)
+                p = capi.nicp_params(eps=1e-3, max_repetitions=reps, approximation=2 if method == "nicp-hybrid" else 0)
+                t0 = time.perf_counter()
+                R, t, it, err = ctx.nicp_register(before, same, p, heads, sub)
+                ms = (time.perf_counter() - t0) * 1e3
+                passes = max(it, 1)
             else:
-                p = capi.cpd_params(max_iterations=50, weight=0.1, const_scale=0, eps=1e-3, tolerance=1e-3)
+                approx = capi.CPD_APPROX_HYBRID if method == "cpd-hybrid" else capi.CPD_APPROX_NONE
+                p = capi.cpd_params(max_iterations=50, weight=0.1, const_scale=0, eps=1e-3, tolerance=1e-3, approximation=approx)
                 t0 = time.perf_counter()
                 sR, t, sc, it, err = ctx.cpd_register(before, after, p)
                 ms = (time.perf_counter() - t0) * 1e3
@@ -59,6 +74,12 @@ def main():
     # GetSizesTestSet: ICP 1 000 ... 100 000 step 4 000 (every third), CPD 100 ... 1 000 step 100 (+ BASELINE.md's 10 000 / 49 000)
     run_set(ctx, capi, os.path.join(out, "sizes-icp.csv"), "icp", list(range(1000, 100001, 12000)) + [10000])
     run_set(ctx, capi, os.path.join(out, "sizes-cpd.csv"), "cpd", list(range(100, 1001, 100)) + [10000, 49000])
+    # the parser's default approximation (hybrid: FGT E-steps, then truncated exact ones) at the same CPD sizes
+    run_set(ctx, capi, os.path.join(out, "sizes-cpd-hybrid.csv"), "cpd-hybrid", [1000, 10000, 49000])
+    # GetSizesTestSet NICP 1 000 ... 200 000 step 4 000 (every tenth, approximation none); GetPerformanceTestSet NICP
+    # 10 000 ... 300 000 (hybrid, 64 repetitions, subcloud 1 000) + 10^6
+    run_set(ctx, capi, os.path.join(out, "sizes-nicp.csv"), "nicp", list(range(1000, 200001, 40000)) + [100000, 200000])
+    run_set(ctx, capi, os.path.join(out, "performance-nicp.csv"), "nicp-hybrid", [10000, 100000, 300000, 1000000])
     ctx.close()
 
 
