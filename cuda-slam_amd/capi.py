@@ -33,7 +33,7 @@ EXPORTS = [
     "mi_icp_register", "mi_icp_load", "mi_icp_reset", "mi_icp_run", "mi_icp_result", "mi_nn_search", "mi_nn_search_ex", "mi_kabsch",
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_estep",
     "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
-    "mi_cpd_mstep", "mi_profile_enable", "mi_profile_reset", "mi_profile_get",
+    "mi_cpd_mstep", "mi_profile_enable", "mi_profile_select", "mi_profile_reset", "mi_profile_get",
 ]
 
 
@@ -370,6 +370,11 @@ class Context:
     # ---- profiling
     def profile_enable(self, on=True):
         _check(lib().mi_profile_enable(self._h, 1 if on else 0))
+
+    def profile_select(self, kernels=None):
+        """Restrict the event timing to these kernels (KERNEL_* ids); None = all."""
+        mask = 0xffffffff if kernels is None else sum(1 << k for k in kernels)
+        _check(lib().mi_profile_select(self._h, C.c_uint(mask)))
 
     def profile_reset(self):
         _check(lib().mi_profile_reset(self._h))

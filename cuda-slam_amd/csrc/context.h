@@ -122,6 +122,7 @@ struct mi_ctx {
 
     // ---- profiling
     bool profile = false;
+    unsigned int prof_mask = 0xffffffffu;                // kernels that get events while profiling (mi_profile_select)
     std::vector<mislam::ProfileSpan> spans;
     std::vector<hipEvent_t> event_pool;
     double prof_ms[MI_KERNEL_COUNT] = {0};
@@ -137,7 +138,7 @@ namespace mislam {
 struct ProfScope {
     mi_ctx* c;
     bool on;
-    ProfScope(mi_ctx* ctx, int kernel) : c(ctx), on(ctx->profile) { if (on) (void)c->prof_begin(kernel); }
+    ProfScope(mi_ctx* ctx, int kernel) : c(ctx), on(ctx->profile && ((ctx->prof_mask >> kernel) & 1u)) { if (on) (void)c->prof_begin(kernel); }
     ~ProfScope() { if (on) (void)c->prof_end(); }
 };
 

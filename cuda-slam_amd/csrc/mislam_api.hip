@@ -218,6 +218,13 @@ extern "C" int mi_profile_enable(mi_ctx* c, int enable)
     return MI_OK;
 }
 
+extern "C" int mi_profile_select(mi_ctx* c, unsigned int kernel_mask)
+{
+    if (!c) { set_error("mi_profile_select: null context"); return MI_ERR_INVALID_ARG; }
+    c->prof_mask = kernel_mask;
+    return MI_OK;
+}
+
 extern "C" int mi_profile_reset(mi_ctx* c)
 {
     if (!c) { set_error("mi_profile_reset: null context"); return MI_ERR_INVALID_ARG; }

@@ -325,6 +325,10 @@ enum {
     MI_KERNEL_COUNT = 10
 };
 int mi_profile_enable(mi_ctx* ctx, int enable);
+/* Which kernels get events while profiling is enabled: bit k = MI_KERNEL_k (default: all).  Two event records around every
+ * launch of a 5-kernel iteration cost a few per cent of a millisecond-sized step; bench.py times only the search in its timed
+ * region and the rest in a separate short run. */
+int mi_profile_select(mi_ctx* ctx, unsigned int kernel_mask);
 int mi_profile_reset(mi_ctx* ctx);
 /* total_ms = sum of event-timed durations of that kernel since the last reset; launches = how many. */
 int mi_profile_get(mi_ctx* ctx, int kernel, double* total_ms, long long* launches);
