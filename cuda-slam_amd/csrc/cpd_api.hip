@@ -22,9 +22,10 @@ struct FgtSide {
     DevBuf<float> dist, xc;
     DevBuf<int> indx, iota, memb, off;
     DevBuf<unsigned int> keys;
+    DevBuf<unsigned char> sweep;   // scratch of the grid-wide sweep (large clouds)
     int iota_n = 0;
     int swept_K = 0;            // the fixed cloud only: centres of the sweep dist/indx currently hold (0 = none); see fgt_kcenter_kernel
-    void release() { dist.release(); xc.release(); indx.release(); iota.release(); memb.release(); off.release(); keys.release(); iota_n = 0; swept_K = 0; }
+    void release() { dist.release(); xc.release(); indx.release(); iota.release(); memb.release(); off.release(); keys.release(); sweep.release(); iota_n = 0; swept_K = 0; }
 };
 
 // Fast-Gauss-Transform E-step workspace ("approximation-type" full / hybrid)
@@ -270,6 +271,8 @@ static int fgt_side(mi_ctx* c, FgtWork* f, FgtSide* sd, const float* x, const fl
     MI_TRY(sd->keys.reserve(n)); MI_TRY(sd->off.reserve((size_t)K + 1)); MI_TRY(sd->xc.reserve(3 * (size_t)K));
     if (sd->iota_n < n) { MI_HIP(fgt_fill_iota(sd->iota.p, n, c->stream)); sd->iota_n = n; }
     MI_TRY(f->sort_temp.reserve(std::max<size_t>(fgt_sort_temp_bytes(n), 16)));
+    if (n > FGT_GRID_SWEEP_MIN_POINTS) MI_TRY(sd->sweep.reserve(FGT_SWEEP_SCRATCH_BYTES));
+    out->sweep_scratch = n > FGT_GRID_SWEEP_MIN_POINTS ? sd->sweep.p : nullptr;
     out->x = x; out->y = y; out->z = z; out->n = n; out->K = K; out->k_done = 0;
     out->dist = sd->dist.p; out->indx = sd->indx.p; out->iota = sd->iota.p; out->keys_sorted = sd->keys.p;
     out->memb = sd->memb.p; out->off = sd->off.p; out->xc = sd->xc.p;

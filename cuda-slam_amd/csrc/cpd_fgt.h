@@ -8,6 +8,9 @@ namespace mislam {
 
 constexpr int FGT_MAX_ORDER = 16;          // p: monomials of total degree < p; exponents are packed in 8 bits each
 constexpr int FGT_KEY_BITS = 16;           // cluster ids are sorted on this many bits: K <= 65535
+constexpr int FGT_GRID_SWEEP_MIN_POINTS = 65536;   // above this the K-centre sweep runs one grid-wide launch per step
+constexpr int FGT_GRID_SWEEP_BLOCKS = 1024;
+constexpr size_t FGT_SWEEP_SCRATCH_BYTES = (size_t)(FGT_GRID_SWEEP_BLOCKS + 1) * 20;   // current centre + per-workgroup arg-max records
 
 // Monomial tables of one truncation order p, device resident (built on the host, cpd_api.hip).  Index t is the reference's
 // graded order (fgt.cpp:124-137): degree by degree, x-power descending, then y-power descending.
@@ -30,6 +33,7 @@ struct FgtClusters {
     int* memb;                  // [n]   point ids grouped by cluster, ascending inside a cluster
     int* off;                   // [K+1] cluster k owns memb[off[k] .. off[k+1])
     float* xc;                  // [K][3] cluster means
+    void* sweep_scratch;        // FGT_SWEEP_SCRATCH_BYTES, used by the grid-wide sweep (may be null for small clouds)
 };
 
 size_t fgt_sort_temp_bytes(int n);

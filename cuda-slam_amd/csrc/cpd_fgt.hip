@@ -37,6 +37,8 @@ struct ArgMax {
     float x, y, z;
 };
 
+static_assert(sizeof(ArgMax) == 20 && FGT_SWEEP_SCRATCH_BYTES >= (FGT_GRID_SWEEP_BLOCKS + 1) * sizeof(ArgMax), "sweep scratch size");
+
 __device__ __forceinline__ bool beats(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
 __device__ __forceinline__ ArgMax wave_argmax(ArgMax a)
@@ -137,6 +139,63 @@ __global__ __launch_bounds__(1024) void fgt_kcenter_kernel(const float* __restri
             const int j = tid + r * 1024;
             if (j < n) { indx[j] = pc[r]; dist[j] = pd[r]; }
         }
+    }
+}
+
+// The same sweep for large clouds, one step per launch over the whole grid.  step_kernel applies centre `cur` (step 0: point 1)
+// to every point -- or, scan_only, just reads the distances a finished sweep left -- and posts each workgroup's arg-max (first
+// maximum: every lane walks ascending indices, ties go to the lower index); pick_kernel reduces those to the next centre.
+__global__ __launch_bounds__(256) void fgt_sweep_step_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ z, int n, const ArgMax* __restrict__ cur, int step,
+                                                             int scan_only, float* __restrict__ dist, int* __restrict__ indx,
+                                                             ArgMax* __restrict__ partials)
+{
+    __shared__ ArgMax s_best[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float cx, cy, cz;
+    if (step == 0) { cx = x[1]; cy = y[1]; cz = z[1]; }     // fgt.cpp:162
+    else { cx = cur->x; cy = cur->y; cz = cur->z; }
+    ArgMax best = {-1.f, 0x7fffffff, 0.f, 0.f, 0.f};
+    for (int j = blockIdx.x * 256 + tid; j < n; j += gridDim.x * 256) {
+        const float qx = x[j], qy = y[j], qz = z[j];
+        float v;
+        if (scan_only) v = dist[j];
+        else {
+            const float d = len2(qx - cx, qy - cy, qz - cz);
+            if (step == 0) { v = d; dist[j] = d; indx[j] = 0; }
+            else {
+                v = dist[j];
+                if (d < v) { v = d; dist[j] = d; indx[j] = step; }       // strict <: fgt.cpp:187
+            }
+        }
+        if (v > best.v) best = {v, j, qx, qy, qz};
+    }
+    best = wave_argmax(best);
+    if (lane == 0) s_best[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+        ArgMax w = s_best[0];
+        for (int q = 1; q < 4; q++) if (beats(s_best[q].v, s_best[q].i, w.v, w.i)) w = s_best[q];
+        partials[blockIdx.x] = w;
+    }
+}
+
+__global__ __launch_bounds__(256) void fgt_sweep_pick_kernel(const ArgMax* __restrict__ partials, int count, ArgMax* __restrict__ cur)
+{
+    __shared__ ArgMax s_best[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ArgMax best = {-1.f, 0x7fffffff, 0.f, 0.f, 0.f};
+    for (int q = tid; q < count; q += 256) {
+        const ArgMax o = partials[q];
+        if (beats(o.v, o.i, best.v, best.i)) best = o;
+    }
+    best = wave_argmax(best);
+    if (lane == 0) s_best[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+        ArgMax w = s_best[0];
+        for (int q = 1; q < 4; q++) if (beats(s_best[q].v, s_best[q].i, w.v, w.i)) w = s_best[q];
+        *cur = w;
     }
 }
 
@@ -394,7 +453,20 @@ hipError_t fgt_fill_iota(int* iota, int n, hipStream_t s)
 hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_bytes, hipStream_t s)
 {
     const int start = c.k_done > 0 && c.k_done < c.K ? c.k_done : 0;
-    if (c.n <= 4 * 1024) hipLaunchKernelGGL(fgt_kcenter_kernel<4>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, c.K, c.dist, c.indx);
+    if (c.n > FGT_GRID_SWEEP_MIN_POINTS && c.sweep_scratch != nullptr) {
+        // large clouds: one grid-wide launch per step (update + per-workgroup arg-max) and a one-workgroup pick in between --
+        // two launches per centre instead of one workgroup streaming the whole cloud K times
+        ArgMax* cur = reinterpret_cast<ArgMax*>(c.sweep_scratch);
+        ArgMax* partials = cur + 1;
+        int G = (c.n + 256 * 8 - 1) / (256 * 8);
+        if (G > FGT_GRID_SWEEP_BLOCKS) G = FGT_GRID_SWEEP_BLOCKS;
+        if (start > 0) hipLaunchKernelGGL(fgt_sweep_step_kernel, dim3(G), dim3(256), 0, s, c.x, c.y, c.z, c.n, cur, 0, 1, c.dist, c.indx, partials);
+        for (int step = start; step < c.K; step++) {
+            if (step > 0) hipLaunchKernelGGL(fgt_sweep_pick_kernel, dim3(1), dim3(256), 0, s, partials, G, cur);
+            hipLaunchKernelGGL(fgt_sweep_step_kernel, dim3(G), dim3(256), 0, s, c.x, c.y, c.z, c.n, cur, step, 0, c.dist, c.indx, partials);
+        }
+    }
+    else if (c.n <= 4 * 1024) hipLaunchKernelGGL(fgt_kcenter_kernel<4>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, c.K, c.dist, c.indx);
     else if (c.n <= 16 * 1024) hipLaunchKernelGGL(fgt_kcenter_kernel<16>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, c.K, c.dist, c.indx);
     else hipLaunchKernelGGL(fgt_kcenter_kernel<0>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, c.K, c.dist, c.indx);
     hipError_t e = hipGetLastError();

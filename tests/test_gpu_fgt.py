@@ -29,7 +29,8 @@ def rel(a, b):
 # K-centre clustering: labels and cell means bit for bit
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("seed,n,K", [(0, 2, 1), (1, 2, 2), (2, 300, 50), (3, 4096, 117), (4, 4097, 64), (5, 14904, 117),
-                                      (6, 16384, 51), (7, 16385, 33), (8, 50000, 70), (9, 1000, 1000)])
+                                      (6, 16384, 51), (7, 16385, 33), (8, 50000, 70), (9, 1000, 1000), (10, 65536, 20), (11, 65537, 37),
+                                      (12, 300000, 51)])
 def test_kcenter_matches_oracle_bit_for_bit(ctx, oracle, seed, n, K):
     c = cloud(seed, n)
     xc_o, lab_o = oracle.fgt_kcenter(c, K)
@@ -176,6 +177,23 @@ def test_resumed_clustering_changes_nothing(ctx, capi, golden, bunny, monkeypatc
     monkeypatch.setenv("MISLAM_FGT_RESUME", "0")
     b = ctx.cpd_register(before, after, p)
     assert a[3] == b[3] == 24 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[4] == b[4]
+
+
+def test_large_cloud_sweep_and_its_resume(ctx, capi, oracle, monkeypatch):
+    # above 65 536 points the sweep runs one grid-wide launch per centre; the fixed cloud's sweep is still resumed as K grows
+    rng = np.random.default_rng(4)
+    b = (rng.normal(size=(90000, 3)) * np.array([2.0, 1.0, 0.5])).astype(np.float32)
+    ang = 0.25
+    Rz = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    a = (b[rng.permutation(90000)[:80000]] @ Rz.T + np.array([0.3, -0.2, 0.1])).astype(np.float32)
+    lab_o = oracle.fgt_kcenter(a, 60)[1]
+    assert np.array_equal(ctx.fgt_kcenter(a, 60)[1], lab_o)
+    p = capi.cpd_params(max_iterations=8, tolerance=0.0, approximation=capi.CPD_APPROX_HYBRID)
+    r1 = ctx.cpd_register(b, a, p)
+    monkeypatch.setenv("MISLAM_FGT_RESUME", "0")
+    r2 = ctx.cpd_register(b, a, p)
+    assert r1[3] == r2[3] == 8 and np.array_equal(r1[0], r2[0]) and np.array_equal(r1[1], r2[1]) and r1[4] == r2[4]
+    assert np.abs(r1[0] / r1[2] - Rz).max() < 0.05             # sR / s: eight iterations in, the rotation is already there
 
 
 @pytest.mark.parametrize("cap", [5, 17])
