@@ -109,7 +109,7 @@ static int cpd_load(mi_ctx* c, CpdWorkspace* w, const float* before_xyz, int m, 
     MI_TRY(c->bx.reserve(mp)); MI_TRY(c->by.reserve(mp)); MI_TRY(c->bz.reserve(mp));
     MI_TRY(c->cx.reserve(mp)); MI_TRY(c->cy.reserve(mp)); MI_TRY(c->cz.reserve(mp));
     MI_TRY(w->ax.reserve(np)); MI_TRY(w->ay.reserve(np)); MI_TRY(w->az.reserve(np));
-    plan_chunks(c, n, 2, m, &w->k_chunks, &w->k_chunk_len);
+    plan_chunks(c, n, 4, m, &w->k_chunks, &w->k_chunk_len);
     plan_chunks(c, m, 2, n, &w->x_chunks, &w->x_chunk_len);
     MI_TRY(w->den_part.reserve((size_t)w->k_chunks * n));
     MI_TRY(w->pt1.reserve(np));
