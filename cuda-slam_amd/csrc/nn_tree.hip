@@ -477,9 +477,13 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
                                                                    const int* __restrict__ done_flag, int stack_depth)
 {
     if (done_flag != nullptr && *done_flag != 0) return;
+    // Pending subtrees: WHICH ones is a 32-bit trail in a register (bit l set = the sibling of this lane's level-l ancestor is
+    // still to be visited; the heap numbering makes it computable), their BOUNDS sit in LDS, one word per level and lane.  Half
+    // the LDS of a (node, bound) stack, and LDS is what caps the occupancy of this 32-VGPR kernel: 8 instead of 4 waves per SIMD
+    // to hide the dependent loads behind.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int* st_node = reinterpret_cast<int*>(smem);
-    float* st_lb = reinterpret_cast<float*>(smem + (size_t)stack_depth * 256 * sizeof(int));
+    float* st_lb = reinterpret_cast<float*>(smem);
+    (void)stack_depth;
     const float4* __restrict__ pairs = t.pairs;
     const float4* __restrict__ leaf_soa = t.leaf_soa;
     const int* __restrict__ leaf_idx = t.leaf_idx;
@@ -494,16 +498,20 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
     int bslot = -1;
 
     const int first_leaf = t.n_pad - 1;
-    int sp = 0;
-    int node = 0;
+    unsigned int trail = 0;
+    int node = 0, level = 0;
     const float root_lb = box_bound<FMA>(t.boxes[0], t.boxes[1], p, p);
     bool have = root_lb <= best && root_lb < __builtin_inff();
+    // next pending subtree that can still matter (deepest first), or have = false when none is left
     auto pop = [&]() {
         have = false;
-        while (sp > 0) {
-            sp--;
-            const float lb = st_lb[sp * 256 + threadIdx.x];
-            if (lb <= best) { node = st_node[sp * 256 + threadIdx.x]; have = true; break; }
+        while (trail != 0) {
+            const int b = 31 - __builtin_clz(trail);              // deepest pending level
+            trail &= ~(1u << b);
+            const int anc = ((node + 1) >> (level - b)) - 1;      // this lane's ancestor at level b ...
+            node = ((anc + 1) ^ 1) - 1;                           // ... its sibling is the pending subtree
+            level = b;                                            // (bits deeper than b are all clear now)
+            if (st_lb[b * 256 + threadIdx.x] <= best) { have = true; break; }
         }
     };
     // candidate at sorted slot `slot` with squared distance d: lexicographic (d, global index) minimum
@@ -526,15 +534,16 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
             const float lbr = box_bound<FMA>(make_float4(b.z, b.w, c.x, 0.f), make_float4(c.y, c.z, c.w, 0.f), p, p);
             const int l = 2 * node + 1;
             const bool left_near = lbl <= lbr;
-            const int near = left_near ? l : l + 1, far = left_near ? l + 1 : l;
             const float lbn = left_near ? lbl : lbr, lbf = left_near ? lbr : lbl;
+            // step to the near child either way: the trail is relative to the current node, and the far child is "the sibling
+            // of my ancestor at the new level"
+            node = left_near ? l : l + 1;
+            level += 1;
             if (lbf <= best && lbf < __builtin_inff()) {
-                st_node[sp * 256 + threadIdx.x] = far;
-                st_lb[sp * 256 + threadIdx.x] = lbf;
-                sp++;
+                trail |= 1u << level;
+                st_lb[level * 256 + threadIdx.x] = lbf;
             }
-            if (lbn <= best && lbn < __builtin_inff()) node = near;
-            else pop();
+            if (!(lbn <= best && lbn < __builtin_inff())) pop();
         }
         if (!have) break;
         const int leaf = node - first_leaf;
@@ -636,8 +645,9 @@ hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, 
         dim3 grid((n + 255) / 256), block(256);
         static const bool compact = [] { const char* v = getenv("MISLAM_TREE_COMPACT"); return !(v && *v == '0'); }();
         if (compact && t.pairs != nullptr) {   // same walk over the compact copies (default)
-            if (fma) hipLaunchKernelGGL(nn_tree_lane_compact_kernel<true>, grid, block, lds, s, t, sx, sy, sz, n, keys, done_flag, depth);
-            else hipLaunchKernelGGL(nn_tree_lane_compact_kernel<false>, grid, block, lds, s, t, sx, sy, sz, n, keys, done_flag, depth);
+            const size_t lds_c = (size_t)(t.height + 1) * 256 * sizeof(float);      // one bound per level and lane
+            if (fma) hipLaunchKernelGGL(nn_tree_lane_compact_kernel<true>, grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, depth);
+            else hipLaunchKernelGGL(nn_tree_lane_compact_kernel<false>, grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, depth);
             return hipGetLastError();
         }
         if (fma) hipLaunchKernelGGL(nn_tree_lane_kernel<true>, grid, block, lds, s, t.pts, t.boxes, t.n_pad, sx, sy, sz, n, keys, done_flag, depth);
