@@ -9,7 +9,8 @@ namespace mislam {
 #endif
 // points per leaf.  Measured on MI355X (N = M = 1e6, ms per search early / near convergence; 1e7 early):
 //   float4 leaves, 64-byte node records:  4: 2.03 / 1.17 / 36.8    8: 1.84 / 1.08 / 33.3    16: 1.68 / 1.04 / 30.0    32: 1.62 / 1.06 / 28.0
-//   compact copies (the default walk):    8: 1.50 / 0.92 / 27.6    16: 1.35 / 0.89 / 24.4    32: 1.32 / 0.91 / 23.2
+//   compact copies, (node, bound) stack:  8: 1.50 / 0.92 / 27.6    16: 1.35 / 0.89 / 24.4    32: 1.32 / 0.91 / 23.2
+//   compact copies, trail + bounds (the default walk):  8: 1.25 / 0.71 / 17.8    16: 1.14 / 0.68 / 16.5    32: 1.22 / 0.77 / 17.9
 constexpr int TREE_LEAF = MISLAM_TREE_LEAF;
 constexpr int TREE_MAX_HEIGHT = 24;
 
