@@ -5,6 +5,7 @@ timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ
 timeout -k 10 300 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM -d gpurun_out/pmc_tree2 --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --brute-ref-steps 0 > gpurun_out/pmc_tree2.log 2>&1
 python3 - <<'PY'
 import csv,glob,collections
+out={}
 for d in ("pmc_tree1","pmc_tree2"):
     fs=glob.glob(f"gpurun_out/{d}/*/*_counter_collection.csv")
     if not fs: print(d,"no csv"); continue
@@ -12,5 +13,9 @@ for d in ("pmc_tree1","pmc_tree2"):
     for r in csv.DictReader(open(fs[0])):
         if "nn_tree" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,v in agg.items(): print(d,k,len(v),sum(v)/len(v))
+    out.update({k: sum(v)/len(v) for k,v in agg.items()})
+import json
+json.dump({"command": "rocprofv3 --pmc <two counter sets, separate passes> -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --brute-ref-steps 0",
+           "kernel": "nn_tree_lane_compact_kernel", "per_launch_mean": out}, open("gpurun_out/tree_counters.json","w"), indent=1)
 PY
 tail -2 gpurun_out/pmc_tree2.log | cut -c1-300
