@@ -221,38 +221,49 @@ __global__ __launch_bounds__(256) void cpd_contract_kernel(CpdView v)
 // The B operand comes from a per-x 16-byte record expanded over lanes by a lane-indexed load (lane l reads word l&3).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <bool TRUNC>
+template <int R, bool TRUNC>
 __global__ __launch_bounds__(256) void cpd_contract_mfma_kernel(CpdView v)
 {
     if (v.state->done != 0) return;
     const int chunk = blockIdx.x % v.x_chunks;
     const int kblk = blockIdx.x / v.x_chunks;
-    const int k = kblk * 256 + threadIdx.x;
-    const int kc = min(k, v.m - 1);
     const float mult = -0.5f / v.state->sigma2;
-    const float yx = v.yx[kc], yy = v.yy[kc], yz = v.yz[kc];
     const int lane = threadIdx.x & 63;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float yx[R], yy[R], yz[R];
+    f32x4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int kc = min(kblk * (256 * R) + r * 256 + (int)threadIdx.x, v.m - 1);
+        yx[r] = v.yx[kc]; yy[r] = v.yy[kc]; yz[r] = v.yz[kc];
+        acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const int x_begin = chunk * v.x_chunk_len;
     const int x_end = min(x_begin + v.x_chunk_len, v.n);
     const float* __restrict__ wrec = reinterpret_cast<const float*>(v.xw4);
+    // R moving points per lane share each fixed point's scalar loads and its operand load
     // (the compiler already pipelines this loop; hand-blocking it by CPD_T with the operand loads hoisted measured 5 % slower)
     for (int x = x_begin; x < x_end; x++) {
         const float ax = v.ax[x], ay = v.ay[x], az = v.az[x];
-        const float p = affinity<TRUNC>(mult * sq_dist(ax, ay, az, yx, yy, yz), v.trunc_log);
         const float b = wrec[4 * (size_t)x + (lane & 3)];
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(p, b, acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float p = affinity<TRUNC>(mult * sq_dist(ax, ay, az, yx[r], yy[r], yz[r]), v.trunc_log);
+            acc[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(p, b, acc[r], 0, 0, 0);
+        }
     }
     // D layout of the 4x4x1 form: lane l holds column j = l & 3 of block l >> 2, register i = row i of that block, i.e.
     // acc[i] = D[k = 4*(l>>2) + i][j = l&3].  Scatter to the chunk partial arrays (j = 3 is P1, j = 0..2 is PX).
-    const int kbase = kblk * 256 + (threadIdx.x & ~63) + 4 * (lane >> 2);
     const int j = lane & 3;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int kk = kbase + i;
-        if (kk < v.m) {
-            if (j == 3) v.p1_part[(size_t)chunk * v.m + kk] = acc[i];
-            else v.px_part[(size_t)chunk * 3 * v.m + (size_t)j * v.m + kk] = acc[i];
+    for (int r = 0; r < R; r++) {
+        const int kbase = kblk * (256 * R) + r * 256 + ((int)threadIdx.x & ~63) + 4 * (lane >> 2);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int kk = kbase + i;
+            if (kk < v.m) {
+                if (j == 3) v.p1_part[(size_t)chunk * v.m + kk] = acc[r][i];
+                else v.px_part[(size_t)chunk * 3 * v.m + (size_t)j * v.m + kk] = acc[r][i];
+            }
         }
     }
 }
@@ -394,6 +405,7 @@ __global__ __launch_bounds__(256) void cpd_transform_kernel(CpdView v, int m_pad
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int CPD_RA = 4;   // fixed points per lane in K7a (measured on the bunny clouds: 0.073 ms against 0.081 with 2)
+constexpr int CPD_RM = 1;   // moving points per lane in the MFMA form of K7b (2: 0.136 against 0.105 ms on the bunny clouds)
 constexpr int CPD_RB = 2;   // moving points per lane in the VALU form of K7b (4: 0.124 against 0.116 ms)
 
 hipError_t cpd_init_sums(const CpdView& v, double* partials, int nblocks, hipStream_t s)
@@ -425,9 +437,9 @@ hipError_t cpd_post_denominators(const CpdView& v, hipStream_t s)
 hipError_t cpd_contract(const CpdView& v, int use_mfma, hipStream_t s)
 {
     if (use_mfma) {
-        const int kblocks = (v.m + 255) / 256;
-        if (v.truncate) hipLaunchKernelGGL(cpd_contract_mfma_kernel<true>, dim3(kblocks * v.x_chunks), dim3(256), 0, s, v);
-        else hipLaunchKernelGGL(cpd_contract_mfma_kernel<false>, dim3(kblocks * v.x_chunks), dim3(256), 0, s, v);
+        const int kblocks = (v.m + 256 * CPD_RM - 1) / (256 * CPD_RM);
+        if (v.truncate) hipLaunchKernelGGL((cpd_contract_mfma_kernel<CPD_RM, true>), dim3(kblocks * v.x_chunks), dim3(256), 0, s, v);
+        else hipLaunchKernelGGL((cpd_contract_mfma_kernel<CPD_RM, false>), dim3(kblocks * v.x_chunks), dim3(256), 0, s, v);
     } else {
         const int kblocks = (v.m + 256 * CPD_RB - 1) / (256 * CPD_RB);
         if (v.truncate) hipLaunchKernelGGL((cpd_contract_kernel<CPD_RB, true>), dim3(kblocks * v.x_chunks), dim3(256), 0, s, v);
