@@ -104,6 +104,7 @@ struct mi_ctx {
     mislam::DevBuf<float4> tpts, tboxes;
     mislam::DevBuf<float4> tpairs, tleaf;                // compact copies for the per-lane walk (NnTreeView)
     mislam::DevBuf<int> tidx;
+    mislam::DevBuf<uint4> tpairs_half;
     mislam::NnTreeView tree{};
     bool tree_valid = false;
     mislam::DevBuf<int> sorder;                          // Morton order of the moving cloud (sorted slot -> caller's index)

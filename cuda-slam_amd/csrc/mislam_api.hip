@@ -154,7 +154,7 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     c->idx_tmp.release(); c->keep_tmp.release();
     c->tcodes_in.release(); c->tcodes_out.release(); c->torder_in.release(); c->torder_out.release();
     c->tbbox.release(); c->tsort_temp.release(); c->tpts.release(); c->tboxes.release(); c->sorder.release(); c->sinv.release(); c->resid.release();
-    c->tpairs.release(); c->tleaf.release(); c->tidx.release();
+    c->tpairs.release(); c->tpairs_half.release(); c->tleaf.release(); c->tidx.release();
     for (auto& s : c->spans) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->d_state) (void)hipFree(c->d_state);
@@ -329,16 +329,17 @@ static int ensure_tree(mi_ctx* c, int m_local, int index_base)
     MI_TRY(c->tpts.reserve((size_t)n_leaves * TREE_LEAF));
     MI_TRY(c->tboxes.reserve((size_t)4 * n_pad));
     MI_TRY(c->tpairs.reserve((size_t)3 * n_pad));
+    MI_TRY(c->tpairs_half.reserve((size_t)2 * n_pad));
     MI_TRY(c->tleaf.reserve((size_t)n_leaves * (3 * TREE_LEAF / 4)));
     MI_TRY(c->tidx.reserve((size_t)n_leaves * TREE_LEAF));
     TreeBuildArgs a{};
     MI_TRY(morton_args(c, c->tx.p, c->ty.p, c->tz.p, m_local, c->torder_out.p, &a.morton));
     a.index_base = index_base; a.n_leaves = n_leaves; a.n_pad = n_pad;
     a.pts = c->tpts.p; a.boxes = c->tboxes.p;
-    a.pairs = c->tpairs.p; a.leaf_soa = c->tleaf.p; a.leaf_idx = c->tidx.p;
+    a.pairs = c->tpairs.p; a.pairs_half = c->tpairs_half.p; a.leaf_soa = c->tleaf.p; a.leaf_idx = c->tidx.p;
     MI_HIP(tree_build(a, c->stream));
     c->tree.pts = c->tpts.p; c->tree.boxes = c->tboxes.p;
-    c->tree.pairs = c->tpairs.p; c->tree.leaf_soa = c->tleaf.p; c->tree.leaf_idx = c->tidx.p;
+    c->tree.pairs = c->tpairs.p; c->tree.pairs_half = c->tpairs_half.p; c->tree.leaf_soa = c->tleaf.p; c->tree.leaf_idx = c->tidx.p;
     c->tree.n_pad = n_pad; c->tree.height = height;
     c->tree_valid = true;
     return MI_OK;

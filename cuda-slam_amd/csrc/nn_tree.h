@@ -23,6 +23,7 @@ struct NnTreeView {
     // compact copies read by the default (per-lane) walk: fewer, fuller 16-byte loads per visit
     const float4* pairs;              // internal node p: the boxes of its two children in 3 float4 (48 B instead of 64):
                                       //   (l.lo.x l.lo.y l.lo.z l.hi.x) (l.hi.y l.hi.z r.lo.x r.lo.y) (r.lo.z r.hi.x r.hi.y r.hi.z)
+    const uint4* pairs_half;          // the same records in half precision, boxes rounded outwards: 2 x 16 bytes (experimental)
     const float4* leaf_soa;           // leaf f: x[TREE_LEAF], y[TREE_LEAF], z[TREE_LEAF] (3*TREE_LEAF/4 float4; no index word)
     const int* leaf_idx;              // GLOBAL index of sorted slot s (read only for the winner and on exact ties)
 };
@@ -46,6 +47,7 @@ struct TreeBuildArgs {
     float4* pts;
     float4* boxes;                    // 2 * (2*n_pad - 1) float4
     float4* pairs;                    // 3 * (n_pad - 1) float4
+    uint4* pairs_half;                // 2 * (n_pad - 1) uint4, or null
     float4* leaf_soa;                 // n_leaves * 3 * TREE_LEAF / 4 float4
     int* leaf_idx;                    // n_leaves * TREE_LEAF
 };

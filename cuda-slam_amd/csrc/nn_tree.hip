@@ -204,6 +204,66 @@ __global__ __launch_bounds__(256) void tree_pack_pairs_kernel(const float4* __re
     pairs[3 * (size_t)p + 2] = make_float4(rlo.z, rhi.x, rhi.y, rhi.z);
 }
 
+// Sibling-box records in half precision: 12 values in 24 of 32 bytes (2 loads instead of 3).  A value w of axis a is stored as
+// h ~ (w - c_a) / s_a (c, s: centre and half-extent of the root box, so |h| <= 1 and the grid is 2^-11 of the extent at
+// worst) and decoded as fma(float(h), s_a, c_a).  Lower corners are rounded DOWN and upper corners UP until the DECODED value
+// is on the outer side of w, so a decoded box always contains the exact one: the walk's bound stays a lower bound (the same
+// monotonicity argument as for the fp32 boxes), it only prunes a hair less.
+__device__ __forceinline__ void tree_half_frame(const float4 root_lo, const float4 root_hi, float c[3], float s[3])
+{
+    const float lo[3] = {root_lo.x, root_lo.y, root_lo.z}, hi[3] = {root_hi.x, root_hi.y, root_hi.z};
+    for (int a = 0; a < 3; a++) {
+        c[a] = 0.5f * (lo[a] + hi[a]);
+        const float e = 0.5f * (hi[a] - lo[a]);
+        s[a] = e > 0.f ? e : 1.0f;
+    }
+}
+
+__device__ __forceinline__ unsigned short half_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
+__device__ __forceinline__ _Float16 half_from_bits(unsigned short b) { return __builtin_bit_cast(_Float16, b); }
+// next representable half towards -inf / +inf (finite input)
+__device__ __forceinline__ _Float16 half_next(_Float16 h, bool up)
+{
+    unsigned short b = half_bits(h);
+    const bool neg = (b & 0x8000u) != 0;
+    if ((b & 0x7fffu) == 0) return half_from_bits(up ? 0x0001u : 0x8001u);
+    if (neg == up) b -= 1; else b += 1;      // moving towards zero shrinks the magnitude
+    return half_from_bits(b);
+}
+
+__device__ __forceinline__ _Float16 tree_encode_half(float w, float c, float s, bool upper)
+{
+    const float u = (w - c) / s;
+    _Float16 h = (_Float16)u;                                  // round to nearest; then walk outwards as far as needed
+    if (!(u - u == 0.f)) return h;                             // +-inf (empty padding boxes) and NaN pass through
+    for (int guard = 0; guard < 8; guard++) {
+        const float d = __builtin_fmaf((float)h, s, c);
+        if (upper ? d >= w : d <= w) break;
+        h = half_next(h, upper);
+    }
+    return h;
+}
+
+__global__ __launch_bounds__(256) void tree_pack_pairs_half_kernel(const float4* __restrict__ boxes, int n_internal, uint4* __restrict__ out)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_internal) return;
+    float c[3], s[3];
+    tree_half_frame(boxes[0], boxes[1], c, s);
+    const int l = 2 * p + 1;
+    const float4 b4[4] = {boxes[2 * (size_t)l], boxes[2 * (size_t)l + 1], boxes[2 * (size_t)l + 2], boxes[2 * (size_t)l + 3]};
+    unsigned short h[16] = {0};
+    for (int q = 0; q < 4; q++) {                              // l.lo, l.hi, r.lo, r.hi
+        const float w[3] = {b4[q].x, b4[q].y, b4[q].z};
+        for (int a = 0; a < 3; a++) h[3 * q + a] = half_bits(tree_encode_half(w[a], c[a], s[a], (q & 1) != 0));
+    }
+    uint4 r0, r1;
+    r0.x = h[0] | ((unsigned)h[1] << 16); r0.y = h[2] | ((unsigned)h[3] << 16); r0.z = h[4] | ((unsigned)h[5] << 16); r0.w = h[6] | ((unsigned)h[7] << 16);
+    r1.x = h[8] | ((unsigned)h[9] << 16); r1.y = h[10] | ((unsigned)h[11] << 16); r1.z = 0; r1.w = 0;
+    out[2 * (size_t)p] = r0;
+    out[2 * (size_t)p + 1] = r1;
+}
+
 __global__ __launch_bounds__(256) void tree_pack_leaves_kernel(const float4* __restrict__ pts, int n_slots, float* __restrict__ soa,
                                                                int* __restrict__ idx)
 {
@@ -227,8 +287,11 @@ hipError_t tree_build(const TreeBuildArgs& a, hipStream_t s)
     hipLaunchKernelGGL(tree_leaf_box_kernel, dim3((a.n_pad + 255) / 256), dim3(256), 0, s, a.pts, a.n_leaves, a.n_pad, a.boxes);
     for (int count = a.n_pad / 2; count >= 1; count /= 2)   // levels bottom-up: nodes [count-1, 2*count-1)
         hipLaunchKernelGGL(tree_level_kernel, dim3((count + 255) / 256), dim3(256), 0, s, count - 1, count, a.boxes);
-    if (a.n_pad > 1)
+    if (a.n_pad > 1) {
         hipLaunchKernelGGL(tree_pack_pairs_kernel, dim3((a.n_pad - 1 + 255) / 256), dim3(256), 0, s, a.boxes, a.n_pad - 1, a.pairs);
+        if (a.pairs_half)
+            hipLaunchKernelGGL(tree_pack_pairs_half_kernel, dim3((a.n_pad - 1 + 255) / 256), dim3(256), 0, s, a.boxes, a.n_pad - 1, a.pairs_half);
+    }
     hipLaunchKernelGGL(tree_pack_leaves_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, a.pts, n_slots, reinterpret_cast<float*>(a.leaf_soa),
                        a.leaf_idx);
     return hipGetLastError();
@@ -471,7 +534,7 @@ __global__ __launch_bounds__(256) void nn_tree_lane_kernel(const float4* __restr
 // (counters: ~12 line accesses per load instruction), so fewer loads per visit is what pays.  The winner is
 // tracked by its sorted SLOT; the global index is fetched once at the end -- and on an exact tie, where the lower GLOBAL index
 // must win (rare: duplicates, or the posted starting candidate met again).
-template <bool FMA>
+template <bool FMA, bool HALF>
 __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t, const float* __restrict__ sx, const float* __restrict__ sy,
                                                                    const float* __restrict__ sz, int n, unsigned long long* __restrict__ keys,
                                                                    const int* __restrict__ done_flag, int stack_depth)
@@ -485,6 +548,9 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
     float* st_lb = reinterpret_cast<float*>(smem);
     (void)stack_depth;
     const float4* __restrict__ pairs = t.pairs;
+    const uint4* __restrict__ pairs_half = t.pairs_half;
+    float hc[3] = {0.f, 0.f, 0.f}, hs[3] = {1.f, 1.f, 1.f};
+    if (HALF) tree_half_frame(t.boxes[0], t.boxes[1], hc, hs);
     const float4* __restrict__ leaf_soa = t.leaf_soa;
     const int* __restrict__ leaf_idx = t.leaf_idx;
 
@@ -528,10 +594,24 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
     };
     while (have) {
         while (have && node < first_leaf) {
-            const float4* __restrict__ rec = pairs + 3 * (size_t)node;
-            const float4 a = rec[0], b = rec[1], c = rec[2];
-            const float lbl = box_bound<FMA>(make_float4(a.x, a.y, a.z, 0.f), make_float4(a.w, b.x, b.y, 0.f), p, p);
-            const float lbr = box_bound<FMA>(make_float4(b.z, b.w, c.x, 0.f), make_float4(c.y, c.z, c.w, 0.f), p, p);
+            float lbl, lbr;
+            if (HALF) {
+                typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                const uint4 r0 = pairs_half[2 * (size_t)node], r1 = pairs_half[2 * (size_t)node + 1];
+                const h8 u = __builtin_bit_cast(h8, r0), w = __builtin_bit_cast(h8, r1);
+                const float v[12] = {(float)u[0], (float)u[1], (float)u[2], (float)u[3], (float)u[4], (float)u[5],
+                                     (float)u[6], (float)u[7], (float)w[0], (float)w[1], (float)w[2], (float)w[3]};
+                float d[12];
+#pragma unroll
+                for (int q = 0; q < 12; q++) d[q] = __builtin_fmaf(v[q], hs[q % 3], hc[q % 3]);
+                lbl = box_bound<FMA>(make_float4(d[0], d[1], d[2], 0.f), make_float4(d[3], d[4], d[5], 0.f), p, p);
+                lbr = box_bound<FMA>(make_float4(d[6], d[7], d[8], 0.f), make_float4(d[9], d[10], d[11], 0.f), p, p);
+            } else {
+                const float4* __restrict__ rec = pairs + 3 * (size_t)node;
+                const float4 a = rec[0], b = rec[1], c = rec[2];
+                lbl = box_bound<FMA>(make_float4(a.x, a.y, a.z, 0.f), make_float4(a.w, b.x, b.y, 0.f), p, p);
+                lbr = box_bound<FMA>(make_float4(b.z, b.w, c.x, 0.f), make_float4(c.y, c.z, c.w, 0.f), p, p);
+            }
             const int l = 2 * node + 1;
             const bool left_near = lbl <= lbr;
             const float lbn = left_near ? lbl : lbr, lbf = left_near ? lbr : lbl;
@@ -643,11 +723,22 @@ hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, 
         const int depth = t.height + 2;
         const size_t lds = (size_t)depth * 256 * 8;
         dim3 grid((n + 255) / 256), block(256);
-        static const bool compact = [] { const char* v = getenv("MISLAM_TREE_COMPACT"); return !(v && *v == '0'); }();
+        const char* compact_env = getenv("MISLAM_TREE_COMPACT");      // read per call: the tests flip these
+        const bool compact = !(compact_env && *compact_env == '0');
         if (compact && t.pairs != nullptr) {   // same walk over the compact copies (default)
             const size_t lds_c = (size_t)(t.height + 1) * 256 * sizeof(float);      // one bound per level and lane
-            if (fma) hipLaunchKernelGGL(nn_tree_lane_compact_kernel<true>, grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, depth);
-            else hipLaunchKernelGGL(nn_tree_lane_compact_kernel<false>, grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, depth);
+            // half-precision sibling records (2 loads instead of 3 per node; exact all the same, 62 parity tests): measured
+            // SLOWER, 1.18 against 1.13 ms per search at N = M = 1e6 -- the 24 extra decode instructions per node cost more than
+            // the 16 bytes save.  Kept as a tested alternative.
+            const char* half_env = getenv("MISLAM_TREE_HALF");
+            const bool half_nodes = half_env && *half_env == '1';
+            if (half_nodes && t.pairs_half != nullptr) {
+                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, depth);
+                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, depth);
+            } else {
+                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, depth);
+                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, depth);
+            }
             return hipGetLastError();
         }
         if (fma) hipLaunchKernelGGL(nn_tree_lane_kernel<true>, grid, block, lds, s, t.pts, t.boxes, t.n_pad, sx, sy, sz, n, keys, done_flag, depth);

@@ -86,12 +86,15 @@ def test_tree_equals_bruteforce_on_clustered_and_degenerate_clouds(ctx, capi, mo
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
 
 
-@pytest.mark.parametrize("tree_r", ["-1", "1", "2"])
+@pytest.mark.parametrize("variant", ["R=-1", "R=1", "R=2", "COMPACT=0", "HALF=1"])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_alternative_hierarchy_walks_are_exact_too(ctx, capi, oracle, monkeypatch, tree_r, mode):
-    # the alternative query forms: -1 = per-lane stackless trail walk (the default is the per-lane walk with an LDS stack);
-    # 1, 2 = one walk per wave (scalar loads, stack across the lanes of a VGPR)
-    monkeypatch.setenv("MISLAM_TREE_R", tree_r)
+def test_alternative_hierarchy_walks_are_exact_too(ctx, capi, oracle, monkeypatch, variant, mode):
+    # the alternative query forms (the default is the per-lane walk over the compact copies, register trail + bounds in LDS):
+    # R=-1 per-lane stackless trail walk over the float4 records; R=1, 2 one walk per wave (scalar loads, stack across the lanes
+    # of a VGPR); COMPACT=0 the per-lane walk with a (node, bound) stack over the float4 records; HALF=1 the default walk over
+    # half-precision sibling boxes rounded outwards
+    name, value = variant.split("=")
+    monkeypatch.setenv("MISLAM_TREE_" + name, value)
     rng = np.random.default_rng(31)
     base = rng.uniform(-5, 5, (6000, 3)).astype(np.float32)
     tgt = np.concatenate([base, base[:2000]])                       # duplicates: ties
