@@ -209,6 +209,31 @@ def test_cfg2_size_properties(ctx, capi, oracle):
     assert frob(R1, t1, R64, ca - R64 @ cb) < 5e-6
 
 
+def test_full_bench_size_iterations(ctx, capi):
+    # BASELINE.json's headline configuration (N = M = 1e6, the bench workload): the first iterations through both searches are
+    # bitwise the same registration, the error falls monotonically, and one iteration equals an fp64 Kabsch solve of its pairs
+    before, after, Rt, tt = synth_cloud(1000000)
+    runs = []
+    for nn_mode in (capi.NN_TREE, capi.NN_BRUTEFORCE):
+        ctx.icp_load(before, after, capi.icp_params(max_iterations=3, nn_mode=nn_mode))
+        errs = []
+        for _ in range(3):
+            ctx.icp_run(1)
+            errs.append(ctx.icp_result()[3])
+        runs.append((ctx.icp_result(), errs))
+    (ra, ea), (rb, eb) = runs
+    assert ea == eb and np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+    assert ea[0] > ea[1] > ea[2]
+    R1, t1, it1, e1 = ctx.icp_register(before, after, capi.icp_params(max_iterations=1))
+    idx, _ = ctx.nn_search(before, after)
+    B, A = before.astype(np.float64), after[idx].astype(np.float64)
+    cb, ca = B.mean(0), A.mean(0)
+    U, S, Vt = np.linalg.svd((A - ca).T @ (B - cb))
+    R64 = U @ np.diag([1.0, 1.0, np.sign(np.linalg.det(U @ Vt))]) @ Vt
+    assert it1 == 1 and frob(R1, t1, R64, ca - R64 @ cb) < 5e-6
+    assert abs(e1 - float((np.linalg.norm(A - (B @ R1.astype(np.float64).T + t1), axis=1) ** 2).mean())) < 1e-5 * e1
+
+
 @pytest.mark.parametrize("n,iters", [(20000, 1), (20000, 6), (40000, 3), (100000, 2)])   # the last one is cfg 2's size
 def test_cpu_sequential_sums_retrace_cpu_slam_beyond_bunny_size(ctx, capi, oracle, n, iters):
     # MI_SUM_CPU_SEQUENTIAL: cpu-slam's sequential fp32 centroid / error sums reproduced bit for bit.  With them the HIP path

@@ -124,6 +124,27 @@ def test_large_sampled_rows_and_properties(ctx, capi, oracle):
     assert np.array_equal(sidx, np.arange(len(after))) and np.all(sd2 == 0)
 
 
+def test_full_bench_size_properties(ctx, capi, oracle):
+    # BASELINE.json's headline size (N = M = 1e6): the box hierarchy against ALL 1e12 pairs of the every-pair kernel (which is
+    # pinned to the oracle above), sampled rows against the oracle itself, and the size-independent properties
+    before, after, Rm, tm = synth_cloud(1000000)
+    idx, d2 = ctx.nn_search(before, after, 0, capi.NN_TREE)
+    bidx, bd2 = ctx.nn_search(before, after, 0, capi.NN_BRUTEFORCE)
+    assert np.array_equal(idx, bidx) and np.array_equal(d2.view(np.uint32), bd2.view(np.uint32))
+    rows = np.random.default_rng(1).choice(len(before), 64, replace=False)
+    ridx, rd2 = oracle.nn_search(before[rows], after)
+    assert np.array_equal(idx[rows], ridx) and np.array_equal(d2[rows].view(np.uint32), rd2.view(np.uint32))
+    diff = after[idx] - before
+    assert np.array_equal(((diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]).view(np.uint32),
+                          d2.view(np.uint32))
+    # searching the registered cloud finds every point's own image: the permutation is recovered exactly
+    moved = (before.astype(np.float64) @ Rm.astype(np.float64).T + tm.astype(np.float64)).astype(np.float32)
+    pidx, pd2 = ctx.nn_search(moved, after)
+    assert len(np.unique(pidx)) == len(after) and float(pd2.max()) < 1e-8
+    sidx, sd2 = ctx.nn_search(after, after)
+    assert np.array_equal(sidx, np.arange(len(after))) and np.all(sd2 == 0)
+
+
 def test_rejects_bad_arguments(ctx, capi):
     with pytest.raises(capi.MiSlamError):
         ctx.nn_search(np.zeros((4, 3), np.float32), np.zeros((0, 3), np.float32))
