@@ -145,6 +145,22 @@ def test_full_bench_size_properties(ctx, capi, oracle):
     assert np.array_equal(sidx, np.arange(len(after))) and np.all(sd2 == 0)
 
 
+def test_ten_million_points(ctx, capi, oracle):
+    # the largest size BASELINE.json lists (N = M = 1e7): sampled rows against the oracle, the distance really is the distance to
+    # the reported index, and the registered cloud finds every point's own image
+    before, after, Rm, tm = synth_cloud(10000000)
+    idx, d2 = ctx.nn_search(before, after)
+    rows = np.random.default_rng(2).choice(len(before), 32, replace=False)
+    ridx, rd2 = oracle.nn_search(before[rows], after)
+    assert np.array_equal(idx[rows], ridx) and np.array_equal(d2[rows].view(np.uint32), rd2.view(np.uint32))
+    diff = after[idx] - before
+    assert np.array_equal(((diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]).view(np.uint32),
+                          d2.view(np.uint32))
+    moved = (before.astype(np.float64) @ Rm.astype(np.float64).T + tm.astype(np.float64)).astype(np.float32)
+    pidx, pd2 = ctx.nn_search(moved, after)
+    assert np.array_equal(np.sort(pidx), np.arange(len(after))) and float(pd2.max()) < 1e-8
+
+
 def test_rejects_bad_arguments(ctx, capi):
     with pytest.raises(capi.MiSlamError):
         ctx.nn_search(np.zeros((4, 3), np.float32), np.zeros((0, 3), np.float32))
