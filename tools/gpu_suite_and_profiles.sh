@@ -7,9 +7,9 @@ step pytest_gpu timeout -k 10 900 python -m pytest tests -m gpu -q -s --timeout 
 step smoke timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()"
 step bench_default timeout -k 10 300 python bench.py
 rm -rf gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write
-step prof_stats timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --brute-ref-steps 2
-step prof_fetch timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_fetch --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --brute-ref-steps 1
-step prof_write timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof_write --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --brute-ref-steps 1
+step prof_stats timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats --output-format csv -- python3 bench.py --steps 50 --warmup 2 --no-cpu-baseline --brute-ref-steps 2
+step prof_fetch timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_fetch --output-format csv -- python3 bench.py --steps 50 --warmup 2 --no-cpu-baseline --brute-ref-steps 1
+step prof_write timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof_write --output-format csv -- python3 bench.py --steps 50 --warmup 2 --no-cpu-baseline --brute-ref-steps 1
 python tools/pmc_summary.py gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/hbm_counters.json
 f=$(find gpurun_out/prof_stats -name '*kernel_stats.csv' | head -1); cp "$f" gpurun_out/bench_kernel_stats.csv
 find gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write -type f ! -name '*stats*' -delete

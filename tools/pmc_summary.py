@@ -32,7 +32,7 @@ def main():
     fetch, write = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
     n = 1000000
     doc = {
-        "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --brute-ref-steps 1",
+        "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 50 --warmup 2 --no-cpu-baseline --brute-ref-steps 1",
         "workload": "icp_synthetic_uniform_n%d" % n,
         "correction": "MI355X_MICROARCH.md HBM section: counters are in KB; gfx950 FETCH_SIZE counts 64 B per 128 B request, so x2 on "
                       "the read side (calibrated there for 16 B/lane streams; other widths uncalibrated)",
