@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Developer tool: what one rank of a W-GPU run sees -- the box-hierarchy search for N/W moving points against the whole 10^6
+fixed cloud (the moving cloud is what the ranks split), 50 iterations after 2 warm-up ones."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+from bench import synth_cloud  # noqa: E402
+
+
+def main():
+    capi = load_package().capi
+    ctx = capi.Context(0)
+    before, after = synth_cloud(np, 1000000)
+    for w in (1, 2, 4, 8):
+        n = len(before) // w
+        ctx.icp_load(before[:n], after, capi.icp_params(eps=0.0, max_iterations=-1))
+        ctx.icp_run(2)
+        ctx.profile_enable(True)
+        ctx.profile_select([capi.KERNEL_NN])
+        ctx.profile_reset()
+        ctx.icp_run(50)
+        ms, launches = ctx.profile_get(capi.KERNEL_NN)
+        ctx.profile_select(None)
+        ctx.profile_reset()
+        ctx.icp_run(5)
+        rest = sum(ctx.profile_get(k)[0] / 5 for k in (capi.KERNEL_MOMENTS, capi.KERNEL_SOLVE, capi.KERNEL_TRANSFORM, capi.KERNEL_FINALIZE))
+        ctx.profile_enable(False)
+        print(json.dumps({"ranks": w, "moving_points_per_rank": n, "search_ms": ms / launches, "other_kernels_ms": rest}), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
