@@ -268,9 +268,9 @@ def main():
                        "dist_arithmetic": "cpu_rounding" if args.dist_mode == 0 else "fma",
                        "compose": "cpu_additive",
                        "parallelism": ("single GPU" if world == 1 else
-                                       "moving cloud sharded x%d, fixed cloud replicated, RCCL 16+2-double sum all-reduces" % world
+                                       "moving cloud sharded x%d, fixed cloud replicated, one 18-double RCCL sum all-reduce per iteration" % world
                                        if source_sharded else
-                                       "fixed cloud sharded x%d, RCCL u64-min all-reduce of the packed keys + 16+2-double sums" % world),
+                                       "fixed cloud sharded x%d, RCCL u64-min all-reduce of the packed keys + one 18-double sum per iteration" % world),
                        "error_after_steps": err},
             "roofline": nn_figures(prof["nn"][0], prof["nn"][1], not used_tree),
             "kernels_ms_per_step": breakdown,     # ms per launch, from the untimed follow-up iterations (every kernel event-timed)

@@ -167,6 +167,8 @@ __device__ void mat3_mul_cm(const float a[9], const float b[9], float out[9])
     for (int i = 0; i < 9; i++) out[i] = r[i];
 }
 
+__device__ void apply_solve(IcpState* __restrict__ state, const double* mom, int compose_mode, int seq_sums);
+
 __global__ __launch_bounds__(256) void icp_solve_kernel(IcpState* __restrict__ state, const double* __restrict__ partials, int nblocks,
                                                         int compose_mode, int seq_sums)
 {
@@ -182,6 +184,12 @@ __global__ __launch_bounds__(256) void icp_solve_kernel(IcpState* __restrict__ s
     if (threadIdx.x != 0) return;
     if (partials != nullptr)
         for (int i = 0; i < ICP_MOMENTS; i++) state->mom[i] = mom[i];
+    apply_solve(state, mom, compose_mode, seq_sums);
+}
+
+// Kabsch solve of the moments + composition with the running transform (one lane)
+__device__ void apply_solve(IcpState* __restrict__ state, const double* mom, int compose_mode, int seq_sums)
+{
     state->pairs = (int)mom[0];
     if (mom[0] <= 0.0) {   // "if (correspondingPoints.size() == 0) break;"  basicicp.cpp:36
         state->done = 1;
@@ -333,6 +341,8 @@ __global__ __launch_bounds__(256) void invert_order_kernel(const int* __restrict
 // ---------------------------------------------------------------------------------------------------------------
 // K6: error + stop rules.
 // ---------------------------------------------------------------------------------------------------------------
+__device__ void finalize_iteration(IcpState* __restrict__ state, double e0, double e1, const IcpRules& rules);
+
 __global__ __launch_bounds__(256) void icp_finalize_kernel(IcpState* __restrict__ state, const double* __restrict__ partials, int nblocks,
                                                            IcpRules rules)
 {
@@ -348,6 +358,13 @@ __global__ __launch_bounds__(256) void icp_finalize_kernel(IcpState* __restrict_
     if (threadIdx.x != 0) return;
     state->err[0] = e[0];
     state->err[1] = e[1];
+    finalize_iteration(state, e[0], e[1], rules);
+}
+
+// error of the iteration just applied + the stop rules (one lane)
+__device__ void finalize_iteration(IcpState* __restrict__ state, double e0, double e1, const IcpRules& rules)
+{
+    const double e[2] = {e0, e1};
     // cpu-slam: mean over the surviving pairs (common.cpp:267); cuda-slam: sum / after.size() (cudacommon.cu:147)
     const double denom = rules.filter_pairs ? e[1] : (double)rules.m_total;
     float error = (float)(e[0] / denom);
@@ -378,8 +395,59 @@ __global__ __launch_bounds__(256) void icp_finalize_kernel(IcpState* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// multi-GPU path with one all-reduce per iteration (kernels.h): the error sums of iteration i ride with the moments of i+1
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void icp_post_error_kernel(IcpState* __restrict__ state, const double* __restrict__ partials, int nblocks)
+{
+    if (state->done != 0) return;
+    __shared__ double lds[256];
+    double e[ICP_ERRSUMS];
+    reduce_partials<ICP_ERRSUMS>(partials, nblocks, e, lds);
+    if (threadIdx.x < ICP_ERRSUMS) state->err[threadIdx.x] = e[threadIdx.x];
+    if (threadIdx.x == 0) state->err_pending = 1;
+}
+
+__global__ void icp_solve_deferred_kernel(IcpState* __restrict__ state, int compose_mode, IcpRules rules)
+{
+    if (threadIdx.x != 0 || state->done != 0) return;
+    if (state->err_pending) {            // the previous iteration's error has just been all-reduced together with the moments
+        state->err_pending = 0;
+        finalize_iteration(state, state->err[0], state->err[1], rules);
+        if (state->done != 0) return;    // its stop rule fired: this iteration's search and moments were in vain, nothing is applied
+    }
+    double mom[ICP_MOMENTS];
+    for (int i = 0; i < ICP_MOMENTS; i++) mom[i] = state->mom[i];
+    apply_solve(state, mom, compose_mode, 0);
+}
+
+__global__ void icp_finalize_pending_kernel(IcpState* __restrict__ state, IcpRules rules)
+{
+    if (threadIdx.x != 0 || state->done != 0 || !state->err_pending) return;
+    state->err_pending = 0;
+    finalize_iteration(state, state->err[0], state->err[1], rules);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------------------------
+hipError_t icp_post_error(IcpState* state, const double* partials, int nblocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(icp_post_error_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks);
+    return hipGetLastError();
+}
+
+hipError_t icp_solve_deferred(IcpState* state, int compose_mode, const IcpRules& rules, hipStream_t s)
+{
+    hipLaunchKernelGGL(icp_solve_deferred_kernel, dim3(1), dim3(64), 0, s, state, compose_mode, rules);
+    return hipGetLastError();
+}
+
+hipError_t icp_finalize_pending(IcpState* state, const IcpRules& rules, hipStream_t s)
+{
+    hipLaunchKernelGGL(icp_finalize_pending_kernel, dim3(1), dim3(64), 0, s, state, rules);
+    return hipGetLastError();
+}
+
 static inline int blocks_for(int n, int cap)
 {
     int b = (n + 255) / 256;

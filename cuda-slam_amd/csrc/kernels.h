@@ -52,7 +52,7 @@ struct IcpState {
     int done;
     int stop_reason;
     int pairs;               // correspondences kept in the last solve (this rank's share in the multi-GPU path)
-    int pad_;
+    int err_pending;         // multi-GPU: err[] holds the last iteration's sums and its stop rule has not been evaluated yet
     double mom[ICP_MOMENTS];
     double err[ICP_ERRSUMS];
     // MI_SUM_CPU_SEQUENTIAL only: cpu-slam's own sequential fp32 running sums over the kept pairs in the caller's order
@@ -101,6 +101,13 @@ hipError_t icp_solve(IcpState* state, const double* partials, int nblocks, int c
 // starts from a tight bound and hardly ever takes its re-scan path)
 hipError_t icp_transform_error(const IcpView& v, double* partials, int nblocks, int rearm, hipStream_t s);
 hipError_t icp_finalize(IcpState* state, const double* partials, int nblocks, const IcpRules& rules, hipStream_t s);
+// Multi-GPU path with ONE all-reduce per iteration: an iteration's error sums wait in state->err (icp_post_error marks them
+// pending) and travel with the NEXT iteration's moments (mom[16] and err[2] are contiguous: one 18-double all-reduce).
+// icp_solve_deferred first evaluates the pending stop rule, then -- unless it fired -- solves from state->mom;
+// icp_finalize_pending does the same evaluation alone (after a last all-reduce of err) when the host stops enqueuing.
+hipError_t icp_post_error(IcpState* state, const double* partials, int nblocks, hipStream_t s);
+hipError_t icp_solve_deferred(IcpState* state, int compose_mode, const IcpRules& rules, hipStream_t s);
+hipError_t icp_finalize_pending(IcpState* state, const IcpRules& rules, hipStream_t s);
 // MI_SUM_CPU_SEQUENTIAL: cpu-slam's sequential fp32 running sums, reproduced bit for bit (one wave per sum)
 hipError_t invert_order(const int* order, int n, int* inv, hipStream_t s);
 hipError_t icp_seq_centroids(const IcpView& v, hipStream_t s);

@@ -564,12 +564,36 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
 }
 
 // One loop body of basicicp.cpp:32-57 / icpcuda.cu:31-54, enqueued without host synchronisation.
+static IcpRules icp_rules(const mi_ctx* c)
+{
+    IcpRules rules{};
+    rules.eps = c->icp.eps;
+    rules.max_iterations = c->icp.max_iterations;
+    rules.filter_pairs = c->icp.filter_pairs;
+    rules.abort_on_increase = c->icp.abort_on_increase;
+    rules.m_total = c->m_total;
+    rules.seq_sums = c->icp.sum_mode == MI_SUM_CPU_SEQUENTIAL;
+    return rules;
+}
+
+// Multi-GPU: the error sums of the last enqueued iteration are still waiting for their all-reduce (they normally travel with the
+// next iteration's moments).  Called when the host stops enqueuing and wants the state.
+static int icp_flush_pending(mi_ctx* c)
+{
+    if (!c->comm) return MI_OK;
+    ProfScope ps(c, MI_KERNEL_FINALIZE);
+    MI_TRY(allreduce_doubles(c, c->d_state->err, ICP_ERRSUMS));
+    MI_HIP(icp_finalize_pending(c->d_state, icp_rules(c), c->stream));
+    return MI_OK;
+}
+
 static int icp_enqueue_iteration(mi_ctx* c)
 {
     const IcpView v = make_view(c);
     const int m_local = c->shard_hi - c->shard_lo;
     const int nb = icp_reduce_blocks(c->n);
     const int nbp = icp_reduce_blocks(c->n_pad);
+    const IcpRules rules = icp_rules(c);
     // K1 (+ C1)
     MI_TRY(launch_nn(c, c->cx.p, c->cy.p, c->cz.p, c->n, m_local, c->shard_lo, v.fma, &c->d_state->done, c->icp.nn_mode));
     if (!c->source_sharded) MI_TRY(allreduce_keys(c, c->n));   // source-sharded ranks hold disjoint moving points: nothing to merge
@@ -578,10 +602,13 @@ static int icp_enqueue_iteration(mi_ctx* c)
     { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_moments(v, c->part_mom.p, nb, c->stream)); }
     if (seq) { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_seq_centroids(v, c->stream)); }
     if (c->comm) {
+        // ONE all-reduce per iteration: this iteration's 16 moments and the previous iteration's 2 error sums (contiguous in the
+        // state block); the solve kernel first settles the previous iteration's stop rule (kernels.h)
+        static_assert(offsetof(IcpState, err) == offsetof(IcpState, mom) + sizeof(double) * ICP_MOMENTS, "mom and err must be contiguous");
         ProfScope ps(c, MI_KERNEL_SOLVE);
         MI_HIP(icp_reduce_moments(c->d_state, c->part_mom.p, nb, c->stream));
-        MI_TRY(allreduce_doubles(c, c->d_state->mom, ICP_MOMENTS));
-        MI_HIP(icp_solve(c->d_state, nullptr, 0, c->icp.compose_mode, 0, c->stream));
+        MI_TRY(allreduce_doubles(c, c->d_state->mom, ICP_MOMENTS + ICP_ERRSUMS));
+        MI_HIP(icp_solve_deferred(c->d_state, c->icp.compose_mode, rules, c->stream));
     } else {
         ProfScope ps(c, MI_KERNEL_SOLVE);
         MI_HIP(icp_solve(c->d_state, c->part_mom.p, nb, c->icp.compose_mode, seq, c->stream));
@@ -589,18 +616,9 @@ static int icp_enqueue_iteration(mi_ctx* c)
     // K4+K5, K6
     { ProfScope ps(c, MI_KERNEL_TRANSFORM); MI_HIP(icp_transform_error(v, c->part_err.p, nbp, 2, c->stream)); }
     if (seq) { ProfScope ps(c, MI_KERNEL_TRANSFORM); MI_HIP(icp_seq_error(v, c->stream)); }
-    IcpRules rules{};
-    rules.eps = c->icp.eps;
-    rules.max_iterations = c->icp.max_iterations;
-    rules.filter_pairs = c->icp.filter_pairs;
-    rules.abort_on_increase = c->icp.abort_on_increase;
-    rules.m_total = c->m_total;
-    rules.seq_sums = seq;
     if (c->comm) {
         ProfScope ps(c, MI_KERNEL_FINALIZE);
-        MI_HIP(icp_reduce_error(c->d_state, c->part_err.p, nbp, c->stream));
-        MI_TRY(allreduce_doubles(c, c->d_state->err, ICP_ERRSUMS));
-        MI_HIP(icp_finalize(c->d_state, nullptr, 0, rules, c->stream));
+        MI_HIP(icp_post_error(c->d_state, c->part_err.p, nbp, c->stream));      // stays local until the next all-reduce (or the flush)
     } else {
         ProfScope ps(c, MI_KERNEL_FINALIZE);
         MI_HIP(icp_finalize(c->d_state, c->part_err.p, nbp, rules, c->stream));
@@ -635,6 +653,7 @@ extern "C" int mi_icp_run(mi_ctx* c, int max_new_iterations, int* iterations_don
         int todo = batch;
         if (max_new_iterations >= 0) todo = std::min(todo, max_new_iterations - enqueued);
         for (int b = 0; b < todo; b++) MI_TRY(icp_enqueue_iteration(c));
+        MI_TRY(icp_flush_pending(c));
         enqueued += todo;
         const int shown = c->h_state->passes;
         MI_TRY(icp_fetch_state(c));

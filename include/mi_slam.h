@@ -59,7 +59,7 @@ enum {
  *           N packed (min-dist, argmin) keys per iteration, then owner-accumulated moments/error + two small sum all-reduces.
  *           The every-pair search scales perfectly this way (its work is N*M/W per rank).
  *   SOURCE: rank r owns moving points [N*r/W, N*(r+1)/W) and a replica of the fixed cloud (12 B/point: trivial at 288 GB);
- *           no per-point exchange at all, only the 16- and 2-double sum all-reduces.  The box-hierarchy search needs this
+ *           no per-point exchange at all, only one 18-double sum all-reduce per iteration.  The box-hierarchy search needs this
  *           split to scale: its cost per moving point hardly depends on how many fixed points a rank holds.
  *   AUTO:   SOURCE when the search runs through the box hierarchy, TARGET when it is the every-pair search. */
 enum {

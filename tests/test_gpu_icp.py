@@ -277,3 +277,23 @@ def test_world1_rccl_context_matches_plain_context(capi, bunny):
         i1, d1 = dctx.nn_search(before[:1000], after)
         i2, d2 = sctx.nn_search(before[:1000], after)
         assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+        # The multi-GPU path settles an iteration's stop rule one all-reduce later (its error sums ride with the next iteration's
+        # moments; a flush closes every host batch).  Same iteration counts, errors and stop reasons as the plain context: a run
+        # to convergence, the GPU reference's rules (abort + rollback on an error increase), the iteration cap, any host batch
+        # size, and a run enqueued in pieces.
+        for kw in (dict(eps=1e-3, max_iterations=50, max_distance_squared=400.0), dict(cuda_slam=True, max_iterations=60),
+                   dict(max_iterations=7), dict(eps=1e-3, max_iterations=50, max_distance_squared=400.0, sync_every=1),
+                   dict(eps=1e-3, max_iterations=50, max_distance_squared=400.0, sync_every=3)):
+            cuda = kw.pop("cuda_slam", False)
+            a = dctx.icp_register(before, after, capi.icp_params(cuda_slam=cuda, **kw))
+            b = sctx.icp_register(before, after, capi.icp_params(cuda_slam=cuda, **kw))
+            assert a[2] == b[2] and a[3] == b[3] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), kw
+        for c in (dctx, sctx):
+            c.icp_load(before, after, capi.icp_params(eps=1e-3, max_iterations=50, max_distance_squared=400.0))
+            assert c.icp_run(5) == 5
+            mid = c.icp_result()
+            assert mid[2] == 5 and mid[4] == capi.STOP_RUNNING
+            c.icp_run(-1)
+        ra, rb = dctx.icp_result(), sctx.icp_result()
+        assert ra[2] == rb[2] == 39 and ra[3] == rb[3] and ra[4] == rb[4] == capi.STOP_CONVERGED
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
