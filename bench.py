@@ -4,16 +4,18 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--points P]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step is ONE ICP iteration of the hot path (brute-force nearest-neighbour search K1, [RCCL packed-min all-reduce C1],
-moments K2, SVD solve K3, transform + error K4/K5, stop rule K6) on clouds already resident in HBM.  The stop rule runs on
-the device every step but never fires (eps = 0), so every step does identical work.  With N > 1 the TARGET cloud is
-sharded over the ranks (strong scaling: the problem is fixed, so "scaling": "strong") and the per-point packed keys are
-all-reduced with ncclMin over xGMI inside libmislam.so; torch.distributed (gloo) is only the bootstrap / barrier / max.
+A step is ONE ICP iteration of the hot path (exact nearest-neighbour search -- K1t, the box hierarchy, at this size; K1, every
+pair, with --nn brute --, moments K2, SVD solve K3, transform + error K4/K5, stop rule K6) on clouds already resident in HBM.
+The stop rule runs on the device every step but never fires (eps = 0).  With N > 1 the problem is fixed ("scaling":
+"strong"): the moving cloud is sharded over the ranks for the box hierarchy (one 18-double RCCL sum all-reduce per iteration),
+the fixed cloud for the every-pair search (plus a ncclMin all-reduce of the packed keys), all inside libmislam.so over xGMI;
+torch.distributed (gloo) is only the bootstrap / barrier / max.
 
-Rank 0 prints one JSON line.  `roofline` is the NN kernel: algorithmic bytes (20*N + 12*M_local) over its
-HIP-event-timed average launch; `valu` gives the same launch against the fp32 vector-issue rate, which is what actually
-bounds a brute-force search.  `cpu_baseline` times the REFERENCE's own GetCorrespondingPoints (oracle/_ref, all host
-threads) on a bounded sample of source rows and scales it to a full iteration.
+Rank 0 prints one JSON line.  `roofline` is the search kernel of the timed steps: algorithmic bytes (20*N + 12*M_local, SURVEY
+8d) over its HIP-event-timed average launch; `bruteforce_nn` gives the every-pair kernel on the same clouds with `valu`, its
+launch against the fp32 vector-issue rate (what actually bounds a brute-force search); `cpd_bunny` is the CPD leg of the
+metric.  `cpu_baseline` times the REFERENCE's own GetCorrespondingPoints (oracle/_ref, all host threads) on a bounded sample of
+source rows and scales it to a full iteration.
 """
 import argparse
 import json

@@ -56,7 +56,7 @@ enum {
 
 /* What a multi-GPU context (mi_ctx_create_dist) splits across its ranks.  Same registration result either way.
  *   TARGET: rank r owns fixed points [M*r/W, M*(r+1)/W) and ALL moving points; one ncclAllReduce(ncclUint64, ncclMin) of the
- *           N packed (min-dist, argmin) keys per iteration, then owner-accumulated moments/error + two small sum all-reduces.
+ *           N packed (min-dist, argmin) keys per iteration, then owner-accumulated moments/error + one 18-double sum all-reduce.
  *           The every-pair search scales perfectly this way (its work is N*M/W per rank).
  *   SOURCE: rank r owns moving points [N*r/W, N*(r+1)/W) and a replica of the fixed cloud (12 B/point: trivial at 288 GB);
  *           no per-point exchange at all, only one 18-double sum all-reduce per iteration.  The box-hierarchy search needs this
