@@ -110,9 +110,10 @@ int mi_device_count(int* count);
 
 int mi_ctx_create(int device, mi_ctx** out);
 
-/* Multi-GPU, one process per GPU.  Rank r of `world` ranks owns targets [r*M/world, (r+1)*M/world) of the fixed cloud
- * and all source points; per ICP iteration the per-point packed (min-dist, argmin) keys are combined with ONE
- * ncclAllReduce(ncclUint64, ncclMin) over xGMI (no reference counterpart: the reference is single-GPU).
+/* Multi-GPU, one process per GPU (no reference counterpart: the reference is single-GPU).  What the ranks split is
+ * mi_icp_params.shard_mode (MI_SHARD_* above) for ICP -- with the fixed cloud sharded, the per-point packed (min-dist, argmin)
+ * keys are combined with ONE ncclAllReduce(ncclUint64, ncclMin) over xGMI per iteration -- and the fixed cloud for CPD.
+ * The library creates the communicator and issues every collective on its own stream.
  * unique_id is the 128-byte ncclUniqueId produced by mi_dist_unique_id() on rank 0 and shipped to the other ranks by
  * the caller's bootstrap (torch.distributed store, MPI, a socket ...). */
 #define MI_UNIQUE_ID_BYTES 128
