@@ -25,11 +25,13 @@ STOP_RUNNING, STOP_CONVERGED, STOP_MAX_ITERATIONS, STOP_NO_PAIRS, STOP_ERROR_INC
 KERNEL_NAMES = ["nn", "moments", "solve", "transform", "finalize", "allreduce", "cpd_denom", "cpd_contract", "cpd_mstep", "cpd_fgt"]
 CPD_APPROX_NONE, CPD_APPROX_FULL, CPD_APPROX_HYBRID = 0, 1, 2
 UNIQUE_ID_BYTES = 128
+EXCHANGE_MIN_U64, EXCHANGE_SUM_F64 = 0, 1
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)      # mi_exchange_fn
 
 # every symbol include/mi_slam.h declares (tests check that the library exports each of them)
 EXPORTS = [
     "mi_abi_version", "mi_last_error", "mi_device_count", "mi_ctx_create", "mi_dist_unique_id", "mi_ctx_create_dist",
-    "mi_ctx_rank", "mi_shard_range", "mi_pack_key", "mi_unpack_key", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_icp_params_default", "mi_icp_params_cuda_slam",
+    "mi_ctx_create_exchange", "mi_ctx_rank", "mi_shard_range", "mi_pack_key", "mi_unpack_key", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_icp_params_default", "mi_icp_params_cuda_slam",
     "mi_icp_register", "mi_icp_load", "mi_icp_reset", "mi_icp_run", "mi_icp_result", "mi_nn_search", "mi_nn_search_ex", "mi_kabsch",
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_estep",
     "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
@@ -178,12 +180,27 @@ def _T_to_Rt(T):
 
 
 class Context:
-    """mi_ctx handle.  Context(device) or Context(device, rank, world, unique_id) for the multi-GPU path."""
+    """mi_ctx handle.  Context(device), Context(device, rank, world, unique_id) for the multi-GPU path over RCCL, or
+    Context(device, rank, world, exchange=fn) for the same path over the caller's transport: fn(array, kind) combines the
+    numpy array (uint64 for EXCHANGE_MIN_U64, float64 for EXCHANGE_SUM_F64) in place across the ranks."""
 
-    def __init__(self, device=0, rank=None, world=None, unique_id=None):
+    def __init__(self, device=0, rank=None, world=None, unique_id=None, exchange=None):
         self._h = C.c_void_p()
+        self._exchange_cb = None
         if world is None:
             _check(lib().mi_ctx_create(device, C.byref(self._h)))
+        elif exchange is not None:
+            def trampoline(_user, buf, count, kind):
+                try:
+                    ctype = C.c_uint64 if kind == EXCHANGE_MIN_U64 else C.c_double
+                    exchange(np.ctypeslib.as_array(C.cast(buf, C.POINTER(ctype)), shape=(count,)), kind)
+                    return 0
+                except Exception:       # an exception must not unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._exchange_cb = EXCHANGE_FN(trampoline)      # kept alive with the context
+            _check(lib().mi_ctx_create_exchange(device, rank, world, self._exchange_cb, None, C.byref(self._h)))
         else:
             _check(lib().mi_ctx_create_dist(device, rank, world, unique_id, C.byref(self._h)))
 

@@ -81,6 +81,11 @@ struct mi_ctx {
     hipStream_t stream = nullptr;
     int rank = 0, world = 1;
     ncclComm_t comm = nullptr;
+    mi_exchange_fn exchange = nullptr;                   // the caller's transport instead of RCCL (mi_ctx_create_exchange)
+    void* exchange_user = nullptr;
+    void* exchange_host = nullptr;                       // pinned staging for it
+    size_t exchange_cap = 0;
+    bool distributed() const { return comm != nullptr || exchange != nullptr; }
     int cu_count = 256;
 
     // ---- workspace shared by the drivers
@@ -156,5 +161,9 @@ int upload_target_shard(mi_ctx* ctx, const float* after_xyz, int m_total, bool r
 // Correspondence search of n moving points (SoA, padded) against the loaded fixed-cloud shard into ctx->keys (K1 or K1t).
 int launch_nn(mi_ctx* ctx, const float* sx, const float* sy, const float* sz, int n, int m_local, int index_base, int fma,
               const int* done_flag, int nn_mode);
+// In-place all-reduce of a device array over the ranks, on the context's stream: RCCL, or the caller's transport through pinned
+// host memory.  No-ops on a single-GPU context.
+int allreduce_min_u64(mi_ctx* ctx, unsigned long long* dev_ptr, size_t count);
+int allreduce_sum_f64(mi_ctx* ctx, double* dev_ptr, size_t count);
 
 }  // namespace mislam

@@ -183,7 +183,7 @@ static int cpd_mstep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const
     ProfScope ps(c, MI_KERNEL_CPD_MSTEP);
     MI_HIP(cpd_xsums(v, w->part_x.p, nxb, c->stream));
     MI_HIP(cpd_ksums(v, w->part_k.p, nkb, c->stream));
-    if (!c->comm) {
+    if (!c->distributed()) {
         MI_HIP(cpd_solve(w->d_state, w->part_x.p, nxb, w->part_k.p, nkb, rules, update_loop_state, c->stream));
         return MI_OK;
     }
@@ -192,7 +192,7 @@ static int cpd_mstep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const
     // never travel.  Every rank then runs the same solve.
     static_assert(offsetof(CpdState, ks) == offsetof(CpdState, xs) + sizeof(double) * CPD_XSUMS, "xs and ks must be contiguous");
     MI_HIP(cpd_reduce_sums(w->d_state, w->part_x.p, nxb, w->part_k.p, nkb, c->stream));
-    MI_NCCL(ncclAllReduce(w->d_state->xs, w->d_state->xs, (size_t)(CPD_XSUMS + CPD_KSUMS), ncclDouble, ncclSum, c->comm, c->stream));
+    MI_TRY(allreduce_sum_f64(c, w->d_state->xs, (size_t)(CPD_XSUMS + CPD_KSUMS)));
     MI_HIP(cpd_solve(w->d_state, nullptr, 0, nullptr, 0, rules, update_loop_state, c->stream));
     return MI_OK;
 }
@@ -208,13 +208,13 @@ static int cpd_init(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const CpdRules
 {
     const int nb = icp_reduce_blocks(std::max(w->m, w->n));
     MI_HIP(cpd_init_sums(v, w->part_init.p, nb, c->stream));
-    if (!c->comm) {
+    if (!c->distributed()) {
         MI_HIP(cpd_init_state(w->d_state, w->part_init.p, nb, rules, sigma2_override, c->stream));
         return MI_OK;
     }
     // sharded fixed cloud: its four sums (init[0..3]) are added over the ranks; the moving cloud's (init[4..7]) are replicated
     MI_HIP(cpd_reduce_init(w->d_state, w->part_init.p, nb, c->stream));
-    MI_NCCL(ncclAllReduce(w->d_state->init, w->d_state->init, 4, ncclDouble, ncclSum, c->comm, c->stream));
+    MI_TRY(allreduce_sum_f64(c, w->d_state->init, 4));
     MI_HIP(cpd_init_state(w->d_state, nullptr, 0, rules, sigma2_override, c->stream));
     return MI_OK;
 }

@@ -107,6 +107,53 @@ extern "C" int mi_ctx_create_dist(int device, int rank, int world, const void* u
     return MI_OK;
 }
 
+extern "C" int mi_ctx_create_exchange(int device, int rank, int world, mi_exchange_fn exchange, void* user, mi_ctx** out)
+{
+    if (world < 1 || rank < 0 || rank >= world || !exchange) { set_error("mi_ctx_create_exchange: bad rank/world/callback"); return MI_ERR_INVALID_ARG; }
+    MI_TRY(ctx_create_common(device, out));
+    mi_ctx* c = *out;
+    c->rank = rank;
+    c->world = world;
+    c->exchange = exchange;
+    c->exchange_user = user;
+    return MI_OK;
+}
+
+// The caller's transport: drain the stream, stage through pinned host memory, combine there, copy back.
+static int exchange_on_host(mi_ctx* c, void* dev_ptr, size_t count, int kind)
+{
+    const size_t bytes = count * 8;
+    if (bytes > c->exchange_cap) {
+        if (c->exchange_host) (void)hipHostFree(c->exchange_host);
+        c->exchange_host = nullptr;
+        c->exchange_cap = 0;
+        MI_HIP(hipHostMalloc(&c->exchange_host, bytes, hipHostMallocDefault));
+        c->exchange_cap = bytes;
+    }
+    MI_HIP(hipMemcpyAsync(c->exchange_host, dev_ptr, bytes, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP(hipStreamSynchronize(c->stream));
+    const int r = c->exchange(c->exchange_user, c->exchange_host, count, kind);
+    if (r != 0) { set_error("the exchange callback failed with %d (rank %d of %d, %zu elements, kind %d)", r, c->rank, c->world, count, kind); return MI_ERR_RCCL; }
+    MI_HIP(hipMemcpyAsync(dev_ptr, c->exchange_host, bytes, hipMemcpyHostToDevice, c->stream));
+    return MI_OK;
+}
+
+int mislam::allreduce_min_u64(mi_ctx* c, unsigned long long* dev_ptr, size_t count)
+{
+    if (c->exchange) return exchange_on_host(c, dev_ptr, count, MI_EXCHANGE_MIN_U64);
+    if (!c->comm) return MI_OK;
+    MI_NCCL(ncclAllReduce(dev_ptr, dev_ptr, count, ncclUint64, ncclMin, c->comm, c->stream));
+    return MI_OK;
+}
+
+int mislam::allreduce_sum_f64(mi_ctx* c, double* dev_ptr, size_t count)
+{
+    if (c->exchange) return exchange_on_host(c, dev_ptr, count, MI_EXCHANGE_SUM_F64);
+    if (!c->comm) return MI_OK;
+    MI_NCCL(ncclAllReduce(dev_ptr, dev_ptr, count, ncclDouble, ncclSum, c->comm, c->stream));
+    return MI_OK;
+}
+
 extern "C" int mi_ctx_rank(const mi_ctx* ctx, int* rank, int* world)
 {
     if (!ctx) { set_error("mi_ctx_rank: null context"); return MI_ERR_INVALID_ARG; }
@@ -145,6 +192,7 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->exchange_host) (void)hipHostFree(c->exchange_host);
     cpd_workspace_destroy(c);
     c->staging.release();
     c->bx.release(); c->by.release(); c->bz.release();
@@ -398,18 +446,12 @@ int mislam::launch_nn(mi_ctx* c, const float* sx, const float* sy, const float* 
 
 static int allreduce_keys(mi_ctx* c, int n)
 {
-    if (!c->comm) return MI_OK;
+    if (!c->distributed()) return MI_OK;
     ProfScope ps(c, MI_KERNEL_ALLREDUCE);
-    MI_NCCL(ncclAllReduce(c->keys.p, c->keys.p, (size_t)n, ncclUint64, ncclMin, c->comm, c->stream));
-    return MI_OK;
+    return allreduce_min_u64(c, c->keys.p, (size_t)n);
 }
 
-static int allreduce_doubles(mi_ctx* c, double* dev_ptr, int count)
-{
-    if (!c->comm) return MI_OK;
-    MI_NCCL(ncclAllReduce(dev_ptr, dev_ptr, (size_t)count, ncclDouble, ncclSum, c->comm, c->stream));
-    return MI_OK;
-}
+static int allreduce_doubles(mi_ctx* c, double* dev_ptr, int count) { return allreduce_sum_f64(c, dev_ptr, (size_t)count); }
 
 static void shard_range(int m_total, int rank, int world, int* lo, int* hi) { (void)mi_shard_range(m_total, rank, world, lo, hi); }
 
@@ -525,13 +567,13 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
     if (!before_xyz || !after_xyz || n_before <= 0 || n_after <= 0) { set_error("mi_icp_load: empty or null cloud (n_before=%d, n_after=%d)", n_before, n_after); return MI_ERR_INVALID_ARG; }
     if (n_after < c->world || n_before < c->world) { set_error("mi_icp_load: fewer points (%d, %d) than ranks (%d)", n_before, n_after, c->world); return MI_ERR_INVALID_ARG; }
     MI_TRY(icp_check_params(params));
-    if (params->sum_mode == MI_SUM_CPU_SEQUENTIAL && c->comm) { set_error("mi_icp_load: MI_SUM_CPU_SEQUENTIAL needs a single-GPU context (the running sums follow one global point order)"); return MI_ERR_INVALID_ARG; }
+    if (params->sum_mode == MI_SUM_CPU_SEQUENTIAL && c->distributed()) { set_error("mi_icp_load: MI_SUM_CPU_SEQUENTIAL needs a single-GPU context (the running sums follow one global point order)"); return MI_ERR_INVALID_ARG; }
     MI_HIP(hipSetDevice(c->device));
     c->icp_loaded = false;
     c->icp = *params;
     // what the ranks split (mi_slam.h MI_SHARD_*): decided from GLOBAL sizes, so every rank decides alike
     c->source_sharded = false;
-    if (c->comm) {   // (a one-rank communicator takes the same path: that is what the single-GPU box can test)
+    if (c->distributed()) {   // (a one-rank communicator takes the same path: that is what the single-GPU box can test)
         const int per_rank = n_after / c->world;
         const bool tree = resolve_nn_mode(params->nn_mode, params->shard_mode == MI_SHARD_TARGET ? per_rank : n_after) == MI_NN_TREE;
         c->source_sharded = params->shard_mode == MI_SHARD_SOURCE || (params->shard_mode == MI_SHARD_AUTO && tree);
@@ -580,7 +622,7 @@ static IcpRules icp_rules(const mi_ctx* c)
 // next iteration's moments).  Called when the host stops enqueuing and wants the state.
 static int icp_flush_pending(mi_ctx* c)
 {
-    if (!c->comm) return MI_OK;
+    if (!c->distributed()) return MI_OK;
     ProfScope ps(c, MI_KERNEL_FINALIZE);
     MI_TRY(allreduce_doubles(c, c->d_state->err, ICP_ERRSUMS));
     MI_HIP(icp_finalize_pending(c->d_state, icp_rules(c), c->stream));
@@ -601,7 +643,7 @@ static int icp_enqueue_iteration(mi_ctx* c)
     const int seq = c->icp.sum_mode == MI_SUM_CPU_SEQUENTIAL;
     { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_moments(v, c->part_mom.p, nb, c->stream)); }
     if (seq) { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_seq_centroids(v, c->stream)); }
-    if (c->comm) {
+    if (c->distributed()) {
         // ONE all-reduce per iteration: this iteration's 16 moments and the previous iteration's 2 error sums (contiguous in the
         // state block); the solve kernel first settles the previous iteration's stop rule (kernels.h)
         static_assert(offsetof(IcpState, err) == offsetof(IcpState, mom) + sizeof(double) * ICP_MOMENTS, "mom and err must be contiguous");
@@ -616,7 +658,7 @@ static int icp_enqueue_iteration(mi_ctx* c)
     // K4+K5, K6
     { ProfScope ps(c, MI_KERNEL_TRANSFORM); MI_HIP(icp_transform_error(v, c->part_err.p, nbp, 2, c->stream)); }
     if (seq) { ProfScope ps(c, MI_KERNEL_TRANSFORM); MI_HIP(icp_seq_error(v, c->stream)); }
-    if (c->comm) {
+    if (c->distributed()) {
         ProfScope ps(c, MI_KERNEL_FINALIZE);
         MI_HIP(icp_post_error(c->d_state, c->part_err.p, nbp, c->stream));      // stays local until the next all-reduce (or the flush)
     } else {

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void nn_tree_lane_kernel(const float4* __restr
 template <bool FMA, bool HALF>
 __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t, const float* __restrict__ sx, const float* __restrict__ sy,
                                                                    const float* __restrict__ sz, int n, unsigned long long* __restrict__ keys,
-                                                                   const int* __restrict__ done_flag, int stack_depth)
+                                                                   const int* __restrict__ done_flag)
 {
     if (done_flag != nullptr && *done_flag != 0) return;
     // Pending subtrees: WHICH ones is a 32-bit trail in a register (bit l set = the sibling of this lane's level-l ancestor is
@@ -546,7 +546,6 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
     // to hide the dependent loads behind.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* st_lb = reinterpret_cast<float*>(smem);
-    (void)stack_depth;
     const float4* __restrict__ pairs = t.pairs;
     const uint4* __restrict__ pairs_half = t.pairs_half;
     float hc[3] = {0.f, 0.f, 0.f}, hs[3] = {1.f, 1.f, 1.f};
@@ -554,6 +553,9 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
     const float4* __restrict__ leaf_soa = t.leaf_soa;
     const int* __restrict__ leaf_idx = t.leaf_idx;
 
+    // (Giving only 32 / 16 / 8 lanes of each wave a moving point -- shorter waves for a small moving cloud that leaves wave slots
+    // empty anyway -- measured 0.31 / 0.33 / 0.45 ms against 0.33 ms at 125 000 points and slower everywhere above: a wave is as
+    // long as its WORST lane's walk, not as the union of its lanes' walks.)
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float p[3] = {sx[i], sy[i], sz[i]};
@@ -606,13 +608,14 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
                 for (int q = 0; q < 12; q++) d[q] = __builtin_fmaf(v[q], hs[q % 3], hc[q % 3]);
                 lbl = box_bound<FMA>(make_float4(d[0], d[1], d[2], 0.f), make_float4(d[3], d[4], d[5], 0.f), p, p);
                 lbr = box_bound<FMA>(make_float4(d[6], d[7], d[8], 0.f), make_float4(d[9], d[10], d[11], 0.f), p, p);
-            } else {
+            }
+            const int l = 2 * node + 1;
+            if (!HALF) {
                 const float4* __restrict__ rec = pairs + 3 * (size_t)node;
                 const float4 a = rec[0], b = rec[1], c = rec[2];
                 lbl = box_bound<FMA>(make_float4(a.x, a.y, a.z, 0.f), make_float4(a.w, b.x, b.y, 0.f), p, p);
                 lbr = box_bound<FMA>(make_float4(b.z, b.w, c.x, 0.f), make_float4(c.y, c.z, c.w, 0.f), p, p);
             }
-            const int l = 2 * node + 1;
             const bool left_near = lbl <= lbr;
             const float lbn = left_near ? lbl : lbr, lbf = left_near ? lbr : lbl;
             // step to the near child either way: the trail is relative to the current node, and the far child is "the sibling
@@ -733,11 +736,14 @@ hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, 
             const char* half_env = getenv("MISLAM_TREE_HALF");
             const bool half_nodes = half_env && *half_env == '1';
             if (half_nodes && t.pairs_half != nullptr) {
-                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, depth);
-                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, depth);
+                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag);
+                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag);
             } else {
-                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, depth);
-                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, depth);
+                // (fetching both children's records with the node's own -- two levels per load trip -- measured slower at every
+                // moving-cloud size, 0.35 against 0.33 ms at 125 000 and 1.15 against 0.81 ms at 1e6: most visits are short
+                // excursions into pending subtrees, where the second record is wasted)
+                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag);
+                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag);
             }
             return hipGetLastError();
         }

@@ -121,6 +121,16 @@ int mi_dist_unique_id(void* out_unique_id);
 int mi_ctx_create_dist(int device, int rank, int world, const void* unique_id, mi_ctx** out);
 int mi_ctx_rank(const mi_ctx* ctx, int* rank, int* world);
 
+/* The same multi-GPU path over the CALLER's transport instead of RCCL (MPI between nodes, a test harness ...; no reference
+ * counterpart either).  Wherever the RCCL context issues an all-reduce, this one drains its stream, copies the operand to
+ * pinned host memory, calls `exchange` and copies the result back: `exchange` must combine host_buf[0 .. count) IN PLACE across
+ * all `world` ranks -- element-wise unsigned 64-bit MIN for MI_EXCHANGE_MIN_U64, double SUM for MI_EXCHANGE_SUM_F64 -- and
+ * return 0, or non-zero to fail the call with MI_ERR_RCCL.  Every rank makes the same sequence of calls.  Results are those
+ * of the RCCL context up to the order in which the transport adds the doubles. */
+enum { MI_EXCHANGE_MIN_U64 = 0, MI_EXCHANGE_SUM_F64 = 1 };
+typedef int (*mi_exchange_fn)(void* user, void* host_buf, size_t count, int kind);
+int mi_ctx_create_exchange(int device, int rank, int world, mi_exchange_fn exchange, void* user, mi_ctx** out);
+
 /* Host-side pieces of the multi-GPU protocol (pure functions, usable without a device; the CPU tests drive them over gloo):
  *   mi_shard_range  the contiguous target range [lo, hi) rank `rank` of `world` owns: lo = M*rank/world, hi = M*(rank+1)/world;
  *   mi_pack_key     the 64-bit key the search emits per source point: IEEE bits of d2 (d2 >= 0, so they order like the

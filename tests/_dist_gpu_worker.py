@@ -1,0 +1,108 @@
+"""Worker of tests/test_gpu_dist_ranks.py: one rank of a REAL multi-rank run of the HIP path, all ranks on the one GPU of the box.
+
+RCCL refuses two ranks on one device, so the ranks use mi_ctx_create_exchange with gloo as the transport: every kernel, shard
+range, index base and the order of the collectives are the ones the RCCL context runs (the two contexts differ in the one
+function that moves the operand); the result is checked against a single-GPU context in the same process.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import load_package, synth_cloud  # noqa: E402
+
+SIGN = np.uint64(1 << 63)
+
+
+def frob(Ra, ta, Rb, tb):
+    return float(np.sqrt(((np.asarray(Ra, np.float64) - Rb) ** 2).sum() + ((np.asarray(ta, np.float64) - tb) ** 2).sum()))
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    capi = load_package().capi
+    calls = {capi.EXCHANGE_MIN_U64: 0, capi.EXCHANGE_SUM_F64: 0}
+
+    def exchange(arr, kind):
+        calls[kind] += 1
+        if kind == capi.EXCHANGE_MIN_U64:     # gloo has no unsigned MIN: flipping the top bit maps unsigned order onto signed
+            t = torch.from_numpy((arr ^ SIGN).view(np.int64))
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            arr[:] = t.numpy().view(np.uint64) ^ SIGN
+        else:
+            t = torch.from_numpy(arr)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bunny_clouds.npz"))
+    before, after = z["before"], z["after"]
+    with capi.Context(0, rank, world, exchange=exchange) as dctx, capi.Context(0) as sctx:
+        assert dctx.rank_world() == (rank, world)
+
+        # the sharded correspondence search: bit-exact keys, duplicates across the shard boundary resolved to the lowest index
+        tgt = after.copy()
+        tgt[len(tgt) // 2: len(tgt) // 2 + 200] = tgt[100:300]
+        i1, d1 = dctx.nn_search(before[:3000], tgt)
+        i2, d2 = sctx.nn_search(before[:3000], tgt)
+        assert np.array_equal(i1, i2) and np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
+        assert calls[capi.EXCHANGE_MIN_U64] >= 1
+
+        # ICP, every way of splitting it, both searches: the same iteration count and stop reason, R|t equal to the single-GPU
+        # run up to the order of the fp64 partial sums (1e-6; the correspondences themselves are identical)
+        for nn_mode in (capi.NN_BRUTEFORCE, capi.NN_TREE):
+            for shard_mode in (capi.SHARD_TARGET, capi.SHARD_SOURCE, capi.SHARD_AUTO):
+                for kw in (dict(eps=1e-3, max_iterations=50, max_distance_squared=400.0), dict(max_iterations=7),
+                           dict(eps=1e-3, max_iterations=50, max_distance_squared=400.0, sync_every=3)):
+                    p = capi.icp_params(nn_mode=nn_mode, shard_mode=shard_mode, **kw)
+                    a = dctx.icp_register(before, after, p)
+                    b = sctx.icp_register(before, after, p)
+                    assert a[2] == b[2], (nn_mode, shard_mode, kw, a[2], b[2])
+                    assert frob(a[0], a[1], b[0], b[1]) < 1e-6 and abs(a[3] - b[3]) < 1e-7, (nn_mode, shard_mode, kw)
+        # the GPU reference's rules (abort + rollback when the error rises)
+        a = dctx.icp_register(before, after, capi.icp_params(cuda_slam=True, max_iterations=60))
+        b = sctx.icp_register(before, after, capi.icp_params(cuda_slam=True, max_iterations=60))
+        assert a[2] == b[2] and frob(a[0], a[1], b[0], b[1]) < 1e-6
+
+        # a run enqueued in pieces
+        for c in (dctx, sctx):
+            c.icp_load(before, after, capi.icp_params(eps=1e-3, max_iterations=50, max_distance_squared=400.0))
+            assert c.icp_run(5) == 5
+            c.icp_run(-1)
+        ra, rb = dctx.icp_result(), sctx.icp_result()
+        assert ra[2] == rb[2] and ra[4] == rb[4] == capi.STOP_CONVERGED and frob(ra[0], ra[1], rb[0], rb[1]) < 1e-6
+
+        # a larger synthetic problem with ragged shares (sizes not divisible by the rank count)
+        sb, sa = synth_cloud(200003, m=150001)[:2]
+        for shard_mode in (capi.SHARD_TARGET, capi.SHARD_SOURCE):
+            p = capi.icp_params(eps=0.0, max_iterations=6, shard_mode=shard_mode)
+            a = dctx.icp_register(sb, sa, p)
+            b = sctx.icp_register(sb, sa, p)
+            assert a[2] == b[2] == 6 and frob(a[0], a[1], b[0], b[1]) < 1e-6, shard_mode
+
+        # rigid CPD with the fixed cloud sharded: the per-point sums are fp32 in a different order, hence 1e-4 like the
+        # bar against cpu-slam itself
+        for kw in (dict(max_iterations=50), dict(max_iterations=9, const_scale=1)):
+            cp = capi.cpd_params(approximation=capi.CPD_APPROX_NONE, **kw)
+            ca = dctx.cpd_register(before, after, cp)          # (sR, t, scale, iterations, error)
+            cb = sctx.cpd_register(before, after, cp)
+            assert ca[3] == cb[3], (kw, ca[3], cb[3])
+            assert frob(ca[0], ca[1], cb[0], cb[1]) < 1e-4 and abs(ca[2] - cb[2]) < 1e-5, kw
+        # the Fast Gauss Transform modes need the whole fixed cloud on one GPU
+        try:
+            dctx.cpd_register(before, after, capi.cpd_params(max_iterations=3, approximation=capi.CPD_APPROX_HYBRID))
+            raise AssertionError("the hybrid mode must be refused on %d ranks" % world)
+        except capi.MiSlamError:
+            pass
+        assert calls[capi.EXCHANGE_SUM_F64] > 50
+
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print("DIST_GPU_OK world=%d exchanges=%d+%d" % (world, calls[capi.EXCHANGE_MIN_U64], calls[capi.EXCHANGE_SUM_F64]))
+
+
+if __name__ == "__main__":
+    main()
