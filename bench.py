@@ -163,7 +163,25 @@ def main():
     before, after = synth_cloud(np, args.points)
     n, m = len(before), len(after)
 
-    if use_dist:
+    # Rehearsal of the N > 1 flow on a box with ONE GPU (tools/gpu_dist_rehearsal.sh): MISLAM_BENCH_DEVICE pins every rank to
+    # that device and MISLAM_BENCH_TRANSPORT=gloo swaps RCCL (which refuses two ranks on one device) for the caller's-transport
+    # context over gloo.  It validates the launch line, sharding, barriers and the report -- its numbers mean nothing.
+    rehearsal_transport = os.environ.get("MISLAM_BENCH_TRANSPORT", "rccl")
+    if "MISLAM_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["MISLAM_BENCH_DEVICE"])
+    if use_dist and rehearsal_transport == "gloo":
+        import torch
+        sign = np.uint64(1 << 63)
+
+        def exchange(arr, kind):
+            if kind == capi.EXCHANGE_MIN_U64:      # gloo has no unsigned MIN: flip the top bit and take the signed one
+                tk = torch.from_numpy((arr ^ sign).view(np.int64))
+                dist.all_reduce(tk, op=dist.ReduceOp.MIN)
+                arr[:] = tk.numpy().view(np.uint64) ^ sign
+            else:
+                dist.all_reduce(torch.from_numpy(arr), op=dist.ReduceOp.SUM)
+        ctx = capi.Context(local_rank, rank, world, exchange=exchange)
+    elif use_dist:
         uid = [capi.dist_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx = capi.Context(local_rank, rank, world, uid[0])
@@ -277,6 +295,8 @@ def main():
             "roofline": nn_figures(prof["nn"][0], prof["nn"][1], not used_tree),
             "kernels_ms_per_step": breakdown,     # ms per launch, from the untimed follow-up iterations (every kernel event-timed)
         }
+        if use_dist and rehearsal_transport == "gloo":
+            out["rehearsal"] = "ranks share device %d over the gloo exchange context: flow check only, not a measurement" % local_rank
         if brute_prof is not None:
             out["bruteforce_nn"] = nn_figures(brute_prof[0], brute_prof[1], True)
         if cpd is not None:
