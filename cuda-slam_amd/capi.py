@@ -35,6 +35,7 @@ EXPORTS = [
     "mi_icp_register", "mi_icp_load", "mi_icp_reset", "mi_icp_run", "mi_icp_result", "mi_nn_search", "mi_nn_search_ex", "mi_kabsch",
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_estep",
     "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
+    "mi_prepare_params_default", "mi_prepare_cloud",
     "mi_cpd_mstep", "mi_profile_enable", "mi_profile_select", "mi_profile_reset", "mi_profile_get",
 ]
 
@@ -56,6 +57,11 @@ class CpdParams(C.Structure):
 class NicpParams(C.Structure):
     _fields_ = [("eps", C.c_float), ("max_repetitions", C.c_int), ("approximation", C.c_int), ("verbose", C.c_int),
                 ("reserved", C.c_int * 4)]
+
+
+class PrepareParams(C.Structure):
+    _fields_ = [("has_spread", C.c_int), ("spread", C.c_float), ("noise_intensity", C.c_float), ("has_transform", C.c_int),
+                ("rotation", C.c_float * 9), ("translation", C.c_float * 3), ("reserved", C.c_int * 4)]
 
 
 class MiSlamError(RuntimeError):
@@ -80,6 +86,7 @@ def lib():
         _lib.mi_icp_params_default.restype = None
         _lib.mi_icp_params_cuda_slam.restype = None
         _lib.mi_cpd_params_default.restype = None
+        _lib.mi_prepare_params_default.restype = None
         _lib.mi_pack_key.restype = C.c_ulonglong
         _lib.mi_pack_key.argtypes = [C.c_float, C.c_int]
         _lib.mi_unpack_key.restype = None
@@ -383,6 +390,40 @@ class Context:
                                       sn, T, C.byref(it), C.byref(err)))
         R, t = _T_to_Rt(T)
         return R, t, it.value, err.value
+
+    # ---- input stage
+    def prepare_cloud(self, raw, subcloud_idx=None, shuffle_idx=None, noise_rows=None, noise_unit=None, noise_intensity=0.0,
+                      outlier_unit=None, spread=None, R=None, t=None):
+        """GetCloudsFromConfig's stages for one cloud (mi_prepare_cloud).  R (3x3, row = output component), t: the known
+        transformation, or None.  Returns the prepared cloud [(size + outliers), 3]."""
+        raw = _cloud(raw)
+        opt_i = lambda a: None if a is None else np.ascontiguousarray(a, np.int32)
+        opt_f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32).reshape(-1)
+        sub, shuf, rows, nu, ou = opt_i(subcloud_idx), opt_i(shuffle_idx), opt_i(noise_rows), opt_f(noise_unit), opt_f(outlier_unit)
+        n = raw.shape[0] if sub is None else len(sub)
+        if shuf is not None and len(shuf) != n:
+            raise ValueError("shuffle_idx must have %d entries" % n)
+        n_noise = 0 if rows is None else len(rows)
+        if n_noise and (nu is None or len(nu) != 3 * n_noise):
+            raise ValueError("noise_unit must be [%d, 3]" % n_noise)
+        n_out = 0 if ou is None else len(ou) // 3
+        p = PrepareParams()
+        lib().mi_prepare_params_default(C.byref(p))
+        if spread is not None:
+            p.has_spread, p.spread = 1, spread
+        p.noise_intensity = noise_intensity
+        if R is not None:
+            p.has_transform = 1
+            p.rotation[:] = np.asarray(R, np.float32).T.reshape(9).tolist()        # column-major
+            p.translation[:] = np.asarray(t, np.float32).tolist()
+        out = np.empty((n + n_out, 3), np.float32)
+        got = C.c_int(0)
+        ip = lambda a: None if a is None else a.ctypes.data_as(_i)
+        fp = lambda a: None if a is None else _fp(a)
+        _check(lib().mi_prepare_cloud(self._h, _fp(raw), raw.shape[0], ip(sub), n, ip(shuf), ip(rows), fp(nu), n_noise, fp(ou), n_out,
+                                      C.byref(p), _fp(out), C.byref(got)))
+        assert got.value == n + n_out
+        return out
 
     # ---- profiling
     def profile_enable(self, on=True):

@@ -197,6 +197,103 @@ std::pair<CpuCloud, CpuCloud> GetCloudsFromConfig(const Configuration& config)
     return {before, after};
 }
 
+// The same stage with the per-point work on the device (mi_prepare_cloud): this function only draws the random OUTCOMES, each
+// generator consumed in the order GetCloudsFromConfig consumes it -- g_rng: subcloud before / after, shuffle before / after,
+// noise flags before / after; rand(): noise draws before / after, outlier draws before / after, then the random transform.
+std::pair<CpuCloud, CpuCloud> GetCloudsFromConfigOnDevice(const Configuration& config, mi_ctx* ctx)
+{
+    const unsigned seed = config.RandomSeed ? (unsigned)*config.RandomSeed : std::random_device{}();
+    g_rng = std::mt19937{seed};
+
+    const bool same = config.BeforePath == config.AfterPath;
+    const CpuCloud raw_before = LoadCloud(config.BeforePath);
+    const CpuCloud raw_after_file = same ? CpuCloud{} : LoadCloud(config.AfterPath);
+    const CpuCloud& raw_after = same ? raw_before : raw_after_file;
+    if (raw_before.empty() || raw_after.empty()) return {};
+
+    struct Side {
+        const CpuCloud* raw;
+        int n;                                     // size after the optional resize
+        std::vector<int> sub, shuffle, rows;
+        std::vector<float> noise_unit, outlier_unit;
+        float intensity = 0.f;
+    } b{&raw_before, (int)raw_before.size(), {}, {}, {}, {}, {}}, a{&raw_after, (int)raw_after.size(), {}, {}, {}, {}, {}};
+
+    const auto draw_subcloud = [](Side& s, const std::optional<int>& resize) {
+        if (!resize || *resize >= (int)s.raw->size()) return;          // GetSubcloud returns the cloud and draws nothing
+        s.sub = random_permutation((int)s.raw->size());
+        s.sub.resize((size_t)std::max(*resize, 0));
+        s.n = (int)s.sub.size();
+    };
+    draw_subcloud(b, config.CloudBeforeResize);
+    draw_subcloud(a, config.CloudAfterResize);
+    if (b.n < 1 || a.n < 1) return {};
+    b.shuffle = random_permutation(b.n);                               // std::shuffle of n elements == this permutation as a gather
+    a.shuffle = random_permutation(a.n);
+    const auto draw_flags = [](Side& s, const std::optional<float>& share, float intensity) {
+        if (!share) return;
+        const int affected = std::clamp((int)std::round(*share * s.n), 0, s.n);
+        const auto perm = random_permutation(s.n);
+        for (int i = 0; i < s.n; i++)
+            if (perm[(size_t)i] < affected) s.rows.push_back(i);       // ApplyPermutation: flag[perm[i]]
+        s.intensity = intensity;
+    };
+    draw_flags(b, config.NoiseAffectedPointsBefore, config.NoiseIntensityBefore);
+    draw_flags(a, config.NoiseAffectedPointsAfter, config.NoiseIntensityAfter);
+    const auto unit = [](size_t count) {                               // static_cast<float>(rand()) / RAND_MAX, testutils.cpp:10
+        std::vector<float> u(count);
+        for (auto& v : u) v = static_cast<float>(rand()) / RAND_MAX;
+        return u;
+    };
+    b.noise_unit = unit(3 * b.rows.size());
+    a.noise_unit = unit(3 * a.rows.size());
+    b.outlier_unit = unit(3 * (size_t)std::max(config.AdditionalOutliersBefore, 0));
+    a.outlier_unit = unit(3 * (size_t)std::max(config.AdditionalOutliersAfter, 0));
+
+    mi_prepare_params pb;
+    mi_prepare_params_default(&pb);
+    pb.has_spread = config.CloudSpread ? 1 : 0;
+    pb.spread = config.CloudSpread ? *config.CloudSpread : 1.f;
+    mi_prepare_params pa = pb;
+    pb.noise_intensity = b.intensity;
+    pa.noise_intensity = a.intensity;
+    Mat3 R;
+    Vec3 t;
+    if (config.Transformation) {
+        R = config.Transformation->first;
+        t = config.Transformation->second;
+        pa.has_transform = 1;
+    } else if (config.TransformationParameters) {
+        const auto [rot_range, trans_range] = *config.TransformationParameters;
+        const Point_f ax = rand_point({0, 0, 0}, {1, 1, 1});
+        R = rotation_about({ax.x, ax.y, ax.z}, rot_range);
+        const Point_f d = rand_point({-1, -1, -1}, {1, 1, 1});
+        const float len = std::sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+        t = Vec3{d.x / len * trans_range, d.y / len * trans_range, d.z / len * trans_range};
+        pa.has_transform = 1;
+    }
+    for (int k = 0; k < 9; k++) pa.rotation[k] = R.data()[k];
+    for (int k = 0; k < 3; k++) pa.translation[k] = t[k];
+
+    const auto run = [ctx](const Side& s, const mi_prepare_params& p, CpuCloud* out) {
+        const int n_out = (int)s.outlier_unit.size() / 3;
+        out->resize((size_t)s.n + (size_t)n_out);
+        int got = 0;
+        const int rc = mi_prepare_cloud(ctx, &(*s.raw)[0].x, (int)s.raw->size(), s.sub.empty() ? nullptr : s.sub.data(), s.n, s.shuffle.data(),
+                                        s.rows.empty() ? nullptr : s.rows.data(), s.noise_unit.empty() ? nullptr : s.noise_unit.data(),
+                                        (int)s.rows.size(), n_out ? s.outlier_unit.data() : nullptr, n_out, &p, &(*out)[0].x, &got);
+        if (rc != MI_OK) {       // checkCudaErrors behaviour (include/helper_cuda.h:567-573): report and leave
+            fprintf(stderr, "MI355X device error at mi_prepare_cloud: code=%d \"%s\"\n", rc, mi_last_error());
+            exit(EXIT_FAILURE);
+        }
+        out->resize((size_t)got);
+    };
+    CpuCloud before, after;
+    run(b, pb, &before);
+    run(a, pa, &after);
+    return {before, after};
+}
+
 std::vector<int> GetRandomPermutationVector(int size) { return random_permutation(size); }
 
 }  // namespace Common

@@ -5,6 +5,7 @@
 #include <utility>
 #include <vector>
 
+#include "../../include/mi_slam.h"
 #include "configuration.h"
 #include "slam_types.h"
 
@@ -21,6 +22,10 @@ CpuCloud GetTransformedCloud(const CpuCloud& cloud, const Mat3& R, const Vec3& t
 // Load, optional resize, normalise to "cloud-spread", shuffle with mt19937("random-seed"), optional noise / outliers,
 // apply the configured transform to `after` (common.cpp:134-210).  Returns (before, after).
 std::pair<CpuCloud, CpuCloud> GetCloudsFromConfig(const Configuration& config);
+
+// The same stage, same results bit for bit, with the per-point work on the device (mi_prepare_cloud, include/mi_slam.h): the
+// host only reads the files and draws the random outcomes from the program's generators, in the reference's order.
+std::pair<CpuCloud, CpuCloud> GetCloudsFromConfigOnDevice(const Configuration& config, mi_ctx* ctx);
 
 // iota + std::shuffle on the program's generator (the one "random-seed" seeds and the cloud stage has already drawn from), as
 // Common::GetRandomPermutationVector does on Common::mtRandom (common.cpp:554-560)

@@ -2,7 +2,10 @@
 // source/common/mainwrapper.cpp:5-54) on the MI355X path: parse the JSON configuration, build the two clouds, call the
 // SlamFunc, print rotation / translation / error in the reference's format.  The OpenGL viewer is not part of this build.
 //
-//   mi-slam [config.json] [--rules cuda|cpu] [--device N] [--dump-clouds file.bin] [--result-json file.json]
+//   mi-slam [config.json] [--rules cuda|cpu] [--device N] [--prepare device|host] [--dump-clouds file.bin] [--result-json file.json]
+//
+// --prepare: where the clouds-from-configuration stage runs its per-point work: on the device (mi_prepare_cloud, the default) or
+// on the host (cloud_io.cpp's mirror of the reference) -- identical clouds either way.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,11 +30,12 @@ static void print_matrix3(const Mat3& m)   // PrintMatrixWithSize(matrix, 3), co
 int main(int argc, char** argv)
 {
     std::vector<char*> positional{argv[0]};
-    std::string dump_path, json_path, rules = "cuda";
+    std::string dump_path, json_path, rules = "cuda", prepare = "device";
     int device = 0;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--rules") && i + 1 < argc) rules = argv[++i];
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--prepare") && i + 1 < argc) prepare = argv[++i];
         else if (!strcmp(argv[i], "--dump-clouds") && i + 1 < argc) dump_path = argv[++i];
         else if (!strcmp(argv[i], "--result-json") && i + 1 < argc) json_path = argv[++i];
         else positional.push_back(argv[i]);
@@ -44,9 +48,13 @@ int main(int argc, char** argv)
     }
     configuration.Print();
     const unsigned seed = configuration.RandomSeed ? (unsigned)*configuration.RandomSeed : (unsigned)time(nullptr);
+    SetSlamDevice(device);
+    // the context first: bringing up the HIP runtime consumes rand() draws of its own, and the stage below must see the
+    // stream exactly as srand(seed) leaves it
+    mi_ctx* prepare_ctx = prepare == "host" ? nullptr : GetSlamContext();
     srand(seed);                                                        // mainwrapper.cpp:17-18
 
-    auto [before, after] = GetCloudsFromConfig(configuration);
+    auto [before, after] = prepare_ctx ? GetCloudsFromConfigOnDevice(configuration, prepare_ctx) : GetCloudsFromConfig(configuration);
     if (before.empty() || after.empty()) {
         printf("Aborting: empty cloud (before %zu, after %zu points)\n", before.size(), after.size());
         return -1;
@@ -62,7 +70,6 @@ int main(int argc, char** argv)
         if (json_path.empty() && getenv("MISLAM_DUMP_ONLY")) return 0;
     }
 
-    SetSlamDevice(device);
     SetSlamRules(rules == "cpu" ? SlamRules::CpuSlam : SlamRules::CudaSlam, configuration.MaxDistanceSquared);
     const SlamFunc func = GetGpuSlamResult;
     int iterations = 0;

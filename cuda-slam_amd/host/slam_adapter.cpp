@@ -53,6 +53,7 @@ void SetSlamRules(SlamRules rules, float max_distance_squared)
 }
 
 void SetSlamDevice(int device) { g_device = device; }
+mi_ctx* GetSlamContext() { return context(); }
 
 std::pair<Mat3, Vec3> GetCudaIcpTransformationMatrix(const std::vector<Point_f>& cloudBefore, const std::vector<Point_f>& cloudAfter,
                                                     float eps, int maxIterations, int* iterations, float* error)

@@ -24,6 +24,8 @@ using SlamFunc = std::function<std::pair<Mat3, Vec3>(const CpuCloud&, const CpuC
 enum class SlamRules { CudaSlam, CpuSlam };
 void SetSlamRules(SlamRules rules, float max_distance_squared = 1000.f);
 void SetSlamDevice(int device);
+struct mi_ctx;
+mi_ctx* GetSlamContext();      // the process-wide device context the registration calls use (created on first use)
 
 std::pair<Common::Mat3, Common::Vec3> GetCudaIcpTransformationMatrix(const std::vector<Common::Point_f>& cloudBefore,
                                                                     const std::vector<Common::Point_f>& cloudAfter, float eps,

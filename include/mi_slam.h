@@ -320,6 +320,38 @@ int mi_nicp_register(mi_ctx* ctx, const float* before_xyz, int m_before, const f
                      float out_T[16], int* repetitions, float* error);
 
 /* ----------------------------------------------------------------------------------------------------------------
+ * Input stage: what Common::GetCloudsFromConfig (source/common/common.cpp:134-210) does to ONE cloud between
+ * LoadCloud and the registration call, on the device and with the reference's arithmetic bit for bit:
+ *   GetSubcloud (common.cpp:25-37) -> NormalizeCloud to "cloud-spread" (:81-95; the centre of mass is the reference's
+ *   sequential fp32 accumulate, :281-284) -> std::shuffle (:166-167) -> AddNoiseToCloud (:97-119) -> AddOutliersToCloud
+ *   (:121-132) -> GetTransformedCloud (:219-224, the `after` cloud only).
+ * The random outcomes are the caller's, drawn like the reference draws them (mt19937 + std::shuffle for the index vectors,
+ * rand() for the unit draws; host/cloud_io.cpp does it):
+ *   subcloud_idx   first subcloud_n entries of GetSubcloud's permutation of 0..n_raw-1, or NULL (whole cloud);
+ *   shuffle_idx    the shuffle as a gather order -- std::shuffle of an iota of the cloud's size with the same generator:
+ *                  prepared row i = normalised row shuffle_idx[i] -- or NULL;
+ *   noise_rows     ascending rows of the shuffled cloud that AddNoiseToCloud's flag permutation marks, noise_unit[3q..3q+2]
+ *                  the three rand()/RAND_MAX draws of the q-th of them (x, y, z), in the order the reference consumes them;
+ *   outlier_unit   three draws per appended outlier.
+ * out_xyz holds (cloud size + n_outliers) points; *out_n receives that count.
+ * -------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int   has_spread;       /* "cloud-spread" present: normalise to `spread` */
+    float spread;
+    float noise_intensity;  /* "noise-intensity-before" / "-after" */
+    int   has_transform;    /* apply rotation (column-major, like glm::mat3) and translation: p -> R p + t */
+    float rotation[9];
+    float translation[3];
+    int   reserved[4];
+} mi_prepare_params;
+
+void mi_prepare_params_default(mi_prepare_params* p);
+
+int mi_prepare_cloud(mi_ctx* ctx, const float* raw_xyz, int n_raw, const int* subcloud_idx, int subcloud_n, const int* shuffle_idx,
+                     const int* noise_rows, const float* noise_unit, int n_noise, const float* outlier_unit, int n_outliers,
+                     const mi_prepare_params* params, float* out_xyz, int* out_n);
+
+/* ----------------------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): per-kernel HIP-event timing on the context's own stream.
  * -------------------------------------------------------------------------------------------------------------- */
 enum {

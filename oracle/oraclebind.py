@@ -311,3 +311,26 @@ def cpd_approx(before, after, approximation, eps=1e-3, weight=0.3, const_scale=F
     if trace_cap:
         return out + (trace[:min(tl.value, trace_cap)].copy(),)
     return out
+
+
+# ---- input stage, Common::GetCloudsFromConfig for one cloud (oracle/prep_oracle.c) ----
+def prepare_cloud(raw, subcloud_idx=None, shuffle_idx=None, noise_rows=None, noise_unit=None, noise_intensity=0.0, outlier_unit=None,
+                  spread=None, R=None, t=None):
+    """R (3x3, row = output component) and t: the known transformation, or None.  Returns the prepared cloud."""
+    raw = _cloud(raw)
+    opt_i = lambda a: None if a is None else np.ascontiguousarray(a, np.int32)
+    opt_f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32).reshape(-1)
+    sub, shuf, rows, nu, ou = opt_i(subcloud_idx), opt_i(shuffle_idx), opt_i(noise_rows), opt_f(noise_unit), opt_f(outlier_unit)
+    n = len(raw) if sub is None else len(sub)
+    n_noise = 0 if rows is None else len(rows)
+    n_out = 0 if ou is None else len(ou) // 3
+    out = np.empty((n + n_out, 3), np.float32)
+    rot = None if R is None else np.ascontiguousarray(np.asarray(R, np.float32).T).reshape(9)      # column-major
+    tr = None if R is None else np.ascontiguousarray(t, np.float32)
+    ptr_i = lambda a: None if a is None else _ip(a)
+    ptr_f = lambda a: None if a is None else _fp(a)
+    got = lib().oracle_prepare_cloud(_fp(raw), len(raw), ptr_i(sub), n, ptr_i(shuf), ptr_i(rows), ptr_f(nu), n_noise,
+                                     C.c_float(noise_intensity), ptr_f(ou), n_out, 0 if spread is None else 1,
+                                     C.c_float(spread or 0.0), ptr_f(rot), ptr_f(tr), _fp(out))
+    assert got == n + n_out
+    return out

@@ -90,6 +90,53 @@ REF_API void ref_clouds_from_config(const float* raw_xyz, int n, int has_spread,
     from_cloud(after, after_xyz);
 }
 
+// The whole of GetCloudsFromConfig after LoadCloud (common.cpp:139-190) for in-memory raw clouds (LoadCloud itself needs assimp,
+// Windows .lib only): every stage is the reference's own function, in the reference's order, on the reference's generators
+// (mtRandom for the permutations, rand() -- seeded like mainwrapper.cpp:17-18 -- for the noise and outlier draws).
+// resize_* < 0 / noise_share_* < 0: option absent.  Outputs hold (resized size + outliers) points; the counts are returned.
+REF_API void ref_clouds_from_config_full(const float* raw_before, int nb_raw, const float* raw_after, int na_raw, int resize_before,
+                                         int resize_after, int has_spread, float spread, unsigned seed, float noise_share_before,
+                                         float noise_intensity_before, float noise_share_after, float noise_intensity_after,
+                                         int outliers_before, int outliers_after, const float* rot9_colmajor, const float* trans3,
+                                         float* before_xyz, int* nb_out, float* after_xyz, int* na_out)
+{
+    srand(seed);                                                 // mainwrapper.cpp:17-18
+    Common::randomSeed = seed;                                   // common.cpp:136
+    Common::mtRandom = std::mt19937{ seed };                     // common.cpp:137
+    auto before = to_cloud(raw_before, nb_raw);
+    auto after = raw_after ? to_cloud(raw_after, na_raw) : before;   // common.cpp:141-142
+    if (resize_before >= 0) before = Common::GetSubcloud(before, resize_before);   // common.cpp:145-149
+    if (resize_after >= 0) after = Common::GetSubcloud(after, resize_after);       // common.cpp:151-155
+    if (has_spread) {                                            // common.cpp:158-163
+        before = Common::NormalizeCloud(before, spread);
+        after = Common::NormalizeCloud(after, spread);
+    }
+    std::shuffle(before.begin(), before.end(), Common::mtRandom); // common.cpp:166
+    std::shuffle(after.begin(), after.end(), Common::mtRandom);   // common.cpp:167
+    if (noise_share_before >= 0.f) before = Common::AddNoiseToCloud(before, noise_share_before, noise_intensity_before);   // :170-173
+    if (noise_share_after >= 0.f) after = Common::AddNoiseToCloud(after, noise_share_after, noise_intensity_after);        // :175-178
+    before = Common::AddOutliersToCloud(before, outliers_before);   // common.cpp:180
+    after = Common::AddOutliersToCloud(after, outliers_after);      // common.cpp:181
+    after = Common::GetTransformedCloud(after, to_mat3(rot9_colmajor), glm::vec3(trans3[0], trans3[1], trans3[2]));   // :184-190
+    from_cloud(before, before_xyz);
+    from_cloud(after, after_xyz);
+    *nb_out = (int)before.size();
+    *na_out = (int)after.size();
+}
+
+// Consecutive Common::GetRandomPermutationVector draws (common.cpp:554-560) of the given sizes from a freshly seeded generator,
+// concatenated: the generator stream GetCloudsFromConfig consumes (a std::shuffle of k elements advances it exactly like the
+// permutation of size k does, and moves element perm[i] to place i).
+REF_API void ref_permutation_sequence(unsigned seed, const int* sizes, int count, int* out)
+{
+    Common::mtRandom = std::mt19937{ seed };
+    for (int i = 0; i < count; i++) {
+        auto p = Common::GetRandomPermutationVector(sizes[i]);
+        std::memcpy(out, p.data(), sizeof(int) * sizes[i]);
+        out += sizes[i];
+    }
+}
+
 // Common::GetCorrespondingPoints  common.cpp:509-515 (sequential :399-439, parallel :441-507).
 // Returns the number of kept pairs; idx_before/idx_after hold the kept pair indices.
 REF_API int ref_corresponding_points(const float* before_xyz, int n, const float* after_xyz, int m,

@@ -225,3 +225,74 @@ def random_permutation(seed, size, skip=0):
     out = np.empty(size, np.int32)
     lib().ref_random_permutation(C.c_uint(seed), size, skip, out.ctypes.data_as(C.POINTER(C.c_int)))
     return out
+
+
+# ---- the input stage: GetCloudsFromConfig after LoadCloud, and the random outcomes it draws ----
+def clouds_from_config_full(raw_before, raw_after, seed, R, t, resize_before=None, resize_after=None, spread=None,
+                            noise_before=None, noise_after=None, outliers_before=0, outliers_after=0):
+    """noise_*: (affected share, intensity) or None.  R (3x3, row = output component), t: the known transformation of `after`.
+    raw_after None = the same file for both clouds (common.cpp:141-142)."""
+    raw_before = _cloud(raw_before)
+    nbr = len(raw_before)
+    if raw_after is not None:
+        raw_after = _cloud(raw_after)
+    nar = nbr if raw_after is None else len(raw_after)
+    nb = (min(resize_before, nbr) if resize_before is not None else nbr) + outliers_before
+    na = (min(resize_after, nar) if resize_after is not None else nar) + outliers_after
+    before = np.empty((nb, 3), np.float32)
+    after = np.empty((na, 3), np.float32)
+    rot = np.ascontiguousarray(np.asarray(R, np.float32).T).reshape(9)
+    tr = np.ascontiguousarray(t, np.float32)
+    cb, ca = C.c_int(0), C.c_int(0)
+    lib().ref_clouds_from_config_full(
+        _fp(raw_before), nbr, None if raw_after is None else _fp(raw_after), nar,
+        -1 if resize_before is None else resize_before, -1 if resize_after is None else resize_after,
+        0 if spread is None else 1, C.c_float(spread or 0.0), C.c_uint(seed),
+        C.c_float(-1.0 if noise_before is None else noise_before[0]), C.c_float(0.0 if noise_before is None else noise_before[1]),
+        C.c_float(-1.0 if noise_after is None else noise_after[0]), C.c_float(0.0 if noise_after is None else noise_after[1]),
+        outliers_before, outliers_after, _fp(rot), _fp(tr), _fp(before), C.byref(cb), _fp(after), C.byref(ca))
+    assert (cb.value, ca.value) == (nb, na)
+    return before, after
+
+
+def permutation_sequence(seed, sizes):
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    out = np.empty(int(sizes.sum()), np.int32)
+    lib().ref_permutation_sequence(C.c_uint(seed), _ip(sizes), len(sizes), _ip(out))
+    return np.split(out, np.cumsum(sizes)[:-1])
+
+
+def config_draws(n_before_raw, n_after_raw, seed, resize_before=None, resize_after=None, noise_before=None, noise_after=None,
+                 outliers_before=0, outliers_after=0):
+    """The random outcomes GetCloudsFromConfig (common.cpp:134-190) draws for these options, in the form mi_prepare_cloud and
+    oracle_prepare_cloud take them: two dicts (before, after) with subcloud_idx, shuffle_idx, noise_rows, noise_unit,
+    outlier_unit.  Index vectors: the reference's own generator (ref_permutation_sequence), consumed in the reference's order;
+    unit draws: this process's C library rand() seeded like mainwrapper.cpp:17-18 -- the same one the reference build calls."""
+    sub_b = resize_before is not None and resize_before < n_before_raw        # GetSubcloud draws only then (common.cpp:27-28)
+    sub_a = resize_after is not None and resize_after < n_after_raw
+    nb = resize_before if sub_b else n_before_raw
+    na = resize_after if sub_a else n_after_raw
+    sizes = ([n_before_raw] if sub_b else []) + ([n_after_raw] if sub_a else []) + [nb, na]
+    sizes += ([nb] if noise_before is not None else []) + ([na] if noise_after is not None else [])
+    perms = list(permutation_sequence(seed, sizes))
+    b = {"subcloud_idx": perms.pop(0)[:nb].copy() if sub_b else None}
+    a = {"subcloud_idx": perms.pop(0)[:na].copy() if sub_a else None}
+    b["shuffle_idx"], a["shuffle_idx"] = perms.pop(0), perms.pop(0)
+
+    def rows(n, noise):
+        if noise is None:
+            return None
+        affected = int(np.clip(np.floor(np.float32(noise[0]) * np.float32(n) + np.float32(0.5)), 0, n))   # std::round, clamped
+        return np.nonzero(perms.pop(0) < affected)[0].astype(np.int32)      # ApplyPermutation: flag[perm[i]]
+    b["noise_rows"], a["noise_rows"] = rows(nb, noise_before), rows(na, noise_after)
+
+    libc = C.CDLL("libc.so.6")
+    libc.srand(C.c_uint(seed))
+
+    def unit(count):        # static_cast<float>(rand()) / RAND_MAX   (testutils.cpp:10; RAND_MAX converts to 2^31 in fp32)
+        return (np.array([libc.rand() for _ in range(3 * count)], np.int64).astype(np.float32) / np.float32(2147483648.0)).reshape(count, 3)
+    for d in (b, a):
+        d["noise_unit"] = None if d["noise_rows"] is None else unit(len(d["noise_rows"]))
+    b["outlier_unit"] = unit(outliers_before) if outliers_before else None
+    a["outlier_unit"] = unit(outliers_after) if outliers_after else None
+    return b, a

@@ -90,6 +90,13 @@ void  oracle_nicp(const float* before, int m, const float* after, int n, float e
                   const int* subcloud_idx, int subcloud_n, const int* perms, float rot9[9], float trans3[3], int* repetitions,
                   float* error);
 
+/* ---- input stage, Common::GetCloudsFromConfig for one cloud (oracle/prep_oracle.c) ---- */
+/* NULL index vectors / zero counts / rot9_colmajor NULL: stage absent.  out holds (cloud size + n_outliers) points; returns that count. */
+int   oracle_prepare_cloud(const float* raw, int n_raw, const int* subcloud_idx, int subcloud_n, const int* shuffle_idx,
+                           const int* noise_rows, const float* noise_unit, int n_noise, float noise_intensity,
+                           const float* outlier_unit, int n_outliers, int has_spread, float spread, const float* rot9_colmajor,
+                           const float* trans3, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,3 +103,35 @@ def synth_cloud(n, seed=666, m=None):
 
 def frob(R1, t1, R2, t2):
     return float(np.sqrt(((np.asarray(R1, np.float64) - R2) ** 2).sum() + ((np.asarray(t1, np.float64) - t2) ** 2).sum()))
+
+
+def prepare_cases(golden):
+    """The input-stage fixture (tests/golden/bunny_prepare.npz, oracle/make_golden_prepare.py) as a list of
+    (options, raw cloud, {side: draws}, {side: the reference's prepared cloud})."""
+    z = golden.npz("bunny_prepare.npz")
+    raw_all = golden.npz("bunny_clouds.npz")["before"]
+    cases = []
+    k = 0
+    while "c%d_options" % k in z.files:
+        opt = json.loads(str(z["c%d_options" % k]))
+        draws = {}
+        for side in "ba":
+            d = {}
+            for name in ("subcloud_idx", "shuffle_idx", "noise_rows", "noise_unit", "outlier_unit"):
+                key = "c%d_%s_%s" % (k, side, name)
+                d[name] = (z[key].astype(np.int32) if name.endswith(("idx", "rows")) else z[key]) if key in z.files else None
+            draws[side] = d
+        cases.append((opt, raw_all[:opt["raw_rows"]], draws, {"b": z["c%d_before" % k], "a": z["c%d_after" % k]}))
+        k += 1
+    return cases
+
+
+def prepare_kwargs(opt, draws, side):
+    """Arguments of oraclebind.prepare_cloud / Context.prepare_cloud for one side ('b' = before, 'a' = after) of a case."""
+    d = draws[side]
+    noise = opt["noise_before" if side == "b" else "noise_after"]
+    kw = dict(subcloud_idx=d["subcloud_idx"], shuffle_idx=d["shuffle_idx"], noise_rows=d["noise_rows"], noise_unit=d["noise_unit"],
+              noise_intensity=0.0 if noise is None else noise[1], outlier_unit=d["outlier_unit"], spread=opt["spread"])
+    if side == "a":
+        kw.update(R=np.array(opt["R"], np.float32), t=np.array(opt["t"], np.float32))
+    return kw

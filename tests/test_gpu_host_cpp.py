@@ -124,3 +124,31 @@ def test_mi_slam_rejects_unknown_method_like_the_reference(tmp_path):
            "rotation": [1, 0, 0, 0, 1, 0, 0, 0, 1]}
     r = run_mi_slam(cfg, tmp_path)
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("variant", ["explicit", "random-transform", "two-files"])
+def test_device_input_stage_equals_the_host_one(tmp_path, variant):
+    # --prepare device (mi_prepare_cloud, the default) and --prepare host (cloud_io.cpp's mirror of GetCloudsFromConfig) draw the
+    # same random outcomes and must dump identical clouds: resize, normalisation, shuffle, noise, outliers, transformation
+    make_obj(tmp_path / "model.obj", n_vertices=2000, seed=11)
+    make_obj(tmp_path / "other.obj", n_vertices=1500, seed=12)
+    cfg = {"before-path": "model.obj", "after-path": "model.obj", "method": "icp", "cloud-spread": 7.5, "max-iterations": 3,
+           "random-seed": 31, "cloud-before-resize": 5000, "cloud-after-resize": 7000, "noise-affected-points-before": 0.2,
+           "noise-intensity-before": 0.05, "noise-affected-points-after": 0.6, "noise-intensity-after": 0.01,
+           "additional-outliers-before": 17, "additional-outliers-after": 3}
+    if variant == "random-transform":
+        cfg.update({"translation-range": 2.0, "rotation-range": 0.4})
+    else:
+        cfg.update({"translation": [0.3, -0.2, 0.1], "rotation": [0.9553365, -0.2955202, 0.0, 0.2955202, 0.9553365, 0.0, 0.0, 0.0, 1.0]})
+    if variant == "two-files":
+        cfg["after-path"] = "other.obj"
+        cfg["cloud-after-resize"] = 100000          # beyond the cloud: no subcloud, nothing drawn
+    dumps = {}
+    for where in ("device", "host"):
+        r = run_mi_slam(cfg, tmp_path, "--prepare", where)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        dumps[where] = read_dump(tmp_path / "clouds.bin")
+    for k in (0, 1):
+        assert dumps["device"][k].shape == dumps["host"][k].shape
+        assert np.array_equal(dumps["device"][k].view(np.uint32), dumps["host"][k].view(np.uint32)), (variant, k)
+    assert dumps["device"][0].shape == (5017, 3)

@@ -21,7 +21,7 @@ def run(cfg, tmp_path, *extra, dump=False):
         pytest.skip("mi-slam not built (run __graft_entry__.build())")
     p = tmp_path / "cfg.json"
     p.write_text(json.dumps(cfg) if isinstance(cfg, dict) else cfg)
-    args = [EXE, str(p)] + list(extra)
+    args = [EXE, str(p), "--prepare", "host"] + list(extra)      # the device input stage is the GPU suite's (test_gpu_host_cpp.py)
     if dump:
         args += ["--dump-clouds", str(tmp_path / "clouds.bin")]
     env = dict(os.environ, MISLAM_DUMP_ONLY="1")
