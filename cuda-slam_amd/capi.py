@@ -36,7 +36,7 @@ EXPORTS = [
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_estep",
     "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
     "mi_prepare_params_default", "mi_prepare_cloud",
-    "mi_cpd_mstep", "mi_profile_enable", "mi_profile_select", "mi_profile_reset", "mi_profile_get",
+    "mi_cpd_mstep", "mi_profile_enable", "mi_profile_select", "mi_profile_reset", "mi_profile_get", "mi_nn_kernel_name",
 ]
 
 
@@ -428,6 +428,10 @@ class Context:
     # ---- profiling
     def profile_enable(self, on=True):
         _check(lib().mi_profile_enable(self._h, 1 if on else 0))
+
+    def nn_kernel_name(self, n_moving, m_fixed_local, nn_mode=NN_AUTO):
+        lib().mi_nn_kernel_name.restype = C.c_char_p
+        return lib().mi_nn_kernel_name(self._h, n_moving, m_fixed_local, nn_mode).decode()
 
     def profile_select(self, kernels=None):
         """Restrict the event timing to these kernels (KERNEL_* ids); None = all."""

@@ -202,7 +202,7 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     c->idx_tmp.release(); c->keep_tmp.release();
     c->tcodes_in.release(); c->tcodes_out.release(); c->torder_in.release(); c->torder_out.release();
     c->tbbox.release(); c->tsort_temp.release(); c->tpts.release(); c->tboxes.release(); c->sorder.release(); c->sinv.release(); c->resid.release();
-    c->tpairs.release(); c->tpairs_half.release(); c->tleaf.release(); c->tidx.release();
+    c->tpairs.release(); c->tpairs_half.release(); c->tleaf.release(); c->tidx.release(); c->twork.release();
     for (auto& s : c->spans) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->d_state) (void)hipFree(c->d_state);
@@ -415,13 +415,23 @@ static int resolve_nn_mode(int nn_mode, int m_local)
     return m_local >= 32768 ? MI_NN_TREE : MI_NN_BRUTEFORCE;
 }
 
+extern "C" const char* mi_nn_kernel_name(const mi_ctx* c, int n_moving, int m_fixed_local, int nn_mode)
+{
+    if (!c) return "";
+    if (resolve_nn_mode(nn_mode, m_fixed_local) != MI_NN_TREE) return "nn_bruteforce_kernel";
+    return nn_tree_kernel_name(n_moving, env_int("MISLAM_TREE_R", 0), true, c->cu_count * 8);
+}
+
 int mislam::launch_nn(mi_ctx* c, const float* sx, const float* sy, const float* sz, int n, int m_local, int index_base, int fma,
                       const int* done_flag, int nn_mode)
 {
     if (resolve_nn_mode(nn_mode, m_local) == MI_NN_TREE) {
         MI_TRY(ensure_tree(c, m_local, index_base));
+        MI_TRY(c->twork.reserve(TREE_WORK_COUNTER_WORDS));
         ProfScope ps(c, MI_KERNEL_NN);
-        MI_HIP(nn_tree_query(c->tree, sx, sy, sz, n, c->keys.p, done_flag, fma, env_int("MISLAM_TREE_R", 0), c->stream));
+        // resident grid for the dynamically fetching walk: 8 blocks of 4 waves fill a CU's 32 wave slots (17 KB of LDS each)
+        MI_HIP(nn_tree_query(c->tree, sx, sy, sz, n, c->keys.p, done_flag, fma, env_int("MISLAM_TREE_R", 0), c->stream, c->twork.p,
+                             c->cu_count * 8));
         return MI_OK;
     }
     const NnPlan p = plan_nn(c, n, m_local);

@@ -13,6 +13,11 @@ namespace mislam {
 //   compact copies, trail + bounds (the default walk):  8: 1.25 / 0.71 / 17.8    16: 1.14 / 0.68 / 16.5    32: 1.22 / 0.77 / 17.9
 constexpr int TREE_LEAF = MISLAM_TREE_LEAF;
 constexpr int TREE_MAX_HEIGHT = 24;
+// default walk: dynamic work fetching (nn_tree_lane_dynamic_kernel) and the number of finished lanes that triggers a refill
+constexpr bool TREE_DYNAMIC_DEFAULT = true;
+constexpr int TREE_REFILL_MIN = 24;
+constexpr int TREE_DYNAMIC_PARTS = 8;          // ranges of the moving cloud = XCDs; the work counters are 16 words apart
+constexpr int TREE_WORK_COUNTER_WORDS = 16 * TREE_DYNAMIC_PARTS;
 
 struct NnTreeView {
     const float4* pts;                // n_leaves * TREE_LEAF sorted points, w = GLOBAL index bits
@@ -58,7 +63,11 @@ hipError_t permute_soa(const float* x, const float* y, const float* z, const int
                        float* oz, hipStream_t s);
 hipError_t tree_build(const TreeBuildArgs& a, hipStream_t s);
 // R = sources per lane (1 or 2); sources should be Morton-sorted (speed only -- the result never depends on their order)
+// name of the kernel nn_tree_query launches for these arguments and the current MISLAM_TREE_* settings (compact copies built)
+const char* nn_tree_kernel_name(int n, int R, bool have_counter, int resident_blocks);
+// work_counter (one device word, or null) + resident_blocks enable the dynamically fetching form of the default walk.
 hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, const float* sz, int n, unsigned long long* keys,
-                         const int* done_flag, int fma, int R, hipStream_t s);
+                         const int* done_flag, int fma, int R, hipStream_t s, unsigned int* work_counter = nullptr,
+                         int resident_blocks = 0);
 
 }  // namespace mislam

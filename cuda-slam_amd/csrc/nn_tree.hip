@@ -648,6 +648,156 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
     }
 }
 
+// The same walk with DYNAMIC work fetching.  A wave of the kernel above runs as long as its slowest lane while the others idle
+// (counters: 1 875 load instructions per wave where a lane alone needs a few hundred).  Here a resident grid of waves pulls
+// moving points from counters: whenever at least `refill_min` lanes of a wave have finished, those lanes store their
+// results and take the next consecutive points (Morton neighbours, so the wave stays spatially coherent).  Refilling in
+// batches, not lane by lane, keeps the new walks descending together while the rest wait at most one descent.  Per-point
+// results do not depend on which lane or wave computes them: bit-identical to the static kernel.
+// Measured at N = M = 1e6 (average search of the bench's 50 iterations / FETCH_SIZE per launch): static 0.814 ms / 57 MB,
+// one counter 0.741 ms / 163 MB, one counter per XCD range (below) 0.750 ms / 27 MB; 9.20 -> 8.46 ms at 1e7.
+template <bool FMA>
+__global__ __launch_bounds__(256) void nn_tree_lane_dynamic_kernel(NnTreeView t, const float* __restrict__ sx, const float* __restrict__ sy,
+                                                                   const float* __restrict__ sz, int n, unsigned long long* __restrict__ keys,
+                                                                   const int* __restrict__ done_flag, unsigned int* __restrict__ next_point,
+                                                                   int refill_min, int parts)
+{
+    if (done_flag != nullptr && *done_flag != 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* st_lb = reinterpret_cast<float*>(smem);
+    const float4* __restrict__ pairs = t.pairs;
+    const float4* __restrict__ leaf_soa = t.leaf_soa;
+    const int* __restrict__ leaf_idx = t.leaf_idx;
+    const float4 root_lo = t.boxes[0], root_hi = t.boxes[1];
+    const int first_leaf = t.n_pad - 1;
+    const int lane = threadIdx.x & 63;
+
+    int i = -1;                      // the moving point this lane works on, -1 = none
+    float p[3] = {0.f, 0.f, 0.f};
+    float best = __builtin_inff();
+    unsigned int bidx = 0u;
+    int bslot = -1;
+    unsigned int trail = 0;
+    int node = 0, level = 0;
+    bool have = false;
+    bool exhausted = false;          // wave-uniform: the counter has run past n
+    // first assignment static, like the kernel above (the four waves of a block share cache lines of 256 consecutive points);
+    // the counter starts behind the resident grid's first points (set by the host)
+    auto begin = [&](int q) {
+        i = q;
+        p[0] = sx[i]; p[1] = sy[i]; p[2] = sz[i];
+        const unsigned long long k0 = keys[i];
+        const unsigned int hi0 = (unsigned int)(k0 >> 32);
+        best = hi0 < 0x7f800000u ? __uint_as_float(hi0) : __builtin_inff();
+        bidx = hi0 < 0x7f800000u ? (unsigned int)(k0 & 0xffffffffull) : 0u;
+        bslot = -1;
+        trail = 0;
+        node = 0;
+        level = 0;
+        const float root_lb = box_bound<FMA>(root_lo, root_hi, p, p);
+        have = root_lb <= best && root_lb < __builtin_inff();
+    };
+    // The moving cloud is cut into `parts` contiguous ranges with a counter each (64 bytes apart).  parts = 8: one range per XCD
+    // (workgroups are dealt to the XCDs round-robin, so block b runs on XCD b mod 8) -- an XCD then walks one eighth of the
+    // Morton curve and its 4 MB L2 holds that eighth of the hierarchy instead of a bit of everything; a wave whose range is used
+    // up takes from the next one, so the XCDs still balance each other.  parts = 1: one range, one counter.
+    const int part0 = parts == 1 ? 0 : (int)(blockIdx.x % (unsigned int)parts);
+    const int local_block = parts == 1 ? (int)blockIdx.x : (int)(blockIdx.x / (unsigned int)parts);
+    const int static_blocks = (int)gridDim.x / parts;     // per range: blocks whose first 256 points are assigned statically
+    auto range_lo = [&](int k) { return (int)((long long)n * k / parts); };
+    if (local_block < static_blocks) {
+        const int q = range_lo(part0) + local_block * 256 + (int)threadIdx.x;
+        if (q < range_lo(part0 + 1)) begin(q);
+    }
+    int cur = part0, tried = 0;      // wave-uniform: the range this wave draws from, ranges found used up
+    auto pop = [&]() {
+        have = false;
+        while (trail != 0) {
+            const int b = 31 - __builtin_clz(trail);
+            trail &= ~(1u << b);
+            const int anc = ((node + 1) >> (level - b)) - 1;
+            node = ((anc + 1) ^ 1) - 1;
+            level = b;
+            if (st_lb[b * 256 + threadIdx.x] <= best) { have = true; break; }
+        }
+    };
+    auto offer = [&](float d, int slot) {
+        const bool tie = d == best;
+        const bool lt = d < best;
+        best = lt ? d : best;
+        bslot = lt ? slot : bslot;
+        if (tie) {
+            const unsigned int j = (unsigned int)leaf_idx[slot];
+            const unsigned int jb = bslot >= 0 ? (unsigned int)leaf_idx[bslot] : bidx;
+            if (j < jb) bslot = slot;
+        }
+    };
+    for (;;) {
+        // ---- finished lanes store their result; a batch of them takes the next points
+        if (!have && i >= 0) {
+            if (best < __builtin_inff()) {
+                const unsigned int j = bslot >= 0 ? (unsigned int)leaf_idx[bslot] : bidx;
+                keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | j;
+            }
+            i = -1;
+        }
+        const unsigned long long idle = __ballot(!have);
+        const int n_idle = __popcll(idle);
+        if (n_idle == 64 && exhausted) break;
+        if (!exhausted && n_idle >= refill_min) {
+            // (a per-block stream of 256-point chunks through an LDS counter instead -- the four waves of a block keep sharing
+            // cache lines, but blocks no longer balance each other -- measured 0.80 ms against 0.75 ms for this global counter)
+            while (!exhausted) {
+                const int lo = range_lo(cur), hi = range_lo(cur + 1);
+                unsigned int taken = 0;          // points of this range handed out before this fetch
+                if (lane == 0) taken = atomicAdd(next_point + 16 * cur, (unsigned int)n_idle);
+                taken = (unsigned int)__builtin_amdgcn_readfirstlane((int)taken);
+                if ((long long)lo + taken < (long long)hi) {
+                    if (!have) {
+                        const long long q = (long long)lo + taken + __popcll(idle & ((1ull << lane) - 1ull));
+                        if (q < (long long)hi) begin((int)q);
+                    }
+                    break;
+                }
+                cur = cur + 1 == parts ? 0 : cur + 1;      // used up: the next range
+                tried += 1;
+                exhausted = tried >= parts;
+            }
+            if (__ballot(have) == 0ull) continue;      // nothing to walk (all pruned at the root, or no points left): store / refill again
+        }
+        while (have && node < first_leaf) {
+            const float4* __restrict__ rec = pairs + 3 * (size_t)node;
+            const float4 a = rec[0], b = rec[1], c = rec[2];
+            const float lbl = box_bound<FMA>(make_float4(a.x, a.y, a.z, 0.f), make_float4(a.w, b.x, b.y, 0.f), p, p);
+            const float lbr = box_bound<FMA>(make_float4(b.z, b.w, c.x, 0.f), make_float4(c.y, c.z, c.w, 0.f), p, p);
+            const int l = 2 * node + 1;
+            const bool left_near = lbl <= lbr;
+            const float lbn = left_near ? lbl : lbr, lbf = left_near ? lbr : lbl;
+            node = left_near ? l : l + 1;
+            level += 1;
+            if (lbf <= best && lbf < __builtin_inff()) {
+                trail |= 1u << level;
+                st_lb[level * 256 + threadIdx.x] = lbf;
+            }
+            if (!(lbn <= best && lbn < __builtin_inff())) pop();
+        }
+        if (have) {
+            const int leaf = node - first_leaf;
+            const int slot0 = leaf * TREE_LEAF;
+            const float4* __restrict__ lp = leaf_soa + (size_t)leaf * (3 * TREE_LEAF / 4);
+#pragma unroll
+            for (int c4 = 0; c4 < TREE_LEAF / 4; c4++) {
+                const float4 X = lp[c4], Y = lp[TREE_LEAF / 4 + c4], Z = lp[2 * (TREE_LEAF / 4) + c4];
+                offer(sq3<FMA>(X.x - p[0], Y.x - p[1], Z.x - p[2]), slot0 + 4 * c4);
+                offer(sq3<FMA>(X.y - p[0], Y.y - p[1], Z.y - p[2]), slot0 + 4 * c4 + 1);
+                offer(sq3<FMA>(X.z - p[0], Y.z - p[1], Z.z - p[2]), slot0 + 4 * c4 + 2);
+                offer(sq3<FMA>(X.w - p[0], Y.w - p[1], Z.w - p[2]), slot0 + 4 * c4 + 3);
+            }
+            pop();
+        }
+    }
+}
+
 // Per-lane form without any stack: the heap numbering makes ancestors and siblings computable, so a 32-bit "trail" (bit l set
 // = the sibling of this lane's level-l ancestor is still to be visited) replaces the LDS stack.  Same visiting order as the
 // stack form (deepest pending sibling first); a pending sibling's bound is re-computed from its box when it comes up
@@ -718,10 +868,32 @@ __global__ __launch_bounds__(256) void nn_tree_trail_kernel(const float4* __rest
     if (best < __builtin_inff()) keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
 }
 
+// Dynamic work fetching for the default walk: MISLAM_TREE_DYNAMIC=1 forces it, =0 forbids it (read per call: the tests flip it);
+// unset, a moving cloud that fits the resident grid has nothing to fetch and takes the static kernel.
+static bool want_dynamic(int n, bool have_counter, int resident_blocks)
+{
+    if (!have_counter || resident_blocks <= 0) return false;
+    const char* dyn_env = getenv("MISLAM_TREE_DYNAMIC");
+    return dyn_env ? *dyn_env == '1' : (TREE_DYNAMIC_DEFAULT && (n + 255) / 256 > resident_blocks);
+}
+
+const char* nn_tree_kernel_name(int n, int R, bool have_counter, int resident_blocks)
+{
+    if (R < 0) return "nn_tree_trail_kernel";
+    if (R > 0) return "nn_tree_wave_kernel";
+    const char* compact_env = getenv("MISLAM_TREE_COMPACT");
+    if (compact_env && *compact_env == '0') return "nn_tree_lane_kernel";
+    const char* half_env = getenv("MISLAM_TREE_HALF");
+    if (half_env && *half_env == '1') return "nn_tree_lane_compact_kernel";
+    return want_dynamic(n, have_counter, resident_blocks) ? "nn_tree_lane_dynamic_kernel" : "nn_tree_lane_compact_kernel";
+}
+
 hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, const float* sz, int n, unsigned long long* keys,
-                         const int* done_flag, int fma, int R, hipStream_t s)
+                         const int* done_flag, int fma, int R, hipStream_t s, unsigned int* work_counter, int resident_blocks)
 {
     if (n <= 0) return hipSuccess;
+    const char* resident_env = getenv("MISLAM_TREE_RESIDENT");      // test hook: a tiny resident grid makes a small cloud refill often
+    if (resident_env && atoi(resident_env) > 0) resident_blocks = atoi(resident_env);
     if (R == 0) {   // per-lane form with an LDS stack (default: 1.68 / 1.04 ms at N = M = 1e6 early / late; trail form 1.84 / 1.09)
         const int depth = t.height + 2;
         const size_t lds = (size_t)depth * 256 * 8;
@@ -735,6 +907,21 @@ hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, 
             // the 16 bytes save.  Kept as a tested alternative.
             const char* half_env = getenv("MISLAM_TREE_HALF");
             const bool half_nodes = half_env && *half_env == '1';
+            if (!half_nodes && want_dynamic(n, work_counter != nullptr, resident_blocks)) {
+                const char* refill_env = getenv("MISLAM_TREE_REFILL");
+                int refill_min = refill_env ? atoi(refill_env) : TREE_REFILL_MIN;
+                refill_min = refill_min < 1 ? 1 : (refill_min > 64 ? 64 : refill_min);
+                dim3 dgrid(std::min((n + 255) / 256, resident_blocks));
+                const char* parts_env = getenv("MISLAM_TREE_PARTS");      // 8 = one range of the moving cloud per XCD (default), 1 = one range
+                int parts = parts_env ? atoi(parts_env) : TREE_DYNAMIC_PARTS;
+                if (parts < 1 || parts > TREE_DYNAMIC_PARTS || (int)dgrid.x < parts) parts = 1;
+                // every range's counter starts behind the points its blocks take statically
+                hipError_t e = hipMemsetD32Async((hipDeviceptr_t)work_counter, (int)(dgrid.x / parts) * 256, 16 * TREE_DYNAMIC_PARTS, s);
+                if (e != hipSuccess) return e;
+                if (fma) hipLaunchKernelGGL(nn_tree_lane_dynamic_kernel<true>, dgrid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, work_counter, refill_min, parts);
+                else hipLaunchKernelGGL(nn_tree_lane_dynamic_kernel<false>, dgrid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, work_counter, refill_min, parts);
+                return hipGetLastError();
+            }
             if (half_nodes && t.pairs_half != nullptr) {
                 if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag);
                 else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag);

@@ -375,6 +375,9 @@ int mi_profile_select(mi_ctx* ctx, unsigned int kernel_mask);
 int mi_profile_reset(mi_ctx* ctx);
 /* total_ms = sum of event-timed durations of that kernel since the last reset; launches = how many. */
 int mi_profile_get(mi_ctx* ctx, int kernel, double* total_ms, long long* launches);
+/* Name of the correspondence-search kernel (MI_KERNEL_NN) a search of n_moving points against m_fixed_local fixed points runs
+ * with this nn_mode and the current settings -- the name a rocprofv3 kernel trace shows (static string). */
+const char* mi_nn_kernel_name(const mi_ctx* ctx, int n_moving, int m_fixed_local, int nn_mode);
 
 #ifdef __cplusplus
 }

@@ -86,15 +86,22 @@ def test_tree_equals_bruteforce_on_clustered_and_degenerate_clouds(ctx, capi, mo
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", ["R=-1", "R=1", "R=2", "COMPACT=0", "HALF=1"])
+@pytest.mark.parametrize("variant", ["R=-1", "R=1", "R=2", "COMPACT=0", "HALF=1", "DYNAMIC=1", "DYNAMIC=1,RESIDENT=2", "DYNAMIC=1,RESIDENT=1,REFILL=1",
+                                     "DYNAMIC=1,RESIDENT=3,REFILL=64", "DYNAMIC=1,RESIDENT=8", "DYNAMIC=1,RESIDENT=9,REFILL=1",
+                                     "DYNAMIC=1,RESIDENT=16,PARTS=1", "DYNAMIC=0"])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_alternative_hierarchy_walks_are_exact_too(ctx, capi, oracle, monkeypatch, variant, mode):
-    # the alternative query forms (the default is the per-lane walk over the compact copies, register trail + bounds in LDS):
+    # the alternative query forms (the default is the per-lane walk over the compact copies, register trail + bounds in LDS --
+    # with dynamic work fetching once the moving cloud exceeds the resident grid, which this small case forces on / off):
     # R=-1 per-lane stackless trail walk over the float4 records; R=1, 2 one walk per wave (scalar loads, stack across the lanes
     # of a VGPR); COMPACT=0 the per-lane walk with a (node, bound) stack over the float4 records; HALF=1 the default walk over
-    # half-precision sibling boxes rounded outwards
-    name, value = variant.split("=")
-    monkeypatch.setenv("MISLAM_TREE_" + name, value)
+    # half-precision sibling boxes rounded outwards; DYNAMIC=1 the fetching walk (RESIDENT = blocks in its grid, so that this
+    # small cloud is fetched in many batches -- from 8 blocks on, one range of the cloud per XCD with stealing, 9 leaves a block
+    # without a static share; REFILL = finished lanes that trigger a fetch; PARTS=1 one range for all)
+    for setting in variant.split(","):
+        name, value = setting.split("=")
+        monkeypatch.setenv("MISLAM_TREE_" + name, value)
+    assert ("dynamic" in ctx.nn_kernel_name(4133, 8000, capi.NN_TREE)) == variant.startswith("DYNAMIC=1")
     rng = np.random.default_rng(31)
     base = rng.uniform(-5, 5, (6000, 3)).astype(np.float32)
     tgt = np.concatenate([base, base[:2000]])                       # duplicates: ties

@@ -37,9 +37,11 @@ def main():
         "correction": "MI355X_MICROARCH.md HBM section: counters are in KB; gfx950 FETCH_SIZE counts 64 B per 128 B request, so x2 on "
                       "the read side (calibrated there for 16 B/lane streams; other widths uncalibrated)",
     }
+    tree_note = ("exact box-hierarchy search (default path): compact hierarchy (12 MB leaf coordinates + 3 MB sibling "
+                 "records) + 12 MB sources + 8 MB keys read, 8 MB keys written; the per-lane walks are served by L2/MALL")
     notes = {
-        "nn_tree_lane_compact_kernel": "exact box-hierarchy search (default path): compact hierarchy (12 MB leaf coordinates + 3 MB sibling "
-                                       "records) + 12 MB sources + 8 MB keys read, 8 MB keys written; the per-lane walks are served by L2/MALL",
+        "nn_tree_lane_dynamic_kernel": tree_note,
+        "nn_tree_lane_compact_kernel": tree_note,
         "nn_bruteforce_kernel": "every-pair search, 8 XCD-pinned target chunks: each XCD reads all sources once (8 x 12 MB) and posts one "
                                 "8-byte atomicMin per source and chunk",
     }
