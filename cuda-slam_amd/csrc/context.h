@@ -109,6 +109,7 @@ struct mi_ctx {
     mislam::DevBuf<float4> tpts, tboxes;
     mislam::DevBuf<float4> tpairs, tleaf;                // compact copies for the per-lane walk (NnTreeView)
     mislam::DevBuf<int> tidx;
+    mislam::DevBuf<float4> tquads;                       // 4-wide records for the wide walk
     mislam::DevBuf<unsigned int> twork;                  // the search's work counter (dynamic fetching)
     mislam::DevBuf<uint4> tpairs_half;
     mislam::NnTreeView tree{};

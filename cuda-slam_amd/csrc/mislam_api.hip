@@ -202,7 +202,7 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     c->idx_tmp.release(); c->keep_tmp.release();
     c->tcodes_in.release(); c->tcodes_out.release(); c->torder_in.release(); c->torder_out.release();
     c->tbbox.release(); c->tsort_temp.release(); c->tpts.release(); c->tboxes.release(); c->sorder.release(); c->sinv.release(); c->resid.release();
-    c->tpairs.release(); c->tpairs_half.release(); c->tleaf.release(); c->tidx.release(); c->twork.release();
+    c->tpairs.release(); c->tpairs_half.release(); c->tleaf.release(); c->tidx.release(); c->twork.release(); c->tquads.release();
     for (auto& s : c->spans) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->d_state) (void)hipFree(c->d_state);
@@ -380,15 +380,19 @@ static int ensure_tree(mi_ctx* c, int m_local, int index_base)
     MI_TRY(c->tpairs_half.reserve((size_t)2 * n_pad));
     MI_TRY(c->tleaf.reserve((size_t)n_leaves * (3 * TREE_LEAF / 4)));
     MI_TRY(c->tidx.reserve((size_t)n_leaves * TREE_LEAF));
+    const int quad_levels = (height + 1) / 2, quad_parity = height & 1;
+    MI_TRY(c->tquads.reserve(6 * quad_record_count(quad_levels) + 6));
     TreeBuildArgs a{};
     MI_TRY(morton_args(c, c->tx.p, c->ty.p, c->tz.p, m_local, c->torder_out.p, &a.morton));
     a.index_base = index_base; a.n_leaves = n_leaves; a.n_pad = n_pad;
     a.pts = c->tpts.p; a.boxes = c->tboxes.p;
     a.pairs = c->tpairs.p; a.pairs_half = c->tpairs_half.p; a.leaf_soa = c->tleaf.p; a.leaf_idx = c->tidx.p;
+    a.quads = c->tquads.p; a.quad_levels = quad_levels; a.quad_parity = quad_parity;
     MI_HIP(tree_build(a, c->stream));
     c->tree.pts = c->tpts.p; c->tree.boxes = c->tboxes.p;
     c->tree.pairs = c->tpairs.p; c->tree.pairs_half = c->tpairs_half.p; c->tree.leaf_soa = c->tleaf.p; c->tree.leaf_idx = c->tidx.p;
     c->tree.n_pad = n_pad; c->tree.height = height;
+    c->tree.quads = c->tquads.p; c->tree.quad_levels = quad_levels; c->tree.quad_parity = quad_parity;
     c->tree_valid = true;
     return MI_OK;
 }

@@ -16,6 +16,7 @@ constexpr int TREE_MAX_HEIGHT = 24;
 // default walk: dynamic work fetching (nn_tree_lane_dynamic_kernel) and the number of finished lanes that triggers a refill
 constexpr bool TREE_DYNAMIC_DEFAULT = true;
 constexpr int TREE_REFILL_MIN = 24;
+constexpr bool TREE_WIDE_DEFAULT = false;      // the 4-wide walk (nn_tree_wide_kernel)
 constexpr int TREE_DYNAMIC_PARTS = 8;          // ranges of the moving cloud = XCDs; the work counters are 16 words apart
 constexpr int TREE_WORK_COUNTER_WORDS = 16 * TREE_DYNAMIC_PARTS;
 
@@ -31,6 +32,9 @@ struct NnTreeView {
     const uint4* pairs_half;          // the same records in half precision, boxes rounded outwards: 2 x 16 bytes (experimental)
     const float4* leaf_soa;           // leaf f: x[TREE_LEAF], y[TREE_LEAF], z[TREE_LEAF] (3*TREE_LEAF/4 float4; no index word)
     const int* leaf_idx;              // GLOBAL index of sorted slot s (read only for the winner and on exact ties)
+    // 4-wide records for the wide walk (nn_tree.hip, tree_pack_quads_kernel): two binary levels per visit
+    const float4* quads;
+    int quad_levels, quad_parity;     // wide levels above the leaves = ceil(height / 2); height & 1
 };
 
 // Morton order of a SoA cloud: order_out[s] = index of the s-th point along the Z-curve of the cloud's bounding box.
@@ -55,7 +59,11 @@ struct TreeBuildArgs {
     uint4* pairs_half;                // 2 * (n_pad - 1) uint4, or null
     float4* leaf_soa;                 // n_leaves * 3 * TREE_LEAF / 4 float4
     int* leaf_idx;                    // n_leaves * TREE_LEAF
+    float4* quads;                    // 6 * quad_record_count(quad_levels) float4, or null
+    int quad_levels, quad_parity;     // ceil(height / 2), height & 1
 };
+
+inline size_t quad_record_count(int quad_levels) { return (size_t)(0x55555555u & ((1u << (2 * quad_levels)) - 1u)); }
 
 size_t tree_sort_temp_bytes(int m);
 hipError_t morton_order(const MortonArgs& a, hipStream_t s);

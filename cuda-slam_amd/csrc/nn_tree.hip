@@ -204,6 +204,41 @@ __global__ __launch_bounds__(256) void tree_pack_pairs_kernel(const float4* __re
     pairs[3 * (size_t)p + 2] = make_float4(rlo.z, rhi.x, rhi.y, rhi.z);
 }
 
+// 4-wide records for the wide walk: the same hierarchy read two binary levels at a time.  A wide node at wide level k, position
+// j stands for the binary node at binary level 2k - parity, position j (parity = height & 1; with an odd height the wide root
+// has two children and two empty boxes); its record holds the boxes of its four wide children, one coordinate of all four per
+// float4: (lo.x x4)(lo.y x4)(lo.z x4)(hi.x x4)(hi.y x4)(hi.z x4) = 96 bytes.  Wide level k starts at record (4^k - 1) / 3.
+__host__ __device__ __forceinline__ unsigned int quad_level_offset(int k) { return 0x55555555u & ((1u << (2 * k)) - 1u); }
+
+__global__ __launch_bounds__(256) void tree_pack_quads_kernel(const float4* __restrict__ boxes, int quad_levels, int parity, float4* __restrict__ quads)
+{
+    const unsigned int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= quad_level_offset(quad_levels)) return;
+    int k = 0;
+    while (quad_level_offset(k + 1) <= q) k++;
+    const unsigned int pos = q - quad_level_offset(k);
+    const int child_binary_level = 2 * (k + 1) - parity;
+    float lo[3][4], hi[3][4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const unsigned int cp = 4u * pos + c;
+        float4 l = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
+        float4 h = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), 0.f);
+        if (cp < (1u << child_binary_level)) {
+            const size_t b = (size_t)((1u << child_binary_level) - 1u) + cp;
+            l = boxes[2 * b];
+            h = boxes[2 * b + 1];
+        }
+        lo[0][c] = l.x; lo[1][c] = l.y; lo[2][c] = l.z;
+        hi[0][c] = h.x; hi[1][c] = h.y; hi[2][c] = h.z;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        quads[6 * (size_t)q + a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+        quads[6 * (size_t)q + 3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+    }
+}
+
 // Sibling-box records in half precision: 12 values in 24 of 32 bytes (2 loads instead of 3).  A value w of axis a is stored as
 // h ~ (w - c_a) / s_a (c, s: centre and half-extent of the root box, so |h| <= 1 and the grid is 2^-11 of the extent at
 // worst) and decoded as fma(float(h), s_a, c_a).  Lower corners are rounded DOWN and upper corners UP until the DECODED value
@@ -294,6 +329,10 @@ hipError_t tree_build(const TreeBuildArgs& a, hipStream_t s)
     }
     hipLaunchKernelGGL(tree_pack_leaves_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, a.pts, n_slots, reinterpret_cast<float*>(a.leaf_soa),
                        a.leaf_idx);
+    if (a.quads != nullptr && a.quad_levels > 0) {
+        const unsigned int records = quad_level_offset(a.quad_levels);
+        hipLaunchKernelGGL(tree_pack_quads_kernel, dim3((records + 255) / 256), dim3(256), 0, s, a.boxes, a.quad_levels, a.quad_parity, a.quads);
+    }
     return hipGetLastError();
 }
 
@@ -798,6 +837,165 @@ __global__ __launch_bounds__(256) void nn_tree_lane_dynamic_kernel(NnTreeView t,
     }
 }
 
+// The WIDE walk: the same hierarchy, the same exact pruning rule, two binary levels per visit (NnTreeView::quads).  One visit
+// loads the boxes of four children (6 x 16 bytes), sorts them by bound, steps into the nearest and remembers the others that
+// can still matter -- half the dependent steps of the binary walk, and a pending sibling costs no visit of its own.  Lanes of a
+// wave are therefore out of step less often (counters: 15.6 of 64 lanes active per VALU instruction in the binary walk).
+// Position bookkeeping: a lane is at (level, pos) = the pos-th wide node of its level; children are 4 pos + c, the ancestor at
+// level k is pos >> 2 (level - k), the leaf at level quad_levels is leaf number pos.  Pending children: per level up to three
+// words in LDS, farthest first, each the bound's bits with the child number in the two lowest mantissa bits (clearing them
+// rounds a non-negative bound DOWN: the test `bound <= best` only prunes a hair less, never more); how many are pending per
+// level is a 2-bit field of a register.  Same dynamic fetching, same per-XCD ranges as the kernel above.
+template <bool FMA>
+__global__ __launch_bounds__(256) void nn_tree_wide_kernel(NnTreeView t, const float* __restrict__ sx, const float* __restrict__ sy,
+                                                           const float* __restrict__ sz, int n, unsigned long long* __restrict__ keys,
+                                                           const int* __restrict__ done_flag, unsigned int* __restrict__ next_point,
+                                                           int refill_min, int parts)
+{
+    if (done_flag != nullptr && *done_flag != 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned int* st = reinterpret_cast<unsigned int*>(smem);      // [level - 1][3][256], levels 1 .. quad_levels
+    const float4* __restrict__ quads = t.quads;
+    const float4* __restrict__ leaf_soa = t.leaf_soa;
+    const int* __restrict__ leaf_idx = t.leaf_idx;
+    const float4 root_lo = t.boxes[0], root_hi = t.boxes[1];
+    const int leaf_level = t.quad_levels;
+    const int lane = threadIdx.x & 63;
+
+    int i = -1;
+    float p[3] = {0.f, 0.f, 0.f};
+    float best = __builtin_inff();
+    unsigned int bidx = 0u;
+    int bslot = -1;
+    unsigned int pend = 0;           // 2 bits per level: pending children there
+    unsigned int pos = 0;
+    int level = 0;
+    bool have = false;
+    bool exhausted = false;
+    auto begin = [&](int q) {
+        i = q;
+        p[0] = sx[i]; p[1] = sy[i]; p[2] = sz[i];
+        const unsigned long long k0 = keys[i];
+        const unsigned int hi0 = (unsigned int)(k0 >> 32);
+        best = hi0 < 0x7f800000u ? __uint_as_float(hi0) : __builtin_inff();
+        bidx = hi0 < 0x7f800000u ? (unsigned int)(k0 & 0xffffffffull) : 0u;
+        bslot = -1;
+        pend = 0;
+        pos = 0;
+        level = 0;
+        const float root_lb = box_bound<FMA>(root_lo, root_hi, p, p);
+        have = root_lb <= best && root_lb < __builtin_inff();
+    };
+    const int part0 = parts == 1 ? 0 : (int)(blockIdx.x % (unsigned int)parts);
+    const int local_block = parts == 1 ? (int)blockIdx.x : (int)(blockIdx.x / (unsigned int)parts);
+    const int static_blocks = (int)gridDim.x / parts;
+    auto range_lo = [&](int k) { return (int)((long long)n * k / parts); };
+    if (local_block < static_blocks) {
+        const int q = range_lo(part0) + local_block * 256 + (int)threadIdx.x;
+        if (q < range_lo(part0 + 1)) begin(q);
+    }
+    int cur = part0, tried = 0;
+    // nearest pending child of the deepest level that has one; a level whose nearest is already too far is dropped whole
+    auto pop = [&]() {
+        have = false;
+        while (pend != 0) {
+            const int b = (31 - __builtin_clz(pend)) >> 1;
+            const int count = (int)((pend >> (2 * b)) & 3u);
+            const unsigned int w = st[(((b - 1) * 3) + (count - 1)) * 256 + threadIdx.x];
+            if (__uint_as_float(w & ~3u) <= best) {
+                pend -= 1u << (2 * b);
+                pos = ((pos >> (2 * (level - b + 1))) << 2) | (w & 3u);
+                level = b;
+                have = true;
+                break;
+            }
+            pend &= ~(3u << (2 * b));
+        }
+    };
+    auto offer = [&](float d, int slot) {
+        const bool tie = d == best;
+        const bool lt = d < best;
+        best = lt ? d : best;
+        bslot = lt ? slot : bslot;
+        if (tie) {
+            const unsigned int j = (unsigned int)leaf_idx[slot];
+            const unsigned int jb = bslot >= 0 ? (unsigned int)leaf_idx[bslot] : bidx;
+            if (j < jb) bslot = slot;
+        }
+    };
+    for (;;) {
+        if (!have && i >= 0) {
+            if (best < __builtin_inff()) {
+                const unsigned int j = bslot >= 0 ? (unsigned int)leaf_idx[bslot] : bidx;
+                keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | j;
+            }
+            i = -1;
+        }
+        const unsigned long long idle = __ballot(!have);
+        const int n_idle = __popcll(idle);
+        if (n_idle == 64 && exhausted) break;
+        if (!exhausted && n_idle >= refill_min) {
+            while (!exhausted) {
+                const int lo = range_lo(cur), hi = range_lo(cur + 1);
+                unsigned int taken = 0;
+                if (lane == 0) taken = atomicAdd(next_point + 16 * cur, (unsigned int)n_idle);
+                taken = (unsigned int)__builtin_amdgcn_readfirstlane((int)taken);
+                if ((long long)lo + taken < (long long)hi) {
+                    if (!have) {
+                        const long long q = (long long)lo + taken + __popcll(idle & ((1ull << lane) - 1ull));
+                        if (q < (long long)hi) begin((int)q);
+                    }
+                    break;
+                }
+                cur = cur + 1 == parts ? 0 : cur + 1;
+                tried += 1;
+                exhausted = tried >= parts;
+            }
+            if (__ballot(have) == 0ull) continue;
+        }
+        while (have && level < leaf_level) {
+            const float4* __restrict__ rec = quads + 6 * (size_t)(quad_level_offset(level) + pos);
+            const float4 LX = rec[0], LY = rec[1], LZ = rec[2], HX = rec[3], HY = rec[4], HZ = rec[5];
+            float lb0 = box_bound<FMA>(make_float4(LX.x, LY.x, LZ.x, 0.f), make_float4(HX.x, HY.x, HZ.x, 0.f), p, p);
+            float lb1 = box_bound<FMA>(make_float4(LX.y, LY.y, LZ.y, 0.f), make_float4(HX.y, HY.y, HZ.y, 0.f), p, p);
+            float lb2 = box_bound<FMA>(make_float4(LX.z, LY.z, LZ.z, 0.f), make_float4(HX.z, HY.z, HZ.z, 0.f), p, p);
+            float lb3 = box_bound<FMA>(make_float4(LX.w, LY.w, LZ.w, 0.f), make_float4(HX.w, HY.w, HZ.w, 0.f), p, p);
+            unsigned int c0 = 0u, c1 = 1u, c2 = 2u, c3 = 3u;
+            // sort the four (bound, child) pairs ascending: 5 compare-exchanges
+#define MI_CX(A, B, CA, CB) { const bool sw = B < A; const float ta = sw ? B : A; const float tb = sw ? A : B; A = ta; B = tb; \
+                              const unsigned int ua = sw ? CB : CA; const unsigned int ub = sw ? CA : CB; CA = ua; CB = ub; }
+            MI_CX(lb0, lb1, c0, c1) MI_CX(lb2, lb3, c2, c3) MI_CX(lb0, lb2, c0, c2) MI_CX(lb1, lb3, c1, c3) MI_CX(lb1, lb2, c1, c2)
+#undef MI_CX
+            // children that can still matter are a prefix of the sorted four
+            const int keep = (int)(lb0 <= best && lb0 < __builtin_inff()) + (int)(lb1 <= best && lb1 < __builtin_inff()) +
+                             (int)(lb2 <= best && lb2 < __builtin_inff()) + (int)(lb3 <= best && lb3 < __builtin_inff());
+            if (keep == 0) { pop(); continue; }
+            level += 1;
+            // pending at the new level, farthest first: slot 0 = the (keep-1)-th, ..., slot keep-2 = the second nearest
+            unsigned int* slot = st + ((level - 1) * 3) * 256 + threadIdx.x;
+            if (keep == 4) { slot[0] = (__float_as_uint(lb3) & ~3u) | c3; slot[256] = (__float_as_uint(lb2) & ~3u) | c2; slot[512] = (__float_as_uint(lb1) & ~3u) | c1; }
+            else if (keep == 3) { slot[0] = (__float_as_uint(lb2) & ~3u) | c2; slot[256] = (__float_as_uint(lb1) & ~3u) | c1; }
+            else if (keep == 2) { slot[0] = (__float_as_uint(lb1) & ~3u) | c1; }
+            pend = (pend & ~(3u << (2 * level))) | ((unsigned int)(keep - 1) << (2 * level));
+            pos = (pos << 2) | c0;
+        }
+        if (have) {
+            const int leaf = (int)pos;
+            const int slot0 = leaf * TREE_LEAF;
+            const float4* __restrict__ lp = leaf_soa + (size_t)leaf * (3 * TREE_LEAF / 4);
+#pragma unroll
+            for (int c4 = 0; c4 < TREE_LEAF / 4; c4++) {
+                const float4 X = lp[c4], Y = lp[TREE_LEAF / 4 + c4], Z = lp[2 * (TREE_LEAF / 4) + c4];
+                offer(sq3<FMA>(X.x - p[0], Y.x - p[1], Z.x - p[2]), slot0 + 4 * c4);
+                offer(sq3<FMA>(X.y - p[0], Y.y - p[1], Z.y - p[2]), slot0 + 4 * c4 + 1);
+                offer(sq3<FMA>(X.z - p[0], Y.z - p[1], Z.z - p[2]), slot0 + 4 * c4 + 2);
+                offer(sq3<FMA>(X.w - p[0], Y.w - p[1], Z.w - p[2]), slot0 + 4 * c4 + 3);
+            }
+            pop();
+        }
+    }
+}
+
 // Per-lane form without any stack: the heap numbering makes ancestors and siblings computable, so a 32-bit "trail" (bit l set
 // = the sibling of this lane's level-l ancestor is still to be visited) replaces the LDS stack.  Same visiting order as the
 // stack form (deepest pending sibling first); a pending sibling's bound is re-computed from its box when it comes up
@@ -885,6 +1083,8 @@ const char* nn_tree_kernel_name(int n, int R, bool have_counter, int resident_bl
     if (compact_env && *compact_env == '0') return "nn_tree_lane_kernel";
     const char* half_env = getenv("MISLAM_TREE_HALF");
     if (half_env && *half_env == '1') return "nn_tree_lane_compact_kernel";
+    const char* wide_env = getenv("MISLAM_TREE_WIDE");
+    if (have_counter && resident_blocks > 0 && (wide_env ? *wide_env == '1' : TREE_WIDE_DEFAULT)) return "nn_tree_wide_kernel";
     return want_dynamic(n, have_counter, resident_blocks) ? "nn_tree_lane_dynamic_kernel" : "nn_tree_lane_compact_kernel";
 }
 
@@ -907,6 +1107,26 @@ hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, 
             // the 16 bytes save.  Kept as a tested alternative.
             const char* half_env = getenv("MISLAM_TREE_HALF");
             const bool half_nodes = half_env && *half_env == '1';
+            // the wide walk (MISLAM_TREE_WIDE=1 / =0; two binary levels per visit) always fetches dynamically
+            const char* wide_env = getenv("MISLAM_TREE_WIDE");
+            const bool wide = work_counter != nullptr && resident_blocks > 0 && t.quads != nullptr && t.quad_levels > 0 && !half_nodes &&
+                              (wide_env ? *wide_env == '1' : TREE_WIDE_DEFAULT);
+            if (wide) {
+                const char* refill_env = getenv("MISLAM_TREE_REFILL");
+                int refill_min = refill_env ? atoi(refill_env) : TREE_REFILL_MIN;
+                refill_min = refill_min < 1 ? 1 : (refill_min > 64 ? 64 : refill_min);
+                const size_t lds_w = (size_t)t.quad_levels * 3 * 256 * sizeof(unsigned int);
+                const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds_w);
+                dim3 wgrid(std::min((n + 255) / 256, std::max(1, resident_blocks / 8 * per_cu)));
+                const char* parts_env = getenv("MISLAM_TREE_PARTS");
+                int parts = parts_env ? atoi(parts_env) : TREE_DYNAMIC_PARTS;
+                if (parts < 1 || parts > TREE_DYNAMIC_PARTS || (int)wgrid.x < parts) parts = 1;
+                hipError_t e = hipMemsetD32Async((hipDeviceptr_t)work_counter, (int)(wgrid.x / parts) * 256, 16 * TREE_DYNAMIC_PARTS, s);
+                if (e != hipSuccess) return e;
+                if (fma) hipLaunchKernelGGL(nn_tree_wide_kernel<true>, wgrid, block, lds_w, s, t, sx, sy, sz, n, keys, done_flag, work_counter, refill_min, parts);
+                else hipLaunchKernelGGL(nn_tree_wide_kernel<false>, wgrid, block, lds_w, s, t, sx, sy, sz, n, keys, done_flag, work_counter, refill_min, parts);
+                return hipGetLastError();
+            }
             if (!half_nodes && want_dynamic(n, work_counter != nullptr, resident_blocks)) {
                 const char* refill_env = getenv("MISLAM_TREE_REFILL");
                 int refill_min = refill_env ? atoi(refill_env) : TREE_REFILL_MIN;
