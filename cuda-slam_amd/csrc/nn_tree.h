@@ -13,10 +13,18 @@ namespace mislam {
 //   compact copies, trail + bounds (the default walk):  8: 1.25 / 0.71 / 17.8    16: 1.14 / 0.68 / 16.5    32: 1.22 / 0.77 / 17.9
 constexpr int TREE_LEAF = MISLAM_TREE_LEAF;
 constexpr int TREE_MAX_HEIGHT = 24;
-// default walk: dynamic work fetching (nn_tree_lane_dynamic_kernel) and the number of finished lanes that triggers a refill
-constexpr bool TREE_DYNAMIC_DEFAULT = true;
-constexpr int TREE_REFILL_MIN = 24;
+// The default walk is the static per-lane kernel (nn_tree_lane_compact_kernel) with a bounded number of node visits per round.
+// Measured on MI355X, average search of bench.py's 50 iterations at N = M = 1e6 / 1e7 / 1e5 (ms):
+//   node visits per round   unlimited 0.81 / 9.2 / 0.213    8: 0.550    6: 0.535 / 5.57 / 0.156    5: 0.535    4: 0.545    2: 0.66
+//   + one contiguous eighth of the moving cloud per XCD (TREE_XCD_CHUNKS)   0.576 / 6.47 / 0.151, FETCH_SIZE 18 MB instead of 53 MB
+//   dynamically fetching kernel, 6 visits per round, refill at 24 idle lanes   0.563 / 5.59, FETCH_SIZE 27 MB
+//   4-wide kernel, 3 visits per round                                          0.536 / 5.52
+constexpr int TREE_NODE_STEPS = 6;             // node visits per round before the wave turns to its leaves (0 = no limit)
+constexpr int TREE_XCD_CHUNKS = 0;             // static kernel: block -> chunk mapping that gives every XCD a contiguous eighth
+constexpr bool TREE_DYNAMIC_DEFAULT = false;   // dynamic work fetching (nn_tree_lane_dynamic_kernel) ...
+constexpr int TREE_REFILL_MIN = 24;            // ... and the number of finished lanes that triggers a refill
 constexpr bool TREE_WIDE_DEFAULT = false;      // the 4-wide walk (nn_tree_wide_kernel)
+constexpr int TREE_WIDE_NODE_STEPS = 3;        // its node visits per round
 constexpr int TREE_DYNAMIC_PARTS = 8;          // ranges of the moving cloud = XCDs; the work counters are 16 words apart
 constexpr int TREE_WORK_COUNTER_WORDS = 16 * TREE_DYNAMIC_PARTS;
 

@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void nn_tree_lane_kernel(const float4* __restr
 template <bool FMA, bool HALF>
 __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t, const float* __restrict__ sx, const float* __restrict__ sy,
                                                                    const float* __restrict__ sz, int n, unsigned long long* __restrict__ keys,
-                                                                   const int* __restrict__ done_flag)
+                                                                   const int* __restrict__ done_flag, int node_steps, int xcd_chunks)
 {
     if (done_flag != nullptr && *done_flag != 0) return;
     // Pending subtrees: WHICH ones is a 32-bit trail in a register (bit l set = the sibling of this lane's level-l ancestor is
@@ -595,7 +595,15 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
     // (Giving only 32 / 16 / 8 lanes of each wave a moving point -- shorter waves for a small moving cloud that leaves wave slots
     // empty anyway -- measured 0.31 / 0.33 / 0.45 ms against 0.33 ms at 125 000 points and slower everywhere above: a wave is as
     // long as its WORST lane's walk, not as the union of its lanes' walks.)
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // Which 256 moving points a block takes: workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD b mod 8), so
+    // block b takes chunk (b mod 8) * (grid / 8) + b / 8 -- every XCD walks ONE contiguous eighth of the Morton-sorted moving
+    // cloud, in order, and its 4 MB L2 keeps that eighth of the hierarchy instead of a bit of everything.
+    unsigned int chunk = blockIdx.x;
+    if (xcd_chunks) {
+        const unsigned int per_xcd = gridDim.x >> 3;
+        if (blockIdx.x < (per_xcd << 3)) chunk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    }
+    const int i = (int)(chunk * 256u + threadIdx.x);
     if (i >= n) return;
     const float p[3] = {sx[i], sy[i], sz[i]};
     const unsigned long long k0 = keys[i];
@@ -633,8 +641,13 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
             if (j < jb) bslot = slot;
         }
     };
+    const int step_limit = node_steps > 0 ? node_steps : 0x7fffffff;
     while (have) {
+        // at most `node_steps` node visits per round: lanes that are at their leaf do not wait for the wave's longest descent
+        int step = 0;                                          // wave-uniform (kept in a scalar register)
         while (have && node < first_leaf) {
+            step = __builtin_amdgcn_readfirstlane(step + 1);
+            if (step > step_limit) break;
             float lbl, lbr;
             if (HALF) {
                 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -667,19 +680,20 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
             }
             if (!(lbn <= best && lbn < __builtin_inff())) pop();
         }
-        if (!have) break;
-        const int leaf = node - first_leaf;
-        const int slot0 = leaf * TREE_LEAF;
-        const float4* __restrict__ lp = leaf_soa + (size_t)leaf * (3 * TREE_LEAF / 4);
+        if (have && node >= first_leaf) {
+            const int leaf = node - first_leaf;
+            const int slot0 = leaf * TREE_LEAF;
+            const float4* __restrict__ lp = leaf_soa + (size_t)leaf * (3 * TREE_LEAF / 4);
 #pragma unroll
-        for (int c4 = 0; c4 < TREE_LEAF / 4; c4++) {
-            const float4 X = lp[c4], Y = lp[TREE_LEAF / 4 + c4], Z = lp[2 * (TREE_LEAF / 4) + c4];
-            offer(sq3<FMA>(X.x - p[0], Y.x - p[1], Z.x - p[2]), slot0 + 4 * c4);
-            offer(sq3<FMA>(X.y - p[0], Y.y - p[1], Z.y - p[2]), slot0 + 4 * c4 + 1);
-            offer(sq3<FMA>(X.z - p[0], Y.z - p[1], Z.z - p[2]), slot0 + 4 * c4 + 2);
-            offer(sq3<FMA>(X.w - p[0], Y.w - p[1], Z.w - p[2]), slot0 + 4 * c4 + 3);
+            for (int c4 = 0; c4 < TREE_LEAF / 4; c4++) {
+                const float4 X = lp[c4], Y = lp[TREE_LEAF / 4 + c4], Z = lp[2 * (TREE_LEAF / 4) + c4];
+                offer(sq3<FMA>(X.x - p[0], Y.x - p[1], Z.x - p[2]), slot0 + 4 * c4);
+                offer(sq3<FMA>(X.y - p[0], Y.y - p[1], Z.y - p[2]), slot0 + 4 * c4 + 1);
+                offer(sq3<FMA>(X.z - p[0], Y.z - p[1], Z.z - p[2]), slot0 + 4 * c4 + 2);
+                offer(sq3<FMA>(X.w - p[0], Y.w - p[1], Z.w - p[2]), slot0 + 4 * c4 + 3);
+            }
+            pop();
         }
-        pop();
     }
     if (best < __builtin_inff()) {
         const unsigned int j = bslot >= 0 ? (unsigned int)leaf_idx[bslot] : bidx;
@@ -699,7 +713,7 @@ template <bool FMA>
 __global__ __launch_bounds__(256) void nn_tree_lane_dynamic_kernel(NnTreeView t, const float* __restrict__ sx, const float* __restrict__ sy,
                                                                    const float* __restrict__ sz, int n, unsigned long long* __restrict__ keys,
                                                                    const int* __restrict__ done_flag, unsigned int* __restrict__ next_point,
-                                                                   int refill_min, int parts)
+                                                                   int refill_min, int parts, int node_steps)
 {
     if (done_flag != nullptr && *done_flag != 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -804,7 +818,13 @@ __global__ __launch_bounds__(256) void nn_tree_lane_dynamic_kernel(NnTreeView t,
             }
             if (__ballot(have) == 0ull) continue;      // nothing to walk (all pruned at the root, or no points left): store / refill again
         }
+        // at most `node_steps` node visits per round (0 = until every lane is at a leaf): lanes that have reached their leaf
+        // do not wait for the longest descent of the wave
+        const int step_limit = node_steps > 0 ? node_steps : 0x7fffffff;
+        int step = 0;                                          // wave-uniform (kept in a scalar register)
         while (have && node < first_leaf) {
+            step = __builtin_amdgcn_readfirstlane(step + 1);
+            if (step > step_limit) break;
             const float4* __restrict__ rec = pairs + 3 * (size_t)node;
             const float4 a = rec[0], b = rec[1], c = rec[2];
             const float lbl = box_bound<FMA>(make_float4(a.x, a.y, a.z, 0.f), make_float4(a.w, b.x, b.y, 0.f), p, p);
@@ -820,7 +840,7 @@ __global__ __launch_bounds__(256) void nn_tree_lane_dynamic_kernel(NnTreeView t,
             }
             if (!(lbn <= best && lbn < __builtin_inff())) pop();
         }
-        if (have) {
+        if (have && node >= first_leaf) {
             const int leaf = node - first_leaf;
             const int slot0 = leaf * TREE_LEAF;
             const float4* __restrict__ lp = leaf_soa + (size_t)leaf * (3 * TREE_LEAF / 4);
@@ -850,7 +870,7 @@ template <bool FMA>
 __global__ __launch_bounds__(256) void nn_tree_wide_kernel(NnTreeView t, const float* __restrict__ sx, const float* __restrict__ sy,
                                                            const float* __restrict__ sz, int n, unsigned long long* __restrict__ keys,
                                                            const int* __restrict__ done_flag, unsigned int* __restrict__ next_point,
-                                                           int refill_min, int parts)
+                                                           int refill_min, int parts, int node_steps)
 {
     if (done_flag != nullptr && *done_flag != 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -953,7 +973,11 @@ __global__ __launch_bounds__(256) void nn_tree_wide_kernel(NnTreeView t, const f
             }
             if (__ballot(have) == 0ull) continue;
         }
+        const int step_limit = node_steps > 0 ? node_steps : 0x7fffffff;
+        int step = 0;
         while (have && level < leaf_level) {
+            step = __builtin_amdgcn_readfirstlane(step + 1);
+            if (step > step_limit) break;
             const float4* __restrict__ rec = quads + 6 * (size_t)(quad_level_offset(level) + pos);
             const float4 LX = rec[0], LY = rec[1], LZ = rec[2], HX = rec[3], HY = rec[4], HZ = rec[5];
             float lb0 = box_bound<FMA>(make_float4(LX.x, LY.x, LZ.x, 0.f), make_float4(HX.x, HY.x, HZ.x, 0.f), p, p);
@@ -979,7 +1003,7 @@ __global__ __launch_bounds__(256) void nn_tree_wide_kernel(NnTreeView t, const f
             pend = (pend & ~(3u << (2 * level))) | ((unsigned int)(keep - 1) << (2 * level));
             pos = (pos << 2) | c0;
         }
-        if (have) {
+        if (have && level >= leaf_level) {
             const int leaf = (int)pos;
             const int slot0 = leaf * TREE_LEAF;
             const float4* __restrict__ lp = leaf_soa + (size_t)leaf * (3 * TREE_LEAF / 4);
@@ -1107,6 +1131,10 @@ hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, 
             // the 16 bytes save.  Kept as a tested alternative.
             const char* half_env = getenv("MISLAM_TREE_HALF");
             const bool half_nodes = half_env && *half_env == '1';
+            const char* xcd_env = getenv("MISLAM_TREE_XCD_CHUNKS");        // static kernel: one contiguous eighth of the moving cloud per XCD
+            const int xcd_chunks = xcd_env ? atoi(xcd_env) : TREE_XCD_CHUNKS;
+            const char* steps_env = getenv("MISLAM_TREE_NODE_STEPS");      // node visits per round, 0 = no limit
+            const int node_steps = steps_env ? atoi(steps_env) : TREE_NODE_STEPS;
             // the wide walk (MISLAM_TREE_WIDE=1 / =0; two binary levels per visit) always fetches dynamically
             const char* wide_env = getenv("MISLAM_TREE_WIDE");
             const bool wide = work_counter != nullptr && resident_blocks > 0 && t.quads != nullptr && t.quad_levels > 0 && !half_nodes &&
@@ -1123,8 +1151,9 @@ hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, 
                 if (parts < 1 || parts > TREE_DYNAMIC_PARTS || (int)wgrid.x < parts) parts = 1;
                 hipError_t e = hipMemsetD32Async((hipDeviceptr_t)work_counter, (int)(wgrid.x / parts) * 256, 16 * TREE_DYNAMIC_PARTS, s);
                 if (e != hipSuccess) return e;
-                if (fma) hipLaunchKernelGGL(nn_tree_wide_kernel<true>, wgrid, block, lds_w, s, t, sx, sy, sz, n, keys, done_flag, work_counter, refill_min, parts);
-                else hipLaunchKernelGGL(nn_tree_wide_kernel<false>, wgrid, block, lds_w, s, t, sx, sy, sz, n, keys, done_flag, work_counter, refill_min, parts);
+                const int wide_steps = steps_env ? atoi(steps_env) : TREE_WIDE_NODE_STEPS;
+                if (fma) hipLaunchKernelGGL(nn_tree_wide_kernel<true>, wgrid, block, lds_w, s, t, sx, sy, sz, n, keys, done_flag, work_counter, refill_min, parts, wide_steps);
+                else hipLaunchKernelGGL(nn_tree_wide_kernel<false>, wgrid, block, lds_w, s, t, sx, sy, sz, n, keys, done_flag, work_counter, refill_min, parts, wide_steps);
                 return hipGetLastError();
             }
             if (!half_nodes && want_dynamic(n, work_counter != nullptr, resident_blocks)) {
@@ -1138,19 +1167,19 @@ hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, 
                 // every range's counter starts behind the points its blocks take statically
                 hipError_t e = hipMemsetD32Async((hipDeviceptr_t)work_counter, (int)(dgrid.x / parts) * 256, 16 * TREE_DYNAMIC_PARTS, s);
                 if (e != hipSuccess) return e;
-                if (fma) hipLaunchKernelGGL(nn_tree_lane_dynamic_kernel<true>, dgrid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, work_counter, refill_min, parts);
-                else hipLaunchKernelGGL(nn_tree_lane_dynamic_kernel<false>, dgrid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, work_counter, refill_min, parts);
+                if (fma) hipLaunchKernelGGL(nn_tree_lane_dynamic_kernel<true>, dgrid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, work_counter, refill_min, parts, node_steps);
+                else hipLaunchKernelGGL(nn_tree_lane_dynamic_kernel<false>, dgrid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, work_counter, refill_min, parts, node_steps);
                 return hipGetLastError();
             }
             if (half_nodes && t.pairs_half != nullptr) {
-                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag);
-                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag);
+                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, node_steps, xcd_chunks);
+                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, node_steps, xcd_chunks);
             } else {
                 // (fetching both children's records with the node's own -- two levels per load trip -- measured slower at every
                 // moving-cloud size, 0.35 against 0.33 ms at 125 000 and 1.15 against 0.81 ms at 1e6: most visits are short
                 // excursions into pending subtrees, where the second record is wasted)
-                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag);
-                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag);
+                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, node_steps, xcd_chunks);
+                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, node_steps, xcd_chunks);
             }
             return hipGetLastError();
         }
