@@ -5,12 +5,15 @@
 namespace mislam {
 
 #ifndef MISLAM_TREE_LEAF
-#define MISLAM_TREE_LEAF 16
+#define MISLAM_TREE_LEAF 8
 #endif
 // points per leaf.  Measured on MI355X (N = M = 1e6, ms per search early / near convergence; 1e7 early):
 //   float4 leaves, 64-byte node records:  4: 2.03 / 1.17 / 36.8    8: 1.84 / 1.08 / 33.3    16: 1.68 / 1.04 / 30.0    32: 1.62 / 1.06 / 28.0
 //   compact copies, (node, bound) stack:  8: 1.50 / 0.92 / 27.6    16: 1.35 / 0.89 / 24.4    32: 1.32 / 0.91 / 23.2
-//   compact copies, trail + bounds (the default walk):  8: 1.25 / 0.71 / 17.8    16: 1.14 / 0.68 / 16.5    32: 1.22 / 0.77 / 17.9
+//   compact copies, trail + bounds:                     8: 1.25 / 0.71 / 17.8    16: 1.14 / 0.68 / 16.5    32: 1.22 / 0.77 / 17.9
+// With at most TREE_NODE_STEPS node visits per round (the default walk; average search of bench.py's 50 iterations at 1e6 / 1e7):
+//   32: 0.70 / 6.98 (6 visits)    16: 0.535 / 5.57 (6)    8: 0.487 / 5.06 (5; 0.486 with 4, 0.491 with 6)    4: 0.473 / 5.30 (5)
+// -- shorter rounds favour smaller leaves; 8 is within 3 % of the best at both sizes and half the node memory of 4.
 constexpr int TREE_LEAF = MISLAM_TREE_LEAF;
 constexpr int TREE_MAX_HEIGHT = 24;
 // The default walk is the static per-lane kernel (nn_tree_lane_compact_kernel) with a bounded number of node visits per round.
@@ -19,7 +22,7 @@ constexpr int TREE_MAX_HEIGHT = 24;
 //   + one contiguous eighth of the moving cloud per XCD (TREE_XCD_CHUNKS)   0.576 / 6.47 / 0.151, FETCH_SIZE 18 MB instead of 53 MB
 //   dynamically fetching kernel, 6 visits per round, refill at 24 idle lanes   0.563 / 5.59, FETCH_SIZE 27 MB
 //   4-wide kernel, 3 visits per round                                          0.536 / 5.52
-constexpr int TREE_NODE_STEPS = 6;             // node visits per round before the wave turns to its leaves (0 = no limit)
+constexpr int TREE_NODE_STEPS = 5;             // node visits per round before the wave turns to its leaves (0 = no limit)
 constexpr int TREE_XCD_CHUNKS = 0;             // static kernel: block -> chunk mapping that gives every XCD a contiguous eighth
 constexpr bool TREE_DYNAMIC_DEFAULT = false;   // dynamic work fetching (nn_tree_lane_dynamic_kernel) ...
 constexpr int TREE_REFILL_MIN = 24;            // ... and the number of finished lanes that triggers a refill
