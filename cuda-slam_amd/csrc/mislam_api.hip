@@ -415,8 +415,9 @@ static int resolve_nn_mode(int nn_mode, int m_local)
     const int forced = env_int("MISLAM_NN_MODE", 0);
     if (forced == MI_NN_BRUTEFORCE || forced == MI_NN_TREE) nn_mode = forced;
     if (nn_mode == MI_NN_BRUTEFORCE || nn_mode == MI_NN_TREE) return nn_mode;
-    // measured crossover on MI355X (N = M): 15 k points 115 us/iteration every-pair vs 148 us hierarchy; 100 k 1.6 ms vs 0.33 ms
-    return m_local >= 32768 ? MI_NN_TREE : MI_NN_BRUTEFORCE;
+    // measured crossover on MI355X (N = M, us per search every-pair / hierarchy): 16 k 62 / 104, 20 k 89 / 103, 24 k 115 / 109,
+    // 28 k 151 / 112, 32 k 195 / 119, 100 k 1650 / 152
+    return m_local >= 24000 ? MI_NN_TREE : MI_NN_BRUTEFORCE;
 }
 
 extern "C" const char* mi_nn_kernel_name(const mi_ctx* c, int n_moving, int m_fixed_local, int nn_mode)

@@ -49,7 +49,7 @@ enum {
 /* Execution strategy of the nearest-neighbour search.  Every mode returns the SAME idx[] and d2[] bit for bit (strict '<',
  * lowest index on ties, same fp32 arithmetic); they differ only in how many candidate pairs are evaluated. */
 enum {
-    MI_NN_AUTO = 0,         /* box hierarchy for fixed clouds of >= 32768 points per GPU, every pair below (measured crossover) */
+    MI_NN_AUTO = 0,         /* box hierarchy for fixed clouds of >= 24000 points per GPU, every pair below (measured crossover at N = M) */
     MI_NN_BRUTEFORCE = 1,   /* every pair, like FindCorrespondences (cudacommon.cu:57-77): N*M distance evaluations */
     MI_NN_TREE = 2          /* exact search through a box hierarchy over the Morton-sorted fixed cloud */
 };
