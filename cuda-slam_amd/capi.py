@@ -31,7 +31,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int) 
 # every symbol include/mi_slam.h declares (tests check that the library exports each of them)
 EXPORTS = [
     "mi_abi_version", "mi_last_error", "mi_device_count", "mi_ctx_create", "mi_dist_unique_id", "mi_ctx_create_dist",
-    "mi_ctx_create_exchange", "mi_ctx_rank", "mi_shard_range", "mi_pack_key", "mi_unpack_key", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_icp_params_default", "mi_icp_params_cuda_slam",
+    "mi_ctx_create_exchange", "mi_ctx_preload", "mi_ctx_rank", "mi_shard_range", "mi_pack_key", "mi_unpack_key", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_icp_params_default", "mi_icp_params_cuda_slam",
     "mi_icp_register", "mi_icp_load", "mi_icp_reset", "mi_icp_run", "mi_icp_result", "mi_nn_search", "mi_nn_search_ex", "mi_kabsch",
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_estep",
     "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
@@ -230,6 +230,10 @@ class Context:
 
     def synchronize(self):
         _check(lib().mi_ctx_synchronize(self._h))
+
+    def preload(self):
+        """Load all device code now instead of lazily inside the first calls (mi_ctx_preload)."""
+        _check(lib().mi_ctx_preload(self._h))
 
     def rank_world(self):
         r, w = C.c_int(0), C.c_int(0)

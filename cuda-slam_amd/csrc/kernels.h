@@ -113,4 +113,13 @@ hipError_t invert_order(const int* order, int n, int* inv, hipStream_t s);
 hipError_t icp_seq_centroids(const IcpView& v, hipStream_t s);
 hipError_t icp_seq_error(const IcpView& v, hipStream_t s);
 
+// One per translation unit with kernels: loads that unit's code object (see the definitions).
+hipError_t preload_nn_kernel();
+hipError_t preload_nn_tree();
+hipError_t preload_icp_kernels();
+hipError_t preload_cpd_kernels();
+hipError_t preload_cpd_fgt();
+hipError_t preload_nicp_api();
+hipError_t preload_prepare_api();
+
 }  // namespace mislam

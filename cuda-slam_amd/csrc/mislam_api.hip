@@ -50,6 +50,18 @@ extern "C" int mi_device_count(int* count)
 // ---------------------------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------------------------
+// Loads every code object of the library now.  With the runtime's deferred loading the first launch out of each translation
+// unit otherwise stalls whatever call it happens in (measured: first ICP call at 1e6 points 22 -> 17 ms, first CPD call
+// 36 -> 3 ms) -- at the price of ~170 ms here, so it is the caller's choice: a long-lived process wants it, a one-shot run not.
+extern "C" int mi_ctx_preload(mi_ctx* c)
+{
+    if (!c) { set_error("mi_ctx_preload: null context"); return MI_ERR_INVALID_ARG; }
+    MI_HIP(hipSetDevice(c->device));
+    MI_HIP(preload_nn_kernel()); MI_HIP(preload_nn_tree()); MI_HIP(preload_icp_kernels()); MI_HIP(preload_cpd_kernels());
+    MI_HIP(preload_cpd_fgt()); MI_HIP(preload_nicp_api()); MI_HIP(preload_prepare_api());
+    return MI_OK;
+}
+
 static int ctx_create_common(int device, mi_ctx** out)
 {
     if (!out) { set_error("mi_ctx_create: null out pointer"); return MI_ERR_INVALID_ARG; }
@@ -69,6 +81,8 @@ static int ctx_create_common(int device, mi_ctx** out)
         MI_HIP(hipMalloc((void**)&c->d_state, sizeof(IcpState)));
         MI_HIP(hipHostMalloc((void**)&c->h_state, sizeof(IcpState), hipHostMallocDefault));
         memset(c->h_state, 0, sizeof(IcpState));
+        const char* preload_env = getenv("MISLAM_PRELOAD");       // =1: mi_ctx_preload as part of every context creation
+        if (preload_env && *preload_env == '1') MI_TRY(mi_ctx_preload(c));
         return MI_OK;
     }();
     if (rc != MI_OK) { mi_ctx_destroy(c); return rc; }

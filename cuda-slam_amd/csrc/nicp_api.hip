@@ -405,3 +405,14 @@ extern "C" int mi_nicp_register(mi_ctx* c, const float* before_xyz, int m_before
     out_T[12] = best.rt.t[0]; out_T[13] = best.rt.t[1]; out_T[14] = best.rt.t[2]; out_T[15] = 1.f;
     return MI_OK;
 }
+
+// Touching one kernel of this translation unit makes the runtime load its code object now (mi_ctx_create) instead of at the
+// first launch inside a registration call (deferred loading: 5-16 ms per object, once).
+namespace mislam {
+__global__ void preload_nicp_api_kernel() {}
+hipError_t preload_nicp_api()
+{
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(preload_nicp_api_kernel));
+}
+}  // namespace mislam

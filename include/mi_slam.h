@@ -109,6 +109,9 @@ const char* mi_last_error(void);
 int mi_device_count(int* count);
 
 int mi_ctx_create(int device, mi_ctx** out);
+/* Optional: load all device code now (~170 ms) instead of lazily at the first use of each kernel family, where it would stall
+ * that registration call (first CPD call on the bunny clouds: 36 ms lazily, 3 ms after this).  For long-lived processes. */
+int mi_ctx_preload(mi_ctx* ctx);
 
 /* Multi-GPU, one process per GPU (no reference counterpart: the reference is single-GPU).  What the ranks split is
  * mi_icp_params.shard_mode (MI_SHARD_* above) for ICP -- with the fixed cloud sharded, the per-point packed (min-dist, argmin)
