@@ -23,6 +23,7 @@ constexpr int TREE_MAX_HEIGHT = 24;
 //   dynamically fetching kernel, 6 visits per round, refill at 24 idle lanes   0.563 / 5.59, FETCH_SIZE 27 MB
 //   4-wide kernel, 3 visits per round                                          0.536 / 5.52
 constexpr int TREE_NODE_STEPS = 5;             // node visits per round before the wave turns to its leaves (0 = no limit)
+constexpr int TREE_LEAF_STEPS = 1;             // leaf scans per round (2 or 3: 0.508 against 0.483 ms at 1e6, 5.28 against 4.99 at 1e7)
 constexpr int TREE_XCD_CHUNKS = 0;             // static kernel: block -> chunk mapping that gives every XCD a contiguous eighth
 constexpr bool TREE_DYNAMIC_DEFAULT = false;   // dynamic work fetching (nn_tree_lane_dynamic_kernel) ...
 constexpr int TREE_REFILL_MIN = 24;            // ... and the number of finished lanes that triggers a refill

@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void nn_tree_lane_kernel(const float4* __restr
 template <bool FMA, bool HALF>
 __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t, const float* __restrict__ sx, const float* __restrict__ sy,
                                                                    const float* __restrict__ sz, int n, unsigned long long* __restrict__ keys,
-                                                                   const int* __restrict__ done_flag, int node_steps, int xcd_chunks)
+                                                                   const int* __restrict__ done_flag, int node_steps, int xcd_chunks, int leaf_steps)
 {
     if (done_flag != nullptr && *done_flag != 0) return;
     // Pending subtrees: WHICH ones is a 32-bit trail in a register (bit l set = the sibling of this lane's level-l ancestor is
@@ -680,7 +680,10 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
             }
             if (!(lbn <= best && lbn < __builtin_inff())) pop();
         }
-        if (have && node >= first_leaf) {
+        // up to `leaf_steps` leaf scans per round: a lane whose next pending subtree is a leaf again (the sibling leaf, mostly)
+        // scans it right away instead of sitting through the next round's node visits
+        for (int scan = 0; scan < leaf_steps; scan++) {
+            if (!(have && node >= first_leaf)) break;
             const int leaf = node - first_leaf;
             const int slot0 = leaf * TREE_LEAF;
             const float4* __restrict__ lp = leaf_soa + (size_t)leaf * (3 * TREE_LEAF / 4);
@@ -1133,6 +1136,8 @@ hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, 
             const bool half_nodes = half_env && *half_env == '1';
             const char* xcd_env = getenv("MISLAM_TREE_XCD_CHUNKS");        // static kernel: one contiguous eighth of the moving cloud per XCD
             const int xcd_chunks = xcd_env ? atoi(xcd_env) : TREE_XCD_CHUNKS;
+            const char* leaf_steps_env = getenv("MISLAM_TREE_LEAF_STEPS");  // leaf scans per round
+            const int leaf_steps = leaf_steps_env && atoi(leaf_steps_env) > 0 ? atoi(leaf_steps_env) : TREE_LEAF_STEPS;
             const char* steps_env = getenv("MISLAM_TREE_NODE_STEPS");      // node visits per round, 0 = no limit
             const int node_steps = steps_env ? atoi(steps_env) : TREE_NODE_STEPS;
             // the wide walk (MISLAM_TREE_WIDE=1 / =0; two binary levels per visit) always fetches dynamically
@@ -1172,14 +1177,14 @@ hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, 
                 return hipGetLastError();
             }
             if (half_nodes && t.pairs_half != nullptr) {
-                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, node_steps, xcd_chunks);
-                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, node_steps, xcd_chunks);
+                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, node_steps, xcd_chunks, leaf_steps);
+                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, true>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, node_steps, xcd_chunks, leaf_steps);
             } else {
                 // (fetching both children's records with the node's own -- two levels per load trip -- measured slower at every
                 // moving-cloud size, 0.35 against 0.33 ms at 125 000 and 1.15 against 0.81 ms at 1e6: most visits are short
                 // excursions into pending subtrees, where the second record is wasted)
-                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, node_steps, xcd_chunks);
-                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, node_steps, xcd_chunks);
+                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, node_steps, xcd_chunks, leaf_steps);
+                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, node_steps, xcd_chunks, leaf_steps);
             }
             return hipGetLastError();
         }
