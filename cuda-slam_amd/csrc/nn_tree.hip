@@ -647,6 +647,8 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
         int step = 0;                                          // wave-uniform (kept in a scalar register)
         while (have && node < first_leaf) {
             step = __builtin_amdgcn_readfirstlane(step + 1);
+            // (ending the node phase as soon as fewer than 4 ... 32 lanes are still descending measured 0.506 ... 0.558 against
+            // 0.483 ms: the stragglers' visits are cheap next to an extra round)
             if (step > step_limit) break;
             float lbl, lbr;
             if (HALF) {
