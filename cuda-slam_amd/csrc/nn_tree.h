@@ -24,7 +24,12 @@ constexpr int TREE_MAX_HEIGHT = 24;
 //   4-wide kernel, 3 visits per round                                          0.536 / 5.52
 constexpr int TREE_NODE_STEPS = 5;             // node visits per round before the wave turns to its leaves (0 = no limit)
 constexpr int TREE_LEAF_STEPS = 1;             // leaf scans per round (2 or 3: 0.508 against 0.483 ms at 1e6, 5.28 against 4.99 at 1e7)
-constexpr int TREE_XCD_CHUNKS = 0;             // static kernel: block -> chunk mapping that gives every XCD a contiguous eighth
+// Static kernel, which 256-point chunk a block takes (blocks are dealt to the 8 XCDs round-robin): 0 = chunk b; 1 = every XCD one
+// contiguous eighth of the moving cloud; S > 1 = runs of S consecutive chunks per XCD, the XCDs taking neighbouring runs.
+// Measured (8-point leaves, 5 visits per round; search ms at 1e6 / 1e7, FETCH_SIZE MB per launch at 1e6):
+//   0: 0.483 / 4.99, 62.8    1: 0.513 / 5.81, 19.7 (the eighths are not equally hard)    4: 0.478 / 4.96, 41.9    16: 0.478 / 4.93, 32.3
+//   32: 0.479 / 4.93, 29.3    64: 0.492 / 4.94, 29.6    128: 0.492 / 4.94, 33.0
+constexpr int TREE_XCD_CHUNKS = 32;
 constexpr bool TREE_DYNAMIC_DEFAULT = false;   // dynamic work fetching (nn_tree_lane_dynamic_kernel) ...
 constexpr int TREE_REFILL_MIN = 24;            // ... and the number of finished lanes that triggers a refill
 constexpr bool TREE_WIDE_DEFAULT = false;      // the 4-wide walk (nn_tree_wide_kernel)

@@ -599,9 +599,18 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
     // block b takes chunk (b mod 8) * (grid / 8) + b / 8 -- every XCD walks ONE contiguous eighth of the Morton-sorted moving
     // cloud, in order, and its 4 MB L2 keeps that eighth of the hierarchy instead of a bit of everything.
     unsigned int chunk = blockIdx.x;
-    if (xcd_chunks) {
+    if (xcd_chunks == 1) {
         const unsigned int per_xcd = gridDim.x >> 3;
         if (blockIdx.x < (per_xcd << 3)) chunk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    } else if (xcd_chunks > 1) {
+        // runs of `xcd_chunks` consecutive chunks per XCD, the 8 XCDs taking neighbouring runs: an XCD still walks contiguous
+        // stretches of the Morton curve (its L2 sees each leaf-level node once), but every XCD gets a share of every region
+        const unsigned int run = (unsigned int)xcd_chunks;
+        const unsigned int whole = gridDim.x / (8u * run) * (8u * run);
+        if (blockIdx.x < whole) {
+            const unsigned int x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+            chunk = ((j / run) * 8u + x) * run + j % run;
+        }
     }
     const int i = (int)(chunk * 256u + threadIdx.x);
     if (i >= n) return;

@@ -89,7 +89,8 @@ def test_tree_equals_bruteforce_on_clustered_and_degenerate_clouds(ctx, capi, mo
 @pytest.mark.parametrize("variant", ["R=-1", "R=1", "R=2", "COMPACT=0", "HALF=1", "DYNAMIC=1", "DYNAMIC=1,RESIDENT=2", "DYNAMIC=1,RESIDENT=1,REFILL=1",
                                      "DYNAMIC=1,RESIDENT=3,REFILL=64", "DYNAMIC=1,RESIDENT=8", "DYNAMIC=1,RESIDENT=9,REFILL=1",
                                      "DYNAMIC=1,RESIDENT=16,PARTS=1", "DYNAMIC=0", "WIDE=1", "WIDE=1,RESIDENT=2,REFILL=1",
-                                     "WIDE=1,RESIDENT=9", "NODE_STEPS=0", "NODE_STEPS=1", "XCD_CHUNKS=1", "WIDE=1,NODE_STEPS=1",
+                                     "WIDE=1,RESIDENT=9", "NODE_STEPS=0", "NODE_STEPS=1", "XCD_CHUNKS=0", "XCD_CHUNKS=1", "XCD_CHUNKS=2",
+                                     "WIDE=1,NODE_STEPS=1",
                                      "DYNAMIC=1,RESIDENT=2,NODE_STEPS=1"])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_alternative_hierarchy_walks_are_exact_too(ctx, capi, oracle, monkeypatch, variant, mode):
@@ -101,8 +102,9 @@ def test_alternative_hierarchy_walks_are_exact_too(ctx, capi, oracle, monkeypatc
     # small cloud is fetched in many batches -- from 8 blocks on, one range of the cloud per XCD with stealing, 9 leaves a block
     # without a static share; REFILL = finished lanes that trigger a fetch; PARTS=1 one range for all); WIDE=1 the 4-wide walk
     # (two binary levels per visit; this hierarchy has an odd height, so its wide root has two empty children); NODE_STEPS = node
-    # visits per round before a wave turns to its leaves (0 = no limit; the default is 6); XCD_CHUNKS=1 the static kernel's
-    # block-to-chunk mapping that gives every XCD a contiguous eighth of the moving cloud
+    # visits per round before a wave turns to its leaves (0 = no limit; the default is 5); XCD_CHUNKS = the static kernel's
+    # block-to-chunk mapping: 0 plain, 1 a contiguous eighth of the moving cloud per XCD, S runs of S chunks per XCD (default 32,
+    # which this 17-block cloud is too small for: 2 exercises the remapping here, the 1e6 / 1e7 tests below run the default)
     for setting in variant.split(","):
         name, value = setting.split("=")
         monkeypatch.setenv("MISLAM_TREE_" + name, value)
