@@ -30,6 +30,7 @@ constexpr int TREE_LEAF_STEPS = 1;             // leaf scans per round (2 or 3: 
 //   0: 0.483 / 4.99, 62.8    1: 0.513 / 5.81, 19.7 (the eighths are not equally hard)    4: 0.478 / 4.96, 41.9    16: 0.478 / 4.93, 32.3
 //   32: 0.479 / 4.93, 29.3    64: 0.492 / 4.94, 29.6    128: 0.492 / 4.94, 33.0
 constexpr int TREE_XCD_CHUNKS = 32;
+constexpr int TREE_BLOCK_THREADS = 128;        // static kernel: threads per block (the run length above stays in 256-point units)
 constexpr bool TREE_DYNAMIC_DEFAULT = false;   // dynamic work fetching (nn_tree_lane_dynamic_kernel) ...
 constexpr int TREE_REFILL_MIN = 24;            // ... and the number of finished lanes that triggers a refill
 constexpr bool TREE_WIDE_DEFAULT = false;      // the 4-wide walk (nn_tree_wide_kernel)

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
             chunk = ((j / run) * 8u + x) * run + j % run;
         }
     }
-    const int i = (int)(chunk * 256u + threadIdx.x);
+    const int i = (int)(chunk * blockDim.x + threadIdx.x);
     if (i >= n) return;
     const float p[3] = {sx[i], sy[i], sz[i]};
     const unsigned long long k0 = keys[i];
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
             const int anc = ((node + 1) >> (level - b)) - 1;      // this lane's ancestor at level b ...
             node = ((anc + 1) ^ 1) - 1;                           // ... its sibling is the pending subtree
             level = b;                                            // (bits deeper than b are all clear now)
-            if (st_lb[b * 256 + threadIdx.x] <= best) { have = true; break; }
+            if (st_lb[b * blockDim.x + threadIdx.x] <= best) { have = true; break; }
         }
     };
     // candidate at sorted slot `slot` with squared distance d: lexicographic (d, global index) minimum
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256) void nn_tree_lane_compact_kernel(NnTreeView t,
             level += 1;
             if (lbf <= best && lbf < __builtin_inff()) {
                 trail |= 1u << level;
-                st_lb[level * 256 + threadIdx.x] = lbf;
+                st_lb[level * blockDim.x + threadIdx.x] = lbf;
             }
             if (!(lbn <= best && lbn < __builtin_inff())) pop();
         }
@@ -1194,8 +1194,17 @@ hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, 
                 // (fetching both children's records with the node's own -- two levels per load trip -- measured slower at every
                 // moving-cloud size, 0.35 against 0.33 ms at 125 000 and 1.15 against 0.81 ms at 1e6: most visits are short
                 // excursions into pending subtrees, where the second record is wasted)
-                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, node_steps, xcd_chunks, leaf_steps);
-                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, false>), grid, block, lds_c, s, t, sx, sy, sz, n, keys, done_flag, node_steps, xcd_chunks, leaf_steps);
+                // threads per block of the static kernel (MISLAM_TREE_BLOCK=64|128|256): a block's wave slots and LDS come free
+                // only when its last wave is done, so smaller blocks refill the CU sooner.  Search ms at 1e6 / 1e7 / 1e5:
+                //   256: 0.484 / 4.95 / 0.144    128: 0.478 / 4.91 / 0.137    64: 0.475 / 5.02 / 0.138
+                const char* block_env = getenv("MISLAM_TREE_BLOCK");
+                const int tb_req = block_env ? atoi(block_env) : TREE_BLOCK_THREADS;
+                const int tb = tb_req == 64 || tb_req == 128 || tb_req == 256 ? tb_req : TREE_BLOCK_THREADS;
+                const dim3 sgrid((n + tb - 1) / tb), sblock(tb);
+                const size_t slds = (size_t)(t.height + 1) * tb * sizeof(float);
+                const int sruns = xcd_chunks > 1 ? xcd_chunks * (256 / tb) : xcd_chunks;
+                if (fma) hipLaunchKernelGGL((nn_tree_lane_compact_kernel<true, false>), sgrid, sblock, slds, s, t, sx, sy, sz, n, keys, done_flag, node_steps, sruns, leaf_steps);
+                else hipLaunchKernelGGL((nn_tree_lane_compact_kernel<false, false>), sgrid, sblock, slds, s, t, sx, sy, sz, n, keys, done_flag, node_steps, sruns, leaf_steps);
             }
             return hipGetLastError();
         }

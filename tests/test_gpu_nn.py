@@ -90,6 +90,7 @@ def test_tree_equals_bruteforce_on_clustered_and_degenerate_clouds(ctx, capi, mo
                                      "DYNAMIC=1,RESIDENT=3,REFILL=64", "DYNAMIC=1,RESIDENT=8", "DYNAMIC=1,RESIDENT=9,REFILL=1",
                                      "DYNAMIC=1,RESIDENT=16,PARTS=1", "DYNAMIC=0", "WIDE=1", "WIDE=1,RESIDENT=2,REFILL=1",
                                      "WIDE=1,RESIDENT=9", "NODE_STEPS=0", "NODE_STEPS=1", "XCD_CHUNKS=0", "XCD_CHUNKS=1", "XCD_CHUNKS=2",
+                                     "BLOCK=64,XCD_CHUNKS=2", "BLOCK=256",
                                      "WIDE=1,NODE_STEPS=1",
                                      "DYNAMIC=1,RESIDENT=2,NODE_STEPS=1"])
 @pytest.mark.parametrize("mode", [0, 1])
