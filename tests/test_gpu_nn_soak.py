@@ -1,0 +1,29 @@
+"""GPU suite: randomized soak of the box-hierarchy search against the every-pair search (tools/nn_soak.py, 40 seeded cases):
+random sizes up to 3e5, uniform / clustered / planar / duplicated clouds, both distance arithmetics -- identical bits."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+from nn_soak import cloud  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_tree_equals_every_pair_on_random_problems(ctx, capi, seed):
+    rng = np.random.default_rng(seed)
+    for _ in range(10):
+        n = int(10 ** rng.uniform(0, 5.48))
+        m = int(10 ** rng.uniform(0.5, 5.48))
+        tgt = cloud(rng, m, rng.integers(0, 4)).astype(np.float32)
+        src = cloud(rng, n, rng.integers(0, 4)).astype(np.float32)
+        if rng.random() < 0.3:
+            take = rng.integers(0, m, min(n, m))
+            src[:len(take)] = tgt[take]
+        mode = int(rng.integers(0, 2))
+        a = ctx.nn_search(src, tgt, mode, capi.NN_BRUTEFORCE)
+        b = ctx.nn_search(src, tgt, mode, capi.NN_TREE)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (seed, n, m, mode)
