@@ -133,8 +133,8 @@ def main():
                     help="what N > 1 GPUs split: auto = moving cloud for the box hierarchy, fixed cloud for the every-pair search")
     ap.add_argument("--brute-ref-steps", type=int, default=2,
                     help="untimed every-pair steps measured after the timed region when the box hierarchy was used (0 = skip)")
-    ap.add_argument("--nn", choices=["auto", "brute", "tree"], default="auto",
-                    help="search strategy (identical results): auto = the library default (box hierarchy at this size)")
+    ap.add_argument("--nn", choices=["auto", "brute", "tree", "grid"], default="auto",
+                    help="search strategy (identical results): auto = the library default (cell grid at this size)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -195,11 +195,11 @@ def main():
         ctx.synchronize()
 
     # eps = 0: the device-side stop rule is evaluated every step and never fires -> every step is a full iteration
-    nn_mode = {"auto": capi.NN_AUTO, "brute": capi.NN_BRUTEFORCE, "tree": capi.NN_TREE}[args.nn]
+    nn_mode = {"auto": capi.NN_AUTO, "brute": capi.NN_BRUTEFORCE, "tree": capi.NN_TREE, "grid": capi.NN_GRID}[args.nn]
     shard_mode = {"auto": capi.SHARD_AUTO, "target": capi.SHARD_TARGET, "source": capi.SHARD_SOURCE}[args.shard]
     # what the library will do with these settings (mi_slam.h MI_NN_AUTO / MI_SHARD_AUTO), for the report below
     per_rank_m = m // world
-    tree_if = lambda mm: args.nn == "tree" or (args.nn == "auto" and mm >= capi.NN_TREE_MIN_POINTS)
+    tree_if = lambda mm: args.nn in ("tree", "grid") or (args.nn == "auto" and mm >= capi.NN_INDEX_MIN_POINTS)
     source_sharded = use_dist and (args.shard == "source" or (args.shard == "auto" and tree_if(m)))
     if source_sharded:
         slo, shi = capi.shard_range(n, rank, world)
@@ -208,7 +208,7 @@ def main():
         lo, hi = capi.shard_range(m, rank, world)
         n_local, m_local = n, hi - lo
     used_tree = tree_if(m_local)
-    tree_kernel = ctx.nn_kernel_name(n_local, m_local, capi.NN_TREE)     # the walk the library picks for this many moving points
+    tree_kernel = ctx.nn_kernel_name(n_local, m_local, capi.NN_TREE if args.nn == "tree" else capi.NN_GRID)
     params = capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=nn_mode, shard_mode=shard_mode)
     ctx.icp_load(before, after, params)            # H2D upload + SoA conversion: outside the timed region
     if args.warmup > 0:
@@ -285,7 +285,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "icp_synthetic_uniform_n%d" % n, "n_before": n, "n_after": m,
-                       "nn": "box-hierarchy (exact)" if used_tree else "bruteforce",
+                       "nn": ("box-hierarchy (exact)" if args.nn == "tree" else "cell-grid + box-hierarchy fallback (exact)") if used_tree else "bruteforce",
                        "dist_arithmetic": "cpu_rounding" if args.dist_mode == 0 else "fma",
                        "compose": "cpu_additive",
                        "parallelism": ("single GPU" if world == 1 else

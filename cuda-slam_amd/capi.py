@@ -15,10 +15,11 @@ LIB_PATH = os.environ.get("MISLAM_LIB") or os.path.join(_HERE, "libmislam.so")  
 MI_OK = 0
 DIST_CPU_ROUNDING, DIST_FMA = 0, 1
 COMPOSE_CPU_ADDITIVE, COMPOSE_EXACT = 0, 1
-NN_AUTO, NN_BRUTEFORCE, NN_TREE = 0, 1, 2
+NN_AUTO, NN_BRUTEFORCE, NN_TREE, NN_GRID = 0, 1, 2, 3
 SHARD_AUTO, SHARD_TARGET, SHARD_SOURCE = 0, 1, 2
 SUM_EXACT, SUM_CPU_SEQUENTIAL = 0, 1
-NN_TREE_MIN_POINTS = 24000          # MI_NN_AUTO switches to the box hierarchy at this many fixed points (mi_slam.h)
+NN_INDEX_MIN_POINTS = 24000         # MI_NN_AUTO switches to the cell grid at this many fixed points (mi_slam.h MI_NN_INDEX_MIN_POINTS)
+NN_TREE_MIN_POINTS = NN_INDEX_MIN_POINTS
 STOP_RUNNING, STOP_CONVERGED, STOP_MAX_ITERATIONS, STOP_NO_PAIRS, STOP_ERROR_INCREASED, STOP_TOLERANCE, STOP_SIGMA = range(7)
 (KERNEL_NN, KERNEL_MOMENTS, KERNEL_SOLVE, KERNEL_TRANSFORM, KERNEL_FINALIZE, KERNEL_ALLREDUCE, KERNEL_CPD_DENOM,
  KERNEL_CPD_CONTRACT, KERNEL_CPD_MSTEP, KERNEL_CPD_FGT) = range(10)
@@ -36,7 +37,7 @@ EXPORTS = [
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_estep",
     "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
     "mi_prepare_params_default", "mi_prepare_cloud",
-    "mi_cpd_mstep", "mi_profile_enable", "mi_profile_select", "mi_profile_reset", "mi_profile_get", "mi_nn_kernel_name",
+    "mi_cpd_mstep", "mi_profile_enable", "mi_profile_select", "mi_profile_reset", "mi_profile_get", "mi_profile_search_stats", "mi_nn_kernel_name",
 ]
 
 
@@ -432,6 +433,13 @@ class Context:
     # ---- profiling
     def profile_enable(self, on=True):
         _check(lib().mi_profile_enable(self._h, 1 if on else 0))
+
+    def search_stats(self, enable):
+        """Counters of the cell-grid search since they were last enabled: (candidates, rows, to_hierarchy, points, nodes, leaves,
+        walking waves, 0)."""
+        out = (C.c_ulonglong * 8)()
+        _check(lib().mi_profile_search_stats(self._h, 1 if enable else 0, out))
+        return tuple(int(v) for v in out)
 
     def nn_kernel_name(self, n_moving, m_fixed_local, nn_mode=NN_AUTO):
         lib().mi_nn_kernel_name.restype = C.c_char_p

@@ -11,6 +11,7 @@
 
 #include "../../include/mi_slam.h"
 #include "kernels.h"
+#include "nn_grid.h"
 #include "nn_tree.h"
 
 namespace mislam {
@@ -87,6 +88,14 @@ struct mi_ctx {
     size_t exchange_cap = 0;
     bool distributed() const { return comm != nullptr || exchange != nullptr; }
     int cu_count = 256;
+    // developer switches, read ONCE at context creation (none changes a result)
+    struct Tuning {
+        int nn_force_mode = 0;                           // MISLAM_NN_MODE: force MI_NN_* whatever the call asks
+        int nn_R = 2, nn_wgs = 0, nn_chunks = 0;         // MISLAM_NN_R / _WGS / _CHUNKS: K1 sources per lane, workgroup budget, target chunks
+        float grid_points_per_cell = mislam::GRID_POINTS_PER_CELL;   // MISLAM_GRID_PPC
+        int cpd_mfma = 1;                                // MISLAM_CPD_MFMA=0: VALU contraction instead of MFMA
+        int fgt_resume = 1;                              // MISLAM_FGT_RESUME=0: re-cluster the fixed cloud from scratch every E-step
+    } tune;
 
     // ---- workspace shared by the drivers
     mislam::DevBuf<float> staging;                       // AoS upload/download staging
@@ -95,25 +104,27 @@ struct mi_ctx {
     mislam::DevBuf<float> tx, ty, tz;                    // this rank's fixed-cloud shard, SoA (K1 scalar streams)
     mislam::DevBuf<float4> tgt4;                         // same shard as float4 (gathers)
     mislam::DevBuf<unsigned long long> keys;
-    mislam::DevBuf<double> part_mom, part_err;
+    mislam::DevBuf<double> part_mom, part_err;           // per-workgroup partial sums of the NICP / CPD drivers
+    mislam::DevBuf<double> rows, rows_reduced;           // ICP: one row of 18 sums per 128 moving points (icp_rows.hpp), and <= 64 reduced rows
     mislam::DevBuf<int> idx_tmp;
     mislam::DevBuf<unsigned char> keep_tmp;
     mislam::IcpState* d_state = nullptr;
     mislam::IcpState* h_state = nullptr;                 // pinned
 
-    // ---- exact-NN box hierarchy over the fixed-cloud shard (built lazily, valid until the shard is replaced)
-    mislam::DevBuf<unsigned int> tcodes_in, tcodes_out;
+    // ---- exact-NN indexes over the fixed-cloud shard (built lazily, valid until the shard is replaced)
+    mislam::DevBuf<unsigned int> tcodes_in, tcodes_out;  // Morton sort scratch (also used for the moving cloud's ordering)
     mislam::DevBuf<int> torder_in, torder_out;
     mislam::DevBuf<float> tbbox;
     mislam::DevBuf<unsigned char> tsort_temp;
-    mislam::DevBuf<float4> tpts, tboxes;
-    mislam::DevBuf<float4> tpairs, tleaf;                // compact copies for the per-lane walk (NnTreeView)
+    mislam::DevBuf<float4> tpts, tboxes;                 // box hierarchy (nn_tree.h): sorted points (build scratch), node boxes
+    mislam::DevBuf<float4> tpairs, tleaf;                // compact copies the walk reads (NnTreeView)
     mislam::DevBuf<int> tidx;
-    mislam::DevBuf<float4> tquads;                       // 4-wide records for the wide walk
-    mislam::DevBuf<unsigned int> twork;                  // the search's work counter (dynamic fetching)
-    mislam::DevBuf<uint4> tpairs_half;
     mislam::NnTreeView tree{};
     bool tree_valid = false;
+    mislam::DevBuf<float4> gpts;                         // cell grid (nn_grid.h): points sorted by cell
+    mislam::DevBuf<unsigned int> gstart, gfill, gscan;   // cell offsets, build cursors, scan scratch
+    mislam::NnGridView grid{};
+    bool grid_valid = false;
     mislam::DevBuf<int> sorder;                          // Morton order of the moving cloud (sorted slot -> caller's index)
     mislam::DevBuf<int> sinv;                            // its inverse (caller's index -> sorted slot), MI_SUM_CPU_SEQUENTIAL only
     mislam::DevBuf<float> resid;                         // per-slot squared residuals, same mode
@@ -123,12 +134,15 @@ struct mi_ctx {
     int n = 0, n_pad = 0;
     int m_total = 0, shard_lo = 0, shard_hi = 0;
     bool source_sharded = false;                         // MI_SHARD_SOURCE in effect: n = this rank's slice, fixed cloud replicated
+    bool fused = false;                                  // the grid search carries the O(N) part of the iteration (nn_grid.hip)
     mi_icp_params icp{};
 
     // ---- CPD workspace (allocated on first use)
     mislam::CpdWorkspace* cpd = nullptr;
 
     // ---- profiling
+    mislam::DevBuf<unsigned long long> nn_stats;         // mi_profile_search_stats counters
+    bool nn_stats_on = false;
     bool profile = false;
     unsigned int prof_mask = 0xffffffffu;                // kernels that get events while profiling (mi_profile_select)
     std::vector<mislam::ProfileSpan> spans;
@@ -160,7 +174,8 @@ size_t target_alloc_len(int m_local);
 int upload_soa(mi_ctx* ctx, const float* host_aos, int n, int n_pad, float* x, float* y, float* z, float4* packed);
 // Uploads this rank's shard of the fixed cloud (SoA streams for K1 + float4 for gathers); invalidates the box hierarchy.
 int upload_target_shard(mi_ctx* ctx, const float* after_xyz, int m_total, bool replicate = false);
-// Correspondence search of n moving points (SoA, padded) against the loaded fixed-cloud shard into ctx->keys (K1 or K1t).
+// Correspondence search of n moving points (SoA, padded) against the loaded fixed-cloud shard into ctx->keys (K1, K1t or K1g).
+int resolve_nn_mode(const mi_ctx* ctx, int nn_mode, int m_local);
 int launch_nn(mi_ctx* ctx, const float* sx, const float* sy, const float* sz, int n, int m_local, int index_base, int fma,
               const int* done_flag, int nn_mode);
 // In-place all-reduce of a device array over the ranks, on the context's stream: RCCL, or the caller's transport through pinned

@@ -161,17 +161,13 @@ static CpdRules cpd_rules(const CpdWorkspace* w, const mi_cpd_params* p)
     return r;
 }
 
-static int use_mfma_contraction()
-{
-    const char* v = getenv("MISLAM_CPD_MFMA");
-    return (v && *v) ? atoi(v) : 1;
-}
+static int use_mfma_contraction(const mi_ctx* c) { return c->tune.cpd_mfma; }   // MISLAM_CPD_MFMA, read at context creation
 
 static int cpd_estep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
 {
     { ProfScope ps(c, MI_KERNEL_CPD_DENOM); MI_HIP(cpd_denominators(v, c->stream)); }
     MI_HIP(cpd_post_denominators(v, c->stream));
-    { ProfScope ps(c, MI_KERNEL_CPD_CONTRACT); MI_HIP(cpd_contract(v, use_mfma_contraction(), c->stream)); }
+    { ProfScope ps(c, MI_KERNEL_CPD_CONTRACT); MI_HIP(cpd_contract(v, use_mfma_contraction(c), c->stream)); }
     MI_HIP(cpd_post_contract(v, c->stream));
     (void)w;
     return MI_OK;
@@ -319,9 +315,8 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
     // P1 and PX: sources = fixed cloud weighted by 1/den and x/den, queried at the moving cloud   (:54-66; the reference
     // clusters the fixed cloud four times with the same result -- once is enough)
     // the fixed cloud does not move: the same K needs no new clustering at all, a larger K only the additional centres
-    // (MISLAM_FGT_RESUME=0 re-clusters from scratch every time; the results must not change by a bit -- tests/test_gpu_fgt.py)
-    const char* resume_env = getenv("MISLAM_FGT_RESUME");
-    const bool resume = !(resume_env && *resume_env == '0');
+    // (a context created under MISLAM_FGT_RESUME=0 re-clusters from scratch every time; the results must not change by a bit -- tests/test_gpu_fgt.py)
+    const bool resume = c->tune.fgt_resume != 0;
     if (!resume || f->a.swept_K != K) {
         ca.k_done = resume && f->a.swept_K < K ? f->a.swept_K : 0;
         MI_HIP(fgt_cluster(ca, f->sort_temp.p, temp, c->stream));

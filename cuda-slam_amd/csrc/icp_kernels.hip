@@ -15,13 +15,19 @@
 //   K6  icp_finalize_kernel         error reduction + the stop rules of basicicp.cpp:52-57 / icpcuda.cu:40-53, evaluated
 //                                   on the device: every kernel of later iterations returns at once when `done` is set.
 //
-// Reductions are two-stage with a fixed summation order (per-block partials, then one workgroup), so results are
-// bitwise reproducible run to run; there are no float atomics.
+// Since round 2 the default (cell-grid) search carries K2 and K4+K5 itself (nn_grid.hip: the fused iteration); the stand-alone
+// kernels below serve the every-pair search, the multi-GPU split of the fixed cloud, MI_SUM_CPU_SEQUENTIAL and the test-grade
+// primitives.  Either way an iteration's sums are "rows" (icp_rows.hpp): one row of 18 partial sums per 128 moving points, added
+// in one fixed tree -- so every strategy yields the same bits -- then icp_rows_reduce (<= 64 workgroups) and the solve kernel
+// sum the rows in index order.  No float atomics: results are bitwise reproducible run to run.
+// The stop rule of iteration i is evaluated at the START of the solve kernel of iteration i+1 (its error sums ride in the same
+// rows as that iteration's moments), or by icp_finalize_pending when the host stops enqueuing: one all-reduce per iteration on
+// several GPUs, three launches per iteration on one.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "icp_rows.hpp"
 #include "kernels.h"
-#include "reduce.hpp"
 #include "svd3.hpp"
 
 namespace mislam {
@@ -84,11 +90,15 @@ __global__ __launch_bounds__(256) void pack_keys_kernel(const int* __restrict__ 
 // every pair is accumulated by exactly one rank, the one that owns the target's coordinates -- and, with filter_pairs,
 // when d2 < max_distance_squared (common.cpp:490).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void icp_moments_kernel(IcpView v, double* __restrict__ partials)
+__global__ __launch_bounds__(ICP_ROW_POINTS) void icp_moments_rows_kernel(IcpView v, double* __restrict__ rows)
 {
     if (v.state->done != 0) return;
-    double acc[ICP_MOMENTS] = {0};
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n; i += gridDim.x * 256) {
+    __shared__ double lds[ICP_ROW_WAVES * 16];
+    double mom[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) mom[k] = 0.0;
+    const int i = blockIdx.x * ICP_ROW_POINTS + threadIdx.x;
+    if (i < v.n) {
         const unsigned long long key = v.keys[i];
         const int gidx = (int)(unsigned int)(key & 0xffffffffull);
         const float d2 = __uint_as_float((unsigned int)(key >> 32));
@@ -96,36 +106,53 @@ __global__ __launch_bounds__(256) void icp_moments_kernel(IcpView v, double* __r
         const bool kept = v.filter_pairs ? (d2 < v.max_distance_squared) : true;
         if (mine && kept) {
             const float4 a = v.tgt4[gidx - v.shard_lo];
-            const double bx = v.cx[i], by = v.cy[i], bz = v.cz[i];
-            const double ax = a.x, ay = a.y, az = a.z;
-            acc[0] += 1.0;
-            acc[1] += bx; acc[2] += by; acc[3] += bz;
-            acc[4] += ax; acc[5] += ay; acc[6] += az;
-            acc[7] += ax * bx;  acc[8] += ax * by;  acc[9] += ax * bz;
-            acc[10] += ay * bx; acc[11] += ay * by; acc[12] += ay * bz;
-            acc[13] += az * bx; acc[14] += az * by; acc[15] += az * bz;
+            pair_moments(mom, v.cx[i], v.cy[i], v.cz[i], a.x, a.y, a.z);
         }
     }
-    block_sum_store<ICP_MOMENTS>(acc, partials + (size_t)blockIdx.x * ICP_MOMENTS);
+    row_store_moments(mom, rows + (size_t)blockIdx.x * ICP_ROW, lds);
 }
 
-// Reduce block partials into the state (multi-GPU path: the result is then all-reduced before the solve).
-__global__ __launch_bounds__(256) void icp_reduce_moments_kernel(IcpState* __restrict__ state, const double* __restrict__ partials, int nblocks)
+// rows [first, first + count) of ICP_ROW doubles -> out[blockIdx.x] : workgroup g sums its contiguous slice of rows in index
+// order (14 strips of rows, then the strips in order)
+__global__ __launch_bounds__(256) void icp_rows_reduce_kernel(const double* __restrict__ rows, int nrows, int rows_per_block,
+                                                              double* __restrict__ out)
 {
-    if (state->done != 0) return;
-    __shared__ double lds[256];
-    double mom[ICP_MOMENTS];
-    reduce_partials<ICP_MOMENTS>(partials, nblocks, mom, lds);
-    if (threadIdx.x < ICP_MOMENTS) state->mom[threadIdx.x] = mom[threadIdx.x];
+    constexpr int STRIPS = 256 / ICP_ROW;                      // 14
+    __shared__ double lds[STRIPS * ICP_ROW];
+    const int k = threadIdx.x % ICP_ROW, strip = threadIdx.x / ICP_ROW;
+    const int lo = blockIdx.x * rows_per_block;
+    const int hi = lo + rows_per_block < nrows ? lo + rows_per_block : nrows;
+    if (strip < STRIPS) {
+        double s = 0.0;
+#pragma unroll 4
+        for (int r = lo + strip; r < hi; r += STRIPS) s += rows[(size_t)r * ICP_ROW + k];
+        lds[strip * ICP_ROW + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < ICP_ROW) {
+        double tot = lds[threadIdx.x];
+        for (int g = 1; g < STRIPS; g++) tot += lds[g * ICP_ROW + threadIdx.x];
+        out[(size_t)blockIdx.x * ICP_ROW + threadIdx.x] = tot;
+    }
 }
 
-__global__ __launch_bounds__(256) void icp_reduce_error_kernel(IcpState* __restrict__ state, const double* __restrict__ partials, int nblocks)
+// sum of `count` reduced rows, column threadIdx.x (< ICP_ROW), in index order
+__device__ __forceinline__ double reduced_column(const double* __restrict__ part, int count)
+{
+    double tot = 0.0;
+#pragma unroll 8
+    for (int g = 0; g < count; g++) tot += part[(size_t)g * ICP_ROW + threadIdx.x];
+    return tot;
+}
+
+// reduced rows -> state->mom[16], state->err[2] (contiguous in the state block); which = 1 moments, 2 error sums, 3 both
+__global__ __launch_bounds__(64) void icp_rows_to_state_kernel(IcpState* __restrict__ state, const double* __restrict__ part, int count, int which)
 {
     if (state->done != 0) return;
-    __shared__ double lds[256];
-    double e[ICP_ERRSUMS];
-    reduce_partials<ICP_ERRSUMS>(partials, nblocks, e, lds);
-    if (threadIdx.x < ICP_ERRSUMS) state->err[threadIdx.x] = e[threadIdx.x];
+    if (threadIdx.x >= ICP_ROW) return;
+    const double tot = reduced_column(part, count);
+    if (threadIdx.x < ICP_MOMENTS) { if (which & 1) state->mom[threadIdx.x] = tot; }
+    else if (which & 2) state->err[threadIdx.x - ICP_MOMENTS] = tot;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -167,26 +194,6 @@ __device__ void mat3_mul_cm(const float a[9], const float b[9], float out[9])
     for (int i = 0; i < 9; i++) out[i] = r[i];
 }
 
-__device__ void apply_solve(IcpState* __restrict__ state, const double* mom, int compose_mode, int seq_sums);
-
-__global__ __launch_bounds__(256) void icp_solve_kernel(IcpState* __restrict__ state, const double* __restrict__ partials, int nblocks,
-                                                        int compose_mode, int seq_sums)
-{
-    if (state->done != 0) return;
-    __shared__ double lds[256];
-    double mom[ICP_MOMENTS];
-    if (partials != nullptr) {
-        reduce_partials<ICP_MOMENTS>(partials, nblocks, mom, lds);
-    } else {
-#pragma unroll
-        for (int i = 0; i < ICP_MOMENTS; i++) mom[i] = state->mom[i];
-    }
-    if (threadIdx.x != 0) return;
-    if (partials != nullptr)
-        for (int i = 0; i < ICP_MOMENTS; i++) state->mom[i] = mom[i];
-    apply_solve(state, mom, compose_mode, seq_sums);
-}
-
 // Kabsch solve of the moments + composition with the running transform (one lane)
 __device__ void apply_solve(IcpState* __restrict__ state, const double* mom, int compose_mode, int seq_sums)
 {
@@ -225,16 +232,18 @@ __device__ void apply_solve(IcpState* __restrict__ state, const double* mom, int
 // against the OLD correspondences (basicicp.cpp:48, icpcuda.cu:38), keys re-armed for the next search.
 // err partial = { sum |a - cur|^2, kept pairs }
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void icp_transform_error_kernel(IcpView v, double* __restrict__ partials, int rearm)
+__global__ __launch_bounds__(ICP_ROW_POINTS) void icp_transform_error_rows_kernel(IcpView v, double* __restrict__ rows, int rearm)
 {
     if (v.state->done != 0) return;
+    __shared__ double lds[ICP_ROW_WAVES * 2];
     float R[9], t[3];
 #pragma unroll
     for (int i = 0; i < 9; i++) R[i] = v.state->R[i];
 #pragma unroll
     for (int i = 0; i < 3; i++) t[i] = v.state->t[i];
-    double acc[ICP_ERRSUMS] = {0};
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n_pad; i += gridDim.x * 256) {
+    double e0 = 0.0, e1 = 0.0;
+    const int i = blockIdx.x * ICP_ROW_POINTS + threadIdx.x;
+    if (i < v.n_pad) {
         const float x = v.bx[i], y = v.by[i], z = v.bz[i];
         // TransformPoint: (rotationMatrix * point) + translationVector  (common.cpp:45-49), glm operation order
         const float ox = ((R[0] * x + R[3] * y) + R[6] * z) + t[0];
@@ -254,12 +263,12 @@ __global__ __launch_bounds__(256) void icp_transform_error_kernel(IcpView v, dou
                 const float dx = a.x - ox, dy = a.y - oy, dz = a.z - oz;
                 const float e = (dx * dx + dy * dy) + dz * dz;       // diff.LengthSquared(), common.cpp:264-265
                 if (kept) {
-                    acc[0] += (double)e;
-                    acc[1] += 1.0;
+                    e0 = (double)e;
+                    e1 = 1.0;
                     resid = e;
                 }
                 // The old match under the new transform is a real candidate of the next search, evaluated with the
-                // search's own arithmetic, so its key is a valid starting bound for K1.
+                // search's own arithmetic, so its key is a valid starting bound.
                 const float c = v.fma ? __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) : e;
                 next_key = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned int)gidx;
             }
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(256) void icp_transform_error_kernel(IcpView v, dou
             if (v.resid != nullptr) v.resid[i] = resid;
         }
     }
-    block_sum_store<ICP_ERRSUMS>(acc, partials + (size_t)blockIdx.x * ICP_ERRSUMS);
+    row_store_error(e0, e1, rows + (size_t)blockIdx.x * ICP_ROW, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -341,26 +350,6 @@ __global__ __launch_bounds__(256) void invert_order_kernel(const int* __restrict
 // ---------------------------------------------------------------------------------------------------------------
 // K6: error + stop rules.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ void finalize_iteration(IcpState* __restrict__ state, double e0, double e1, const IcpRules& rules);
-
-__global__ __launch_bounds__(256) void icp_finalize_kernel(IcpState* __restrict__ state, const double* __restrict__ partials, int nblocks,
-                                                           IcpRules rules)
-{
-    if (state->done != 0) return;
-    __shared__ double lds[256];
-    double e[ICP_ERRSUMS];
-    if (partials != nullptr) {
-        reduce_partials<ICP_ERRSUMS>(partials, nblocks, e, lds);
-    } else {
-        e[0] = state->err[0];
-        e[1] = state->err[1];
-    }
-    if (threadIdx.x != 0) return;
-    state->err[0] = e[0];
-    state->err[1] = e[1];
-    finalize_iteration(state, e[0], e[1], rules);
-}
-
 // error of the iteration just applied + the stop rules (one lane)
 __device__ void finalize_iteration(IcpState* __restrict__ state, double e0, double e1, const IcpRules& rules)
 {
@@ -395,56 +384,97 @@ __device__ void finalize_iteration(IcpState* __restrict__ state, double e0, doub
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// multi-GPU path with one all-reduce per iteration (kernels.h): the error sums of iteration i ride with the moments of i+1
+// K3 + K6: the deferred solve.  An iteration's error sums arrive together with the NEXT iteration's moments (same rows), so the
+// solve kernel first settles the previous iteration's stop rule (err_pending) and, if it fired, applies nothing -- that
+// iteration's search and moments were in vain, once per registration.  part != null: the sums are the `count` reduced rows;
+// part == null: they are already in state->mom / state->err (multi-GPU: all-reduced there).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void icp_post_error_kernel(IcpState* __restrict__ state, const double* __restrict__ partials, int nblocks)
+__global__ __launch_bounds__(64) void icp_solve_deferred_kernel(IcpState* __restrict__ state, const double* __restrict__ part, int count,
+                                                                int compose_mode, IcpRules rules, int mark_pending)
 {
     if (state->done != 0) return;
-    __shared__ double lds[256];
-    double e[ICP_ERRSUMS];
-    reduce_partials<ICP_ERRSUMS>(partials, nblocks, e, lds);
-    if (threadIdx.x < ICP_ERRSUMS) state->err[threadIdx.x] = e[threadIdx.x];
-    if (threadIdx.x == 0) state->err_pending = 1;
-}
-
-__global__ void icp_solve_deferred_kernel(IcpState* __restrict__ state, int compose_mode, IcpRules rules)
-{
-    if (threadIdx.x != 0 || state->done != 0) return;
-    if (state->err_pending) {            // the previous iteration's error has just been all-reduced together with the moments
+    __shared__ double sums[ICP_ROW];
+    if (threadIdx.x < ICP_ROW) {
+        sums[threadIdx.x] = part != nullptr ? reduced_column(part, count)
+                                            : (threadIdx.x < ICP_MOMENTS ? state->mom[threadIdx.x] : state->err[threadIdx.x - ICP_MOMENTS]);
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (state->err_pending) {            // the previous iteration's error sums have arrived with these moments
         state->err_pending = 0;
-        finalize_iteration(state, state->err[0], state->err[1], rules);
-        if (state->done != 0) return;    // its stop rule fired: this iteration's search and moments were in vain, nothing is applied
+        state->err[0] = sums[ICP_MOMENTS];
+        state->err[1] = sums[ICP_MOMENTS + 1];
+        finalize_iteration(state, sums[ICP_MOMENTS], sums[ICP_MOMENTS + 1], rules);
+        if (state->done != 0) return;    // its stop rule fired: nothing of this iteration is applied
     }
     double mom[ICP_MOMENTS];
-    for (int i = 0; i < ICP_MOMENTS; i++) mom[i] = state->mom[i];
-    apply_solve(state, mom, compose_mode, 0);
+    for (int i = 0; i < ICP_MOMENTS; i++) { mom[i] = sums[i]; state->mom[i] = sums[i]; }
+    apply_solve(state, mom, compose_mode, rules.seq_sums);
+    if (mark_pending && state->done == 0) state->err_pending = 1;
 }
 
-__global__ void icp_finalize_pending_kernel(IcpState* __restrict__ state, IcpRules rules)
+// the same evaluation alone, when the host stops enqueuing and wants the state
+__global__ __launch_bounds__(64) void icp_finalize_pending_kernel(IcpState* __restrict__ state, const double* __restrict__ part, int count, IcpRules rules)
 {
-    if (threadIdx.x != 0 || state->done != 0 || !state->err_pending) return;
+    if (state->done != 0 || !state->err_pending) return;
+    __shared__ double sums[ICP_ROW];
+    if (threadIdx.x < ICP_ROW)
+        sums[threadIdx.x] = part != nullptr ? reduced_column(part, count)
+                                            : (threadIdx.x < ICP_MOMENTS ? 0.0 : state->err[threadIdx.x - ICP_MOMENTS]);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     state->err_pending = 0;
-    finalize_iteration(state, state->err[0], state->err[1], rules);
+    state->err[0] = sums[ICP_MOMENTS];
+    state->err[1] = sums[ICP_MOMENTS + 1];
+    finalize_iteration(state, sums[ICP_MOMENTS], sums[ICP_MOMENTS + 1], rules);
+}
+
+__global__ void icp_mark_pending_kernel(IcpState* __restrict__ state)
+{
+    if (threadIdx.x == 0 && state->done == 0) state->err_pending = 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------------------------
-hipError_t icp_post_error(IcpState* state, const double* partials, int nblocks, hipStream_t s)
+int icp_row_count(int n) { return (n + ICP_ROW_POINTS - 1) / ICP_ROW_POINTS; }
+
+int icp_reduced_count(int nrows)
 {
-    hipLaunchKernelGGL(icp_post_error_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks);
+    int g = (nrows + 31) / 32;           // at least ~32 rows per workgroup
+    if (g > ICP_MAX_REDUCED_ROWS) g = ICP_MAX_REDUCED_ROWS;
+    return g < 1 ? 1 : g;
+}
+
+hipError_t icp_rows_reduce(const double* rows, int nrows, double* part, hipStream_t s)
+{
+    const int g = icp_reduced_count(nrows);
+    const int per = (nrows + g - 1) / g;
+    hipLaunchKernelGGL(icp_rows_reduce_kernel, dim3(g), dim3(256), 0, s, rows, nrows, per, part);
     return hipGetLastError();
 }
 
-hipError_t icp_solve_deferred(IcpState* state, int compose_mode, const IcpRules& rules, hipStream_t s)
+hipError_t icp_rows_to_state(IcpState* state, const double* part, int count, int which, hipStream_t s)
 {
-    hipLaunchKernelGGL(icp_solve_deferred_kernel, dim3(1), dim3(64), 0, s, state, compose_mode, rules);
+    hipLaunchKernelGGL(icp_rows_to_state_kernel, dim3(1), dim3(64), 0, s, state, part, count, which);
     return hipGetLastError();
 }
 
-hipError_t icp_finalize_pending(IcpState* state, const IcpRules& rules, hipStream_t s)
+hipError_t icp_solve_deferred(IcpState* state, const double* part, int count, int compose_mode, const IcpRules& rules, int mark_pending, hipStream_t s)
 {
-    hipLaunchKernelGGL(icp_finalize_pending_kernel, dim3(1), dim3(64), 0, s, state, rules);
+    hipLaunchKernelGGL(icp_solve_deferred_kernel, dim3(1), dim3(64), 0, s, state, part, count, compose_mode, rules, mark_pending);
+    return hipGetLastError();
+}
+
+hipError_t icp_finalize_pending(IcpState* state, const double* part, int count, const IcpRules& rules, hipStream_t s)
+{
+    hipLaunchKernelGGL(icp_finalize_pending_kernel, dim3(1), dim3(64), 0, s, state, part, count, rules);
+    return hipGetLastError();
+}
+
+hipError_t icp_mark_pending(IcpState* state, hipStream_t s)
+{
+    hipLaunchKernelGGL(icp_mark_pending_kernel, dim3(1), dim3(64), 0, s, state);
     return hipGetLastError();
 }
 
@@ -493,27 +523,9 @@ hipError_t pack_keys(const int* idx, const unsigned char* keep, int n, unsigned 
 
 int icp_reduce_blocks(int n) { return blocks_for(n, ICP_MAX_PARTIAL_BLOCKS); }
 
-hipError_t icp_moments(const IcpView& v, double* partials, int nblocks, hipStream_t s)
+hipError_t icp_moments_rows(const IcpView& v, double* rows, hipStream_t s)
 {
-    hipLaunchKernelGGL(icp_moments_kernel, dim3(nblocks), dim3(256), 0, s, v, partials);
-    return hipGetLastError();
-}
-
-hipError_t icp_reduce_moments(IcpState* state, const double* partials, int nblocks, hipStream_t s)
-{
-    hipLaunchKernelGGL(icp_reduce_moments_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks);
-    return hipGetLastError();
-}
-
-hipError_t icp_reduce_error(IcpState* state, const double* partials, int nblocks, hipStream_t s)
-{
-    hipLaunchKernelGGL(icp_reduce_error_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks);
-    return hipGetLastError();
-}
-
-hipError_t icp_solve(IcpState* state, const double* partials, int nblocks, int compose_mode, int seq_sums, hipStream_t s)
-{
-    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks, compose_mode, seq_sums);
+    hipLaunchKernelGGL(icp_moments_rows_kernel, dim3(icp_row_count(v.n)), dim3(ICP_ROW_POINTS), 0, s, v, rows);
     return hipGetLastError();
 }
 
@@ -536,15 +548,9 @@ hipError_t icp_seq_error(const IcpView& v, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t icp_transform_error(const IcpView& v, double* partials, int nblocks, int rearm, hipStream_t s)
+hipError_t icp_transform_error_rows(const IcpView& v, double* rows, int rearm, hipStream_t s)
 {
-    hipLaunchKernelGGL(icp_transform_error_kernel, dim3(nblocks), dim3(256), 0, s, v, partials, rearm);
-    return hipGetLastError();
-}
-
-hipError_t icp_finalize(IcpState* state, const double* partials, int nblocks, const IcpRules& rules, hipStream_t s)
-{
-    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks, rules);
+    hipLaunchKernelGGL(icp_transform_error_rows_kernel, dim3(icp_row_count(v.n_pad)), dim3(ICP_ROW_POINTS), 0, s, v, rows, rearm);
     return hipGetLastError();
 }
 

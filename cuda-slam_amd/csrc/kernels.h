@@ -93,21 +93,25 @@ hipError_t unpack_keys(const unsigned long long* keys, const int* order, int n, 
 hipError_t pack_keys(const int* idx, const unsigned char* keep, int n, unsigned long long* keys, hipStream_t s);
 
 int icp_reduce_blocks(int n);
-hipError_t icp_moments(const IcpView& v, double* partials, int nblocks, hipStream_t s);
-hipError_t icp_reduce_moments(IcpState* state, const double* partials, int nblocks, hipStream_t s);
-hipError_t icp_reduce_error(IcpState* state, const double* partials, int nblocks, hipStream_t s);
-hipError_t icp_solve(IcpState* state, const double* partials, int nblocks, int compose_mode, int seq_sums, hipStream_t s);
-// rearm: 0 = leave keys, 1 = KEY_INIT, 2 = the previous match's key under the NEW transform (a real candidate: K1 then
-// starts from a tight bound and hardly ever takes its re-scan path)
-hipError_t icp_transform_error(const IcpView& v, double* partials, int nblocks, int rearm, hipStream_t s);
-hipError_t icp_finalize(IcpState* state, const double* partials, int nblocks, const IcpRules& rules, hipStream_t s);
-// Multi-GPU path with ONE all-reduce per iteration: an iteration's error sums wait in state->err (icp_post_error marks them
-// pending) and travel with the NEXT iteration's moments (mom[16] and err[2] are contiguous: one 18-double all-reduce).
-// icp_solve_deferred first evaluates the pending stop rule, then -- unless it fired -- solves from state->mom;
-// icp_finalize_pending does the same evaluation alone (after a last all-reduce of err) when the host stops enqueuing.
-hipError_t icp_post_error(IcpState* state, const double* partials, int nblocks, hipStream_t s);
-hipError_t icp_solve_deferred(IcpState* state, int compose_mode, const IcpRules& rules, hipStream_t s);
-hipError_t icp_finalize_pending(IcpState* state, const IcpRules& rules, hipStream_t s);
+// An iteration's sums are "rows" (icp_rows.hpp): one row of 18 partial sums -- 16 moments, 2 error sums -- per 128 moving points,
+// whichever kernel produced them (the fused search of nn_grid.hip, or the two stand-alone kernels below).
+int icp_row_count(int n);                  // rows of a cloud of n points
+int icp_reduced_count(int nrows);          // rows left after icp_rows_reduce (<= 64)
+hipError_t icp_moments_rows(const IcpView& v, double* rows, hipStream_t s);                    // K2: columns [0,16) of rows [0, row_count(n))
+// K4+K5: cur = R*before + t for all n_pad entries, columns [16,18) of rows [0, row_count(n_pad)), keys re-armed:
+// rearm 0 = leave keys, 1 = KEY_INIT, 2 = the previous match's key under the NEW transform (a real candidate: the next search
+// starts from a tight bound)
+hipError_t icp_transform_error_rows(const IcpView& v, double* rows, int rearm, hipStream_t s);
+hipError_t icp_rows_reduce(const double* rows, int nrows, double* part, hipStream_t s);         // -> part[icp_reduced_count(nrows)][18]
+// reduced rows -> state->mom / state->err (which: 1 moments, 2 error sums, 3 both); the multi-GPU paths all-reduce them there
+hipError_t icp_rows_to_state(IcpState* state, const double* part, int count, int which, hipStream_t s);
+// K3 + K6, deferred: settles the PREVIOUS iteration's stop rule from the error sums (if state->err_pending), then -- unless it
+// fired -- solves from the moments and composes.  part != null: sums = the reduced rows; null: already in state->mom / err.
+// mark_pending: this iteration's own error will arrive with the next call (or with icp_finalize_pending).
+hipError_t icp_solve_deferred(IcpState* state, const double* part, int count, int compose_mode, const IcpRules& rules, int mark_pending,
+                              hipStream_t s);
+hipError_t icp_finalize_pending(IcpState* state, const double* part, int count, const IcpRules& rules, hipStream_t s);
+hipError_t icp_mark_pending(IcpState* state, hipStream_t s);
 // MI_SUM_CPU_SEQUENTIAL: cpu-slam's sequential fp32 running sums, reproduced bit for bit (one wave per sum)
 hipError_t invert_order(const int* order, int n, int* inv, hipStream_t s);
 hipError_t icp_seq_centroids(const IcpView& v, hipStream_t s);
@@ -116,6 +120,7 @@ hipError_t icp_seq_error(const IcpView& v, hipStream_t s);
 // One per translation unit with kernels: loads that unit's code object (see the definitions).
 hipError_t preload_nn_kernel();
 hipError_t preload_nn_tree();
+hipError_t preload_nn_grid();
 hipError_t preload_icp_kernels();
 hipError_t preload_cpd_kernels();
 hipError_t preload_cpd_fgt();

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "context.h"
 
@@ -57,7 +58,7 @@ extern "C" int mi_ctx_preload(mi_ctx* c)
 {
     if (!c) { set_error("mi_ctx_preload: null context"); return MI_ERR_INVALID_ARG; }
     MI_HIP(hipSetDevice(c->device));
-    MI_HIP(preload_nn_kernel()); MI_HIP(preload_nn_tree()); MI_HIP(preload_icp_kernels()); MI_HIP(preload_cpd_kernels());
+    MI_HIP(preload_nn_kernel()); MI_HIP(preload_nn_tree()); MI_HIP(preload_nn_grid()); MI_HIP(preload_icp_kernels()); MI_HIP(preload_cpd_kernels());
     MI_HIP(preload_cpd_fgt()); MI_HIP(preload_nicp_api()); MI_HIP(preload_prepare_api());
     return MI_OK;
 }
@@ -81,8 +82,16 @@ static int ctx_create_common(int device, mi_ctx** out)
         MI_HIP(hipMalloc((void**)&c->d_state, sizeof(IcpState)));
         MI_HIP(hipHostMalloc((void**)&c->h_state, sizeof(IcpState), hipHostMallocDefault));
         memset(c->h_state, 0, sizeof(IcpState));
-        const char* preload_env = getenv("MISLAM_PRELOAD");       // =1: mi_ctx_preload as part of every context creation
-        if (preload_env && *preload_env == '1') MI_TRY(mi_ctx_preload(c));
+        // developer switches: read here, once -- nothing on the per-iteration path looks at the environment
+        auto env_i = [](const char* name, int dflt) { const char* v = getenv(name); return (v && *v) ? atoi(v) : dflt; };
+        c->tune.nn_force_mode = env_i("MISLAM_NN_MODE", 0);
+        c->tune.nn_R = env_i("MISLAM_NN_R", 2);
+        c->tune.nn_wgs = env_i("MISLAM_NN_WGS", 0);
+        c->tune.nn_chunks = env_i("MISLAM_NN_CHUNKS", 0);
+        c->tune.cpd_mfma = env_i("MISLAM_CPD_MFMA", 1);
+        c->tune.fgt_resume = env_i("MISLAM_FGT_RESUME", 1);
+        if (const char* ppc = getenv("MISLAM_GRID_PPC")) { const float f = (float)atof(ppc); if (f >= 0.25f && f <= 64.f) c->tune.grid_points_per_cell = f; }
+        if (env_i("MISLAM_PRELOAD", 0) == 1) MI_TRY(mi_ctx_preload(c));       // =1: mi_ctx_preload as part of every context creation
         return MI_OK;
     }();
     if (rc != MI_OK) { mi_ctx_destroy(c); return rc; }
@@ -216,7 +225,8 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     c->idx_tmp.release(); c->keep_tmp.release();
     c->tcodes_in.release(); c->tcodes_out.release(); c->torder_in.release(); c->torder_out.release();
     c->tbbox.release(); c->tsort_temp.release(); c->tpts.release(); c->tboxes.release(); c->sorder.release(); c->sinv.release(); c->resid.release();
-    c->tpairs.release(); c->tpairs_half.release(); c->tleaf.release(); c->tidx.release(); c->twork.release(); c->tquads.release();
+    c->tpairs.release(); c->tleaf.release(); c->tidx.release(); c->nn_stats.release();
+    c->gpts.release(); c->gstart.release(); c->gfill.release(); c->gscan.release(); c->rows.release(); c->rows_reduced.release();
     for (auto& s : c->spans) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->d_state) (void)hipFree(c->d_state);
@@ -296,6 +306,27 @@ extern "C" int mi_profile_reset(mi_ctx* c)
     return MI_OK;
 }
 
+extern "C" int mi_profile_search_stats(mi_ctx* c, int enable, unsigned long long out[8])
+{
+    if (!c) { set_error("mi_profile_search_stats: null context"); return MI_ERR_INVALID_ARG; }
+    MI_HIP(hipSetDevice(c->device));
+    const size_t words = (size_t)GRID_STATS_ROWS * 8;
+    MI_TRY(c->nn_stats.reserve(words));
+    if (out) {
+        for (int i = 0; i < 8; i++) out[i] = 0;
+        if (c->nn_stats_on) {
+            std::vector<unsigned long long> h(words);
+            MI_HIP(hipMemcpyAsync(h.data(), c->nn_stats.p, sizeof(unsigned long long) * words, hipMemcpyDeviceToHost, c->stream));
+            MI_HIP(hipStreamSynchronize(c->stream));
+            for (size_t r = 0; r < (size_t)GRID_STATS_ROWS; r++)
+                for (int i = 0; i < 8; i++) out[i] += h[r * 8 + i];
+        }
+    }
+    c->nn_stats_on = enable != 0;
+    if (enable) MI_HIP(hipMemsetAsync(c->nn_stats.p, 0, sizeof(unsigned long long) * words, c->stream));
+    return MI_OK;
+}
+
 extern "C" int mi_profile_get(mi_ctx* c, int kernel, double* total_ms, long long* launches)
 {
     if (!c || kernel < 0 || kernel >= MI_KERNEL_COUNT) { set_error("mi_profile_get: bad argument"); return MI_ERR_INVALID_ARG; }
@@ -310,12 +341,6 @@ extern "C" int mi_profile_get(mi_ctx* c, int kernel, double* total_ms, long long
 // shared helpers
 // ---------------------------------------------------------------------------------------------------------------
 namespace mislam {
-
-static int env_int(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 
 static inline int round_up(int v, int g) { return (v + g - 1) / g * g; }
 
@@ -333,10 +358,10 @@ size_t target_alloc_len(int m_local)
 NnPlan plan_nn(const mi_ctx* ctx, int n, int m_local)
 {
     NnPlan p;
-    p.R = env_int("MISLAM_NN_R", 2);
+    p.R = ctx->tune.nn_R;
     if (p.R != 1 && p.R != 2 && p.R != 4 && p.R != 8) p.R = 2;
     const int n_src_blocks = round_up(std::max(n, 1), 256 * p.R) / (256 * p.R);
-    const int target_wgs = env_int("MISLAM_NN_WGS", ctx->cu_count * 8);
+    const int target_wgs = ctx->tune.nn_wgs > 0 ? ctx->tune.nn_wgs : ctx->cu_count * 8;
     int chunks = (target_wgs + n_src_blocks - 1) / n_src_blocks;
     // a chunk should fit an XCD's L2 next to everything else it holds: <= 2 MB of target xyz (12 B/point)
     const int l2_chunks = (int)(((long long)std::max(m_local, 1) * 12 + (2 << 20) - 1) / (2 << 20));
@@ -345,7 +370,7 @@ NnPlan plan_nn(const mi_ctx* ctx, int n, int m_local)
     chunks = std::max(1, std::min(chunks, max_chunks));
     // multiples of 8 get the XCD-pinned block mapping of K1
     if (chunks > 1 && max_chunks >= 8) chunks = std::min(round_up(chunks, 8), max_chunks / 8 * 8);
-    const int forced = env_int("MISLAM_NN_CHUNKS", 0);
+    const int forced = ctx->tune.nn_chunks;
     if (forced > 0) chunks = std::min(forced, NN_MAX_CHUNKS);
     p.chunk_len = round_up((std::max(m_local, 1) + chunks - 1) / chunks, NN_TARGET_BLOCK);
     p.n_chunks = (std::max(m_local, 1) + p.chunk_len - 1) / p.chunk_len;
@@ -391,23 +416,47 @@ static int ensure_tree(mi_ctx* c, int m_local, int index_base)
     MI_TRY(c->tpts.reserve((size_t)n_leaves * TREE_LEAF));
     MI_TRY(c->tboxes.reserve((size_t)4 * n_pad));
     MI_TRY(c->tpairs.reserve((size_t)3 * n_pad));
-    MI_TRY(c->tpairs_half.reserve((size_t)2 * n_pad));
     MI_TRY(c->tleaf.reserve((size_t)n_leaves * (3 * TREE_LEAF / 4)));
     MI_TRY(c->tidx.reserve((size_t)n_leaves * TREE_LEAF));
-    const int quad_levels = (height + 1) / 2, quad_parity = height & 1;
-    MI_TRY(c->tquads.reserve(6 * quad_record_count(quad_levels) + 6));
     TreeBuildArgs a{};
     MI_TRY(morton_args(c, c->tx.p, c->ty.p, c->tz.p, m_local, c->torder_out.p, &a.morton));
     a.index_base = index_base; a.n_leaves = n_leaves; a.n_pad = n_pad;
     a.pts = c->tpts.p; a.boxes = c->tboxes.p;
-    a.pairs = c->tpairs.p; a.pairs_half = c->tpairs_half.p; a.leaf_soa = c->tleaf.p; a.leaf_idx = c->tidx.p;
-    a.quads = c->tquads.p; a.quad_levels = quad_levels; a.quad_parity = quad_parity;
+    a.pairs = c->tpairs.p; a.leaf_soa = c->tleaf.p; a.leaf_idx = c->tidx.p;
     MI_HIP(tree_build(a, c->stream));
-    c->tree.pts = c->tpts.p; c->tree.boxes = c->tboxes.p;
-    c->tree.pairs = c->tpairs.p; c->tree.pairs_half = c->tpairs_half.p; c->tree.leaf_soa = c->tleaf.p; c->tree.leaf_idx = c->tidx.p;
+    c->tree.boxes = c->tboxes.p;
+    c->tree.pairs = c->tpairs.p; c->tree.leaf_soa = c->tleaf.p; c->tree.leaf_idx = c->tidx.p;
     c->tree.n_pad = n_pad; c->tree.height = height;
-    c->tree.quads = c->tquads.p; c->tree.quad_levels = quad_levels; c->tree.quad_parity = quad_parity;
     c->tree_valid = true;
+    return MI_OK;
+}
+
+// Builds the cell grid over the resident fixed-cloud shard if it is not there yet.  The cell size comes from the cloud's bounding
+// box, which the host reads back: one stream synchronisation per fixed cloud, at load time.
+static int ensure_grid(mi_ctx* c, int m_local, int index_base)
+{
+    if (c->grid_valid) return MI_OK;
+    MI_TRY(c->tbbox.reserve(256 * 6 + 8));
+    float* d_bbox = c->tbbox.p + 256 * 6;
+    MI_HIP(cloud_bbox(c->tx.p, c->ty.p, c->tz.p, m_local, c->tbbox.p, d_bbox, c->stream));
+    float bbox[6];
+    MI_HIP(hipMemcpyAsync(bbox, d_bbox, sizeof bbox, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP(hipStreamSynchronize(c->stream));
+    NnGridView g{};
+    grid_plan(bbox, m_local, c->tune.grid_points_per_cell, &g);
+    const size_t n_cells = (size_t)g.nx * g.ny * g.nz;
+    MI_TRY(c->gpts.reserve((size_t)m_local));
+    MI_TRY(c->gstart.reserve(n_cells + 1));
+    MI_TRY(c->gfill.reserve(n_cells + 1));
+    MI_TRY(c->gscan.reserve((n_cells + 1) / 1024 + 2));
+    g.pts = c->gpts.p;
+    g.cell_start = c->gstart.p;
+    GridBuildArgs a{};
+    a.x = c->tx.p; a.y = c->ty.p; a.z = c->tz.p; a.m = m_local; a.index_base = index_base;
+    a.view = g; a.cell_fill = c->gfill.p; a.scan_tmp = c->gscan.p; a.pts_out = c->gpts.p; a.cell_start_out = c->gstart.p;
+    MI_HIP(grid_build(a, c->stream));
+    c->grid = g;
+    c->grid_valid = true;
     return MI_OK;
 }
 
@@ -424,33 +473,39 @@ static int sort_sources(mi_ctx* c, const float* sx, const float* sy, const float
     return MI_OK;
 }
 
-static int resolve_nn_mode(int nn_mode, int m_local)
+int resolve_nn_mode(const mi_ctx* c, int nn_mode, int m_local)
 {
-    const int forced = env_int("MISLAM_NN_MODE", 0);
-    if (forced == MI_NN_BRUTEFORCE || forced == MI_NN_TREE) nn_mode = forced;
-    if (nn_mode == MI_NN_BRUTEFORCE || nn_mode == MI_NN_TREE) return nn_mode;
-    // measured crossover on MI355X (N = M, us per search every-pair / hierarchy): 16 k 62 / 104, 20 k 89 / 103, 24 k 115 / 109,
-    // 28 k 151 / 112, 32 k 195 / 119, 100 k 1650 / 152
-    return m_local >= 24000 ? MI_NN_TREE : MI_NN_BRUTEFORCE;
+    const int forced = c->tune.nn_force_mode;
+    if (forced == MI_NN_BRUTEFORCE || forced == MI_NN_TREE || forced == MI_NN_GRID) nn_mode = forced;
+    if (nn_mode == MI_NN_BRUTEFORCE || nn_mode == MI_NN_TREE || nn_mode == MI_NN_GRID) return nn_mode;
+    // measured crossover on MI355X, every-pair against indexed search (N = M): DESIGN.md K1g
+    return m_local >= MI_NN_INDEX_MIN_POINTS ? MI_NN_GRID : MI_NN_BRUTEFORCE;
 }
 
 extern "C" const char* mi_nn_kernel_name(const mi_ctx* c, int n_moving, int m_fixed_local, int nn_mode)
 {
+    (void)n_moving;
     if (!c) return "";
-    if (resolve_nn_mode(nn_mode, m_fixed_local) != MI_NN_TREE) return "nn_bruteforce_kernel";
-    return nn_tree_kernel_name(n_moving, env_int("MISLAM_TREE_R", 0), true, c->cu_count * 8);
+    const int mode = resolve_nn_mode(c, nn_mode, m_fixed_local);
+    return mode == MI_NN_GRID ? nn_grid_kernel_name(false) : (mode == MI_NN_TREE ? "nn_tree_lane_kernel" : "nn_bruteforce_kernel");
 }
 
-int mislam::launch_nn(mi_ctx* c, const float* sx, const float* sy, const float* sz, int n, int m_local, int index_base, int fma,
+int launch_nn(mi_ctx* c, const float* sx, const float* sy, const float* sz, int n, int m_local, int index_base, int fma,
                       const int* done_flag, int nn_mode)
 {
-    if (resolve_nn_mode(nn_mode, m_local) == MI_NN_TREE) {
+    const int mode = resolve_nn_mode(c, nn_mode, m_local);
+    if (mode == MI_NN_TREE || mode == MI_NN_GRID) {
         MI_TRY(ensure_tree(c, m_local, index_base));
-        MI_TRY(c->twork.reserve(TREE_WORK_COUNTER_WORDS));
+        if (mode == MI_NN_GRID) MI_TRY(ensure_grid(c, m_local, index_base));
         ProfScope ps(c, MI_KERNEL_NN);
-        // resident grid for the dynamically fetching walk: 8 blocks of 4 waves fill a CU's 32 wave slots (17 KB of LDS each)
-        MI_HIP(nn_tree_query(c->tree, sx, sy, sz, n, c->keys.p, done_flag, fma, env_int("MISLAM_TREE_R", 0), c->stream, c->twork.p,
-                             c->cu_count * 8));
+        if (mode == MI_NN_GRID) {
+            GridSearchArgs a{};
+            a.sx = sx; a.sy = sy; a.sz = sz; a.done_flag = done_flag; a.n = n; a.keys = c->keys.p;
+            a.stats = c->nn_stats_on ? c->nn_stats.p : nullptr;
+            MI_HIP(nn_grid_query(c->grid, c->tree, a, fma, c->stream));
+        } else {
+            MI_HIP(nn_tree_query(c->tree, sx, sy, sz, n, c->keys.p, done_flag, fma, c->stream));
+        }
         return MI_OK;
     }
     const NnPlan p = plan_nn(c, n, m_local);
@@ -485,10 +540,11 @@ static int allreduce_doubles(mi_ctx* c, double* dev_ptr, int count) { return all
 static void shard_range(int m_total, int rank, int world, int* lo, int* hi) { (void)mi_shard_range(m_total, rank, world, lo, hi); }
 
 // Uploads this rank's shard of the fixed cloud (SoA streams for K1 + float4 for gathers).
-int mislam::upload_target_shard(mi_ctx* c, const float* after_xyz, int m_total, bool replicate)
+int upload_target_shard(mi_ctx* c, const float* after_xyz, int m_total, bool replicate)
 {
     c->m_total = m_total;
-    c->tree_valid = false;   // the hierarchy indexes the previous shard
+    c->tree_valid = false;   // the indexes cover the previous shard
+    c->grid_valid = false;
     if (replicate) { c->shard_lo = 0; c->shard_hi = m_total; }      // source-sharded: every rank holds the whole fixed cloud
     else shard_range(m_total, c->rank, c->world, &c->shard_lo, &c->shard_hi);
     const int m_local = c->shard_hi - c->shard_lo;
@@ -497,6 +553,18 @@ int mislam::upload_target_shard(mi_ctx* c, const float* after_xyz, int m_total, 
     MI_TRY(c->tgt4.reserve(len));
     if (m_local > 0)
         MI_TRY(upload_soa(c, after_xyz + 3 * (size_t)c->shard_lo, m_local, (int)len, c->tx.p, c->ty.p, c->tz.p, c->tgt4.p));
+    return MI_OK;
+}
+
+// rows of partial sums for the loaded moving cloud (icp_rows.hpp) + the reduced rows
+static int reserve_rows(mi_ctx* c)
+{
+    const size_t rows = (size_t)icp_row_count(c->n_pad) * (ICP_MOMENTS + ICP_ERRSUMS);
+    if (rows > c->rows.cap) {
+        MI_TRY(c->rows.reserve(rows));
+        MI_HIP(hipMemsetAsync(c->rows.p, 0, sizeof(double) * c->rows.cap, c->stream));   // columns a path never writes stay finite
+    }
+    MI_TRY(c->rows_reduced.reserve((size_t)64 * (ICP_MOMENTS + ICP_ERRSUMS)));
     return MI_OK;
 }
 
@@ -564,7 +632,7 @@ static int icp_check_params(const mi_icp_params* p)
     if (p->dist_mode != MI_DIST_CPU_ROUNDING && p->dist_mode != MI_DIST_FMA) { set_error("ICP: bad dist_mode %d", p->dist_mode); return MI_ERR_INVALID_ARG; }
     if (p->compose_mode != MI_COMPOSE_CPU_ADDITIVE && p->compose_mode != MI_COMPOSE_EXACT) { set_error("ICP: bad compose_mode %d", p->compose_mode); return MI_ERR_INVALID_ARG; }
     if (p->max_iterations < -1) { set_error("ICP: max_iterations %d (use -1 for unbounded)", p->max_iterations); return MI_ERR_INVALID_ARG; }
-    if (p->nn_mode != MI_NN_AUTO && p->nn_mode != MI_NN_BRUTEFORCE && p->nn_mode != MI_NN_TREE) { set_error("ICP: bad nn_mode %d", p->nn_mode); return MI_ERR_INVALID_ARG; }
+    if (p->nn_mode != MI_NN_AUTO && p->nn_mode != MI_NN_BRUTEFORCE && p->nn_mode != MI_NN_TREE && p->nn_mode != MI_NN_GRID) { set_error("ICP: bad nn_mode %d", p->nn_mode); return MI_ERR_INVALID_ARG; }
     if (p->shard_mode != MI_SHARD_AUTO && p->shard_mode != MI_SHARD_TARGET && p->shard_mode != MI_SHARD_SOURCE) { set_error("ICP: bad shard_mode %d", p->shard_mode); return MI_ERR_INVALID_ARG; }
     if (p->sum_mode != MI_SUM_EXACT && p->sum_mode != MI_SUM_CPU_SEQUENTIAL) { set_error("ICP: bad sum_mode %d", p->sum_mode); return MI_ERR_INVALID_ARG; }
     return MI_OK;
@@ -604,8 +672,8 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
     c->source_sharded = false;
     if (c->distributed()) {   // (a one-rank communicator takes the same path: that is what the single-GPU box can test)
         const int per_rank = n_after / c->world;
-        const bool tree = resolve_nn_mode(params->nn_mode, params->shard_mode == MI_SHARD_TARGET ? per_rank : n_after) == MI_NN_TREE;
-        c->source_sharded = params->shard_mode == MI_SHARD_SOURCE || (params->shard_mode == MI_SHARD_AUTO && tree);
+        const bool indexed = resolve_nn_mode(c, params->nn_mode, params->shard_mode == MI_SHARD_TARGET ? per_rank : n_after) != MI_NN_BRUTEFORCE;
+        c->source_sharded = params->shard_mode == MI_SHARD_SOURCE || (params->shard_mode == MI_SHARD_AUTO && indexed);
     }
     if (c->source_sharded) {
         int slo = 0, shi = 0;
@@ -619,8 +687,7 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
     MI_TRY(c->bx.reserve(np)); MI_TRY(c->by.reserve(np)); MI_TRY(c->bz.reserve(np));
     MI_TRY(c->cx.reserve(np)); MI_TRY(c->cy.reserve(np)); MI_TRY(c->cz.reserve(np));
     MI_TRY(c->keys.reserve(np));
-    MI_TRY(c->part_mom.reserve((size_t)ICP_MAX_PARTIAL_BLOCKS * ICP_MOMENTS));
-    MI_TRY(c->part_err.reserve((size_t)ICP_MAX_PARTIAL_BLOCKS * ICP_ERRSUMS));
+    MI_TRY(reserve_rows(c));
     // moving cloud: upload in the caller's order (cx.. as scratch), keep it Morton-sorted in bx..
     MI_TRY(upload_soa(c, before_xyz, n_before, c->n_pad, c->cx.p, c->cy.p, c->cz.p, nullptr));
     MI_TRY(sort_sources(c, c->cx.p, c->cy.p, c->cz.p, n_before, c->n_pad, c->bx.p, c->by.p, c->bz.p));
@@ -630,11 +697,19 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
         MI_HIP(invert_order(c->sorder.p, n_before, c->sinv.p, c->stream));
     }
     MI_TRY(upload_target_shard(c, after_xyz, n_after, c->source_sharded));
+    // The grid search carries the whole O(N) part of the iteration (nn_grid.hip) unless a stand-alone step has to come between
+    // the search and the sums: the key all-reduce of a sharded fixed cloud, or cpu-slam's sequential running sums.
+    const int m_local = c->shard_hi - c->shard_lo;
+    const int mode = resolve_nn_mode(c, params->nn_mode, m_local);
+    c->fused = mode == MI_NN_GRID && (!c->distributed() || c->source_sharded) && params->sum_mode == MI_SUM_EXACT;
+    if (mode != MI_NN_BRUTEFORCE) {          // build the indexes now, not inside the first timed iteration
+        MI_TRY(ensure_tree(c, m_local, c->shard_lo));
+        if (mode == MI_NN_GRID) MI_TRY(ensure_grid(c, m_local, c->shard_lo));
+    }
     c->icp_loaded = true;
     return mi_icp_reset(c);
 }
 
-// One loop body of basicicp.cpp:32-57 / icpcuda.cu:31-54, enqueued without host synchronisation.
 static IcpRules icp_rules(const mi_ctx* c)
 {
     IcpRules rules{};
@@ -647,52 +722,74 @@ static IcpRules icp_rules(const mi_ctx* c)
     return rules;
 }
 
-// Multi-GPU: the error sums of the last enqueued iteration are still waiting for their all-reduce (they normally travel with the
-// next iteration's moments).  Called when the host stops enqueuing and wants the state.
+// The error sums of the last enqueued iteration have not been turned into its stop rule yet (they normally ride with the next
+// iteration's moments).  Called when the host stops enqueuing and wants the state.
 static int icp_flush_pending(mi_ctx* c)
 {
-    if (!c->distributed()) return MI_OK;
+    const IcpView v = make_view(c);
+    const int nrows = icp_row_count(c->n);
+    const int reduced = icp_reduced_count(nrows);
+    // fused path: nobody has evaluated the last applied transform yet -- the next search would have
+    if (c->fused) { ProfScope ps(c, MI_KERNEL_TRANSFORM); MI_HIP(icp_transform_error_rows(v, c->rows.p, 0, c->stream)); }
     ProfScope ps(c, MI_KERNEL_FINALIZE);
-    MI_TRY(allreduce_doubles(c, c->d_state->err, ICP_ERRSUMS));
-    MI_HIP(icp_finalize_pending(c->d_state, icp_rules(c), c->stream));
+    MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream));
+    if (c->distributed()) {
+        MI_HIP(icp_rows_to_state(c->d_state, c->rows_reduced.p, reduced, 2, c->stream));
+        MI_TRY(allreduce_doubles(c, c->d_state->err, ICP_ERRSUMS));
+        MI_HIP(icp_finalize_pending(c->d_state, nullptr, 0, icp_rules(c), c->stream));
+    } else {
+        MI_HIP(icp_finalize_pending(c->d_state, c->rows_reduced.p, reduced, icp_rules(c), c->stream));
+    }
     return MI_OK;
 }
 
+// One loop body of basicicp.cpp:32-57 / icpcuda.cu:31-54, enqueued without host synchronisation.  Three launches on the
+// default path: fused search (transform, previous error, search, moments) -> rows reduce -> solve (previous stop rule, Kabsch,
+// compose).
 static int icp_enqueue_iteration(mi_ctx* c)
 {
     const IcpView v = make_view(c);
     const int m_local = c->shard_hi - c->shard_lo;
-    const int nb = icp_reduce_blocks(c->n);
-    const int nbp = icp_reduce_blocks(c->n_pad);
     const IcpRules rules = icp_rules(c);
-    // K1 (+ C1)
-    MI_TRY(launch_nn(c, c->cx.p, c->cy.p, c->cz.p, c->n, m_local, c->shard_lo, v.fma, &c->d_state->done, c->icp.nn_mode));
-    if (!c->source_sharded) MI_TRY(allreduce_keys(c, c->n));   // source-sharded ranks hold disjoint moving points: nothing to merge
-    // K2, K3
+    const int nrows = icp_row_count(c->n);
+    const int reduced = icp_reduced_count(nrows);
     const int seq = c->icp.sum_mode == MI_SUM_CPU_SEQUENTIAL;
-    { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_moments(v, c->part_mom.p, nb, c->stream)); }
-    if (seq) { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_seq_centroids(v, c->stream)); }
-    if (c->distributed()) {
-        // ONE all-reduce per iteration: this iteration's 16 moments and the previous iteration's 2 error sums (contiguous in the
-        // state block); the solve kernel first settles the previous iteration's stop rule (kernels.h)
-        static_assert(offsetof(IcpState, err) == offsetof(IcpState, mom) + sizeof(double) * ICP_MOMENTS, "mom and err must be contiguous");
-        ProfScope ps(c, MI_KERNEL_SOLVE);
-        MI_HIP(icp_reduce_moments(c->d_state, c->part_mom.p, nb, c->stream));
-        MI_TRY(allreduce_doubles(c, c->d_state->mom, ICP_MOMENTS + ICP_ERRSUMS));
-        MI_HIP(icp_solve_deferred(c->d_state, c->icp.compose_mode, rules, c->stream));
+    if (c->fused) {
+        GridSearchArgs a{};
+        a.n = c->n; a.keys = c->keys.p;
+        a.stats = c->nn_stats_on ? c->nn_stats.p : nullptr;
+        a.state = c->d_state;
+        a.bx = c->bx.p; a.by = c->by.p; a.bz = c->bz.p;
+        a.tgt4 = c->tgt4.p; a.shard_lo = c->shard_lo; a.shard_hi = c->shard_hi;
+        a.filter_pairs = c->icp.filter_pairs; a.max_distance_squared = c->icp.max_distance_squared;
+        a.rows = c->rows.p;
+        ProfScope ps(c, MI_KERNEL_NN);
+        MI_HIP(nn_grid_query(c->grid, c->tree, a, v.fma, c->stream));
     } else {
-        ProfScope ps(c, MI_KERNEL_SOLVE);
-        MI_HIP(icp_solve(c->d_state, c->part_mom.p, nb, c->icp.compose_mode, seq, c->stream));
+        // K1 (+ C1), K2
+        MI_TRY(launch_nn(c, c->cx.p, c->cy.p, c->cz.p, c->n, m_local, c->shard_lo, v.fma, &c->d_state->done, c->icp.nn_mode));
+        if (!c->source_sharded) MI_TRY(allreduce_keys(c, c->n));   // source-sharded ranks hold disjoint moving points: nothing to merge
+        { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_moments_rows(v, c->rows.p, c->stream)); }
+        if (seq) { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_seq_centroids(v, c->stream)); }
     }
-    // K4+K5, K6
-    { ProfScope ps(c, MI_KERNEL_TRANSFORM); MI_HIP(icp_transform_error(v, c->part_err.p, nbp, 2, c->stream)); }
-    if (seq) { ProfScope ps(c, MI_KERNEL_TRANSFORM); MI_HIP(icp_seq_error(v, c->stream)); }
-    if (c->distributed()) {
-        ProfScope ps(c, MI_KERNEL_FINALIZE);
-        MI_HIP(icp_post_error(c->d_state, c->part_err.p, nbp, c->stream));      // stays local until the next all-reduce (or the flush)
-    } else {
-        ProfScope ps(c, MI_KERNEL_FINALIZE);
-        MI_HIP(icp_finalize(c->d_state, c->part_err.p, nbp, rules, c->stream));
+    {   // K3 (+ K6 of the previous iteration)
+        ProfScope ps(c, MI_KERNEL_SOLVE);
+        MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream));
+        if (c->distributed()) {
+            // ONE all-reduce per iteration: this iteration's 16 moments and the previous iteration's 2 error sums (contiguous in
+            // the state block)
+            static_assert(offsetof(IcpState, err) == offsetof(IcpState, mom) + sizeof(double) * ICP_MOMENTS, "mom and err must be contiguous");
+            MI_HIP(icp_rows_to_state(c->d_state, c->rows_reduced.p, reduced, 3, c->stream));
+            MI_TRY(allreduce_doubles(c, c->d_state->mom, ICP_MOMENTS + ICP_ERRSUMS));
+            MI_HIP(icp_solve_deferred(c->d_state, nullptr, 0, c->icp.compose_mode, rules, 1, c->stream));
+        } else {
+            MI_HIP(icp_solve_deferred(c->d_state, c->rows_reduced.p, reduced, c->icp.compose_mode, rules, 1, c->stream));
+        }
+    }
+    if (!c->fused) {
+        // K4+K5: its error sums wait in the rows for the next solve (or the flush)
+        { ProfScope ps(c, MI_KERNEL_TRANSFORM); MI_HIP(icp_transform_error_rows(v, c->rows.p, 2, c->stream)); }
+        if (seq) { ProfScope ps(c, MI_KERNEL_TRANSFORM); MI_HIP(icp_seq_error(v, c->stream)); }
     }
     return MI_OK;
 }
@@ -713,12 +810,13 @@ extern "C" int mi_icp_run(mi_ctx* c, int max_new_iterations, int* iterations_don
     int batch = c->icp.sync_every;
     if (batch <= 0) {
         // auto: a long iteration dwarfs a host round trip (check after each one); short ones are launch-bound (batch them).
-        // Estimated from the measured rates: every-pair ~7e12 pairs/s, box hierarchy ~2 ns per moving point.
+        // Estimated from the measured rates: every-pair ~7e12 pairs/s, indexed searches ~5e-11 s per moving point + launches.
         const int m_local = c->shard_hi - c->shard_lo;
-        const bool tree = resolve_nn_mode(c->icp.nn_mode, m_local) == MI_NN_TREE;
-        const double est_s = tree ? 2e-9 * (double)c->n : (double)c->n * (double)m_local / 7e12;
-        batch = est_s >= 5e-3 ? 1 : (est_s >= 2e-4 ? 4 : 8);
+        const bool brute = resolve_nn_mode(c, c->icp.nn_mode, m_local) == MI_NN_BRUTEFORCE;
+        const double est_s = brute ? (double)c->n * (double)m_local / 7e12 : 2e-5 + 5e-11 * (double)c->n;
+        batch = est_s >= 5e-3 ? 1 : (est_s >= 2e-4 ? 4 : (est_s >= 1e-4 ? 8 : 16));
     }
+    if (c->icp.verbose) batch = 1;       // one "loop_nr" line per iteration, like basicicp.cpp:50 / icpcuda.cu:39
     int enqueued = 0;
     while (!c->h_state->done && (max_new_iterations < 0 || enqueued < max_new_iterations)) {
         int todo = batch;
@@ -776,7 +874,7 @@ extern "C" int mi_nn_search_ex(mi_ctx* c, const float* src_xyz, int n, const flo
                                int* idx, float* d2)
 {
     if (!c) { set_error("mi_nn_search: null context"); return MI_ERR_INVALID_ARG; }
-    if (nn_mode != MI_NN_AUTO && nn_mode != MI_NN_BRUTEFORCE && nn_mode != MI_NN_TREE) { set_error("mi_nn_search: bad nn_mode"); return MI_ERR_INVALID_ARG; }
+    if (nn_mode != MI_NN_AUTO && nn_mode != MI_NN_BRUTEFORCE && nn_mode != MI_NN_TREE && nn_mode != MI_NN_GRID) { set_error("mi_nn_search: bad nn_mode"); return MI_ERR_INVALID_ARG; }
     if (n < 0 || m < 0 || (n > 0 && (!src_xyz || !idx)) || (m > 0 && !tgt_xyz)) { set_error("mi_nn_search: bad arguments"); return MI_ERR_INVALID_ARG; }
     if (dist_mode != MI_DIST_CPU_ROUNDING && dist_mode != MI_DIST_FMA) { set_error("mi_nn_search: bad dist_mode"); return MI_ERR_INVALID_ARG; }
     if (n == 0) return MI_OK;
@@ -818,8 +916,7 @@ static int load_pairs(mi_ctx* c, const float* src_xyz, int n, const float* tgt_x
     MI_TRY(c->bx.reserve(np)); MI_TRY(c->by.reserve(np)); MI_TRY(c->bz.reserve(np));
     MI_TRY(c->cx.reserve(np)); MI_TRY(c->cy.reserve(np)); MI_TRY(c->cz.reserve(np));
     MI_TRY(c->keys.reserve(np));
-    MI_TRY(c->part_mom.reserve((size_t)ICP_MAX_PARTIAL_BLOCKS * ICP_MOMENTS));
-    MI_TRY(c->part_err.reserve((size_t)ICP_MAX_PARTIAL_BLOCKS * ICP_ERRSUMS));
+    MI_TRY(reserve_rows(c));
     MI_TRY(upload_soa(c, src_xyz, n, c->n_pad, c->bx.p, c->by.p, c->bz.p, nullptr));
     const size_t bytes = sizeof(float) * np;
     MI_HIP(hipMemcpyAsync(c->cx.p, c->bx.p, bytes, hipMemcpyDeviceToDevice, c->stream));
@@ -852,9 +949,13 @@ extern "C" int mi_kabsch(mi_ctx* c, const float* src_xyz, int n, const float* tg
     MI_TRY(load_pairs(c, src_xyz, n, tgt_xyz, m, idx, keep));
     MI_HIP(hipMemcpyAsync(c->d_state, c->h_state, sizeof(IcpState), hipMemcpyHostToDevice, c->stream));
     const IcpView v = make_view(c);
-    const int nb = icp_reduce_blocks(n);
-    { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_moments(v, c->part_mom.p, nb, c->stream)); }
-    { ProfScope ps(c, MI_KERNEL_SOLVE); MI_HIP(icp_solve(c->d_state, c->part_mom.p, nb, MI_COMPOSE_EXACT, 0, c->stream)); }
+    const int nrows = icp_row_count(n);
+    { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_moments_rows(v, c->rows.p, c->stream)); }
+    {
+        ProfScope ps(c, MI_KERNEL_SOLVE);
+        MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream));
+        MI_HIP(icp_solve_deferred(c->d_state, c->rows_reduced.p, icp_reduced_count(nrows), MI_COMPOSE_EXACT, IcpRules{}, 0, c->stream));
+    }
     MI_TRY(icp_fetch_state(c));
     if (pairs_used) *pairs_used = c->h_state->pairs;
     if (c->h_state->pairs <= 0) { set_error("mi_kabsch: no pair kept"); return MI_ERR_INVALID_ARG; }
@@ -874,9 +975,10 @@ extern "C" int mi_transform_mse(mi_ctx* c, const float* src_xyz, int n, const fl
     memcpy(c->h_state->t, t3, sizeof(float) * 3);
     MI_HIP(hipMemcpyAsync(c->d_state, c->h_state, sizeof(IcpState), hipMemcpyHostToDevice, c->stream));
     const IcpView v = make_view(c);
-    const int nbp = icp_reduce_blocks(c->n_pad);
-    { ProfScope ps(c, MI_KERNEL_TRANSFORM); MI_HIP(icp_transform_error(v, c->part_err.p, nbp, 0, c->stream)); }
-    MI_HIP(icp_reduce_error(c->d_state, c->part_err.p, nbp, c->stream));
+    const int nrows = icp_row_count(n);
+    { ProfScope ps(c, MI_KERNEL_TRANSFORM); MI_HIP(icp_transform_error_rows(v, c->rows.p, 0, c->stream)); }
+    MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream));
+    MI_HIP(icp_rows_to_state(c->d_state, c->rows_reduced.p, icp_reduced_count(nrows), 2, c->stream));
     if (out_xyz) {
         MI_TRY(c->staging.reserve((size_t)3 * n));
         MI_HIP(soa_to_aos(c->cx.p, c->cy.p, c->cz.p, n, c->staging.p, c->stream));

@@ -1,0 +1,67 @@
+// K1g -- exact nearest-neighbour search through a uniform cell grid over the fixed cloud, with the box hierarchy (nn_tree.h) as
+// the in-kernel fallback for the lanes the grid cannot serve cheaply.  The default search since round 2 (nn_grid.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "nn_tree.h"
+
+namespace mislam {
+
+constexpr int GRID_BLOCK = 64;             // moving points per workgroup: one wave = one row of ICP partial sums (icp_rows.hpp)
+constexpr int GRID_MAX_DIM = 1024;         // cells per axis: keeps the rounding of a cell coordinate (2^-23 * 1024) far below the 1e-3 slack
+constexpr float GRID_POINTS_PER_CELL = 2.0f;
+constexpr float GRID_DU_MAX = 2.0f;        // the grid answers queries whose neighbour lies within this many cells; the others walk the hierarchy
+constexpr int GRID_STATS_ROWS = 1024;         // mi_profile_search_stats: the counters are kept in this many copies
+constexpr float GRID_FAR_FACTOR = 2.0f;    // a starting candidate farther than this many times GRID_DU_MAX cells: straight to the hierarchy
+constexpr int GRID_CAND_BUDGET = 640;      // candidates a lane may test in the grid before it walks the hierarchy instead
+
+struct NnGridView {
+    const float4* pts;                     // the m fixed points sorted by cell (row-major: x fastest), w = GLOBAL index bits
+    const unsigned int* cell_start;        // nx*ny*nz + 1 offsets into pts
+    float ox, oy, oz;                      // lower corner of the bounding box
+    float inv_h;                           // cells per unit length; cell coordinate of p on an axis: floor((p - o) * inv_h)
+    float h_lo;                            // a hair less than 1 / inv_h: turns a gap in cells into a safe lower bound in length
+    int nx, ny, nz;
+};
+
+// cell size and counts for a cloud of m points with bounding box bbox[6] (lo xyz, hi xyz); host-side, the same fp32 expression
+// as the device's cell coordinate so that no point lands beyond the last cell
+void grid_plan(const float bbox[6], int m, float points_per_cell, NnGridView* out);
+
+struct GridBuildArgs {
+    const float *x, *y, *z;                // the fixed-cloud shard, SoA
+    int m;
+    int index_base;                        // global index of point 0
+    NnGridView view;                       // planned dims; pts / cell_start are written
+    unsigned int* cell_fill;               // nx*ny*nz scratch words
+    unsigned int* scan_tmp;                // scan scratch: (n_cells + 1) / 1024 + 2 words
+    float4* pts_out;
+    unsigned int* cell_start_out;
+};
+hipError_t grid_build(const GridBuildArgs& a, hipStream_t s);
+
+// What one launch of the search works on.  Plain form: moving points from sx/sy/sz, keys in/out.  Fused ICP form (state != null):
+// the whole O(N) part of an ICP iteration rides with the search -- see nn_grid.hip.
+struct GridSearchArgs {
+    // plain
+    const float *sx, *sy, *sz;
+    const int* done_flag;
+    // both
+    int n;
+    unsigned long long* keys;
+    unsigned long long* stats;             // null, or GRID_STATS_ROWS x 8 counters: candidates tested in the grid, cell rows scanned, lanes that went to
+                                           // the hierarchy, lanes (mi_profile_search_stats)
+    // fused ICP iteration
+    IcpState* state;
+    const float *bx, *by, *bz;             // the ORIGINAL moving cloud (Morton-sorted), SoA
+    const float4* tgt4;                    // fixed cloud as float4, caller's order (local index = global - shard_lo)
+    int shard_lo, shard_hi;
+    int filter_pairs;
+    float max_distance_squared;
+    double* rows;                          // [ceil(n / GRID_BLOCK)][ICP_ROW] partial sums (icp_rows.hpp)
+};
+hipError_t nn_grid_query(const NnGridView& g, const NnTreeView& t, const GridSearchArgs& a, int fma, hipStream_t s);
+const char* nn_grid_kernel_name(bool fused);
+
+}  // namespace mislam

@@ -1,0 +1,446 @@
+// K1g -- EXACT nearest-neighbour search through a uniform cell grid over the fixed cloud, the default search.
+//
+// Same contract as the every-pair K1 (nn_kernel.hip) and therefore as FindCorrespondences (cudacommon.cu:57-77) /
+// common.cpp:446-462: idx[i] = argmin_j |after[j] - before[i]|^2, strict '<', lowest index on ties, the distance evaluated with
+// the same fp32 operation sequence; results are IDENTICAL to the every-pair search bit for bit (the two rules of nn_walk.hpp).
+//
+// Why a grid.  Round 1's box-hierarchy walk spent 0.49 ms per search at N = M = 1e6 on ~325 L1 line accesses per query: every
+// lane chases ~17 levels of dependent, divergent 16-byte loads before it sees its first candidate, although in ICP the answer is
+// almost always within a fraction of a point spacing of the starting candidate (the previous match under the new transform).  A
+// cell grid reaches the candidates in ONE dependent step: cell coordinate = floor((p - origin) / h) is arithmetic, the points of
+// a cell row are contiguous in memory, and a row of cells [ix0, ix1] is one contiguous run pts[cell_start[r + ix0] ..
+// cell_start[r + ix1 + 1]).  A query with search radius r visits the (2r/h + 1)^2 rows its sphere touches and tests
+// ~(2r + h)^3 * density points: 2 offset loads + a short streaming loop per row, all lanes busy with their own candidates.
+//
+// Exactness.  Cell coordinates are compared in "cell units" u = (p - o) * inv_h, the SAME fp32 expression for fixed points (at
+// build) and for queries, and fp32 rounding is monotonic: a point with p_x in [q_x - r, q_x + r] has u in [u(q_x - r), u(q_x + r)].
+// Every rounding on the way is covered by explicit slack: a relative 1e-5 on radii and cell size (>> 2^-22), and 1e-3 cells on
+// every cell-unit quantity (>> 2^-23 * GRID_MAX_DIM, the rounding of u itself).  A row is skipped only if its gap to the query,
+// shrunk by that slack, squared and summed like a distance, is STRICTLY greater than the running best.  Visiting too many cells
+// is harmless (lexicographic minimum), so every slack errs on that side.
+//
+// Fallback.  The grid is cheap while r is a few cells and cells hold a few points.  A lane without a starting candidate yet, far
+// outside the fixed cloud, or in a crowded cell (clustered clouds, a far outlier stretching the bounding box) would test
+// thousands of candidates: it stops instead (nothing within GRID_DU_MAX cells, or GRID_CAND_BUDGET candidates tested), and the
+// lanes of a wave that stopped walk the box hierarchy together (nn_walk.hpp) from their current bests -- real candidates --
+// inside the same launch.  Early ICP iterations are therefore mostly hierarchy walks, the rest mostly grid.
+//
+// Fused ICP iteration (GridSearchArgs::state != null).  The search needs the current position of every moving point and its
+// previous match re-evaluated as starting candidate; the previous iteration's error needs exactly those two things, and the
+// next solve needs the new matches' coordinates, which the search has just touched.  So ONE kernel does, per moving point:
+// cur = R b + t (TransformCloud, cudacommon.cu:132-136; glm operation order) -> e = |a_old - cur|^2 -> error sums of the
+// iteration just applied (GetMeanSquaredError, :138-148) -> search from (e, old match) -> key -> moments of the new pair
+// (LeastSquaresSVD's sums, :168-201) -> one row of partial sums per workgroup (icp_rows.hpp).  The transformed cloud is never
+// written: 20 bytes read + 8 written per moving point besides the search's own traffic.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "icp_rows.hpp"
+#include "kernels.h"
+#include "nn_grid.h"
+#include "nn_walk.hpp"
+
+namespace mislam {
+
+// ---------------------------------------------------------------------------------------------------------------
+// plan + build
+// ---------------------------------------------------------------------------------------------------------------
+// cell coordinate in cell units; the ONE expression used for fixed points, queries and the plan
+__host__ __device__ __forceinline__ float cell_u(float p, float o, float inv_h) { return (p - o) * inv_h; }
+
+void grid_plan(const float bbox[6], int m, float points_per_cell, NnGridView* out)
+{
+    double ext[3];
+    bool active[3];
+    for (int a = 0; a < 3; a++) {
+        ext[a] = (double)bbox[3 + a] - (double)bbox[a];
+        active[a] = ext[a] > 0.0 && std::isfinite(ext[a]);
+    }
+    const double cells = std::max(1.0, (double)m / (double)points_per_cell);
+    double h = 1.0;
+    for (int pass = 0; pass < 4; pass++) {
+        int d = 0;
+        double vol = 1.0;
+        for (int a = 0; a < 3; a++)
+            if (active[a]) { d++; vol *= ext[a]; }
+        if (d == 0) { h = 1.0; break; }
+        h = std::pow(vol / cells, 1.0 / d);
+        bool changed = false;
+        for (int a = 0; a < 3; a++)
+            if (active[a] && ext[a] < h) { active[a] = false; changed = true; }   // a flat axis: one layer of cells, spend them elsewhere
+        if (!changed) break;
+    }
+    double ext_max = 0.0;
+    for (int a = 0; a < 3; a++)
+        if (std::isfinite(ext[a])) ext_max = std::max(ext_max, ext[a]);
+    if (ext_max > 0.0) h = std::max(h, ext_max / (GRID_MAX_DIM - 2));
+    if (!(h > 0.0) || !std::isfinite(h)) h = 1.0;
+    float inv_h = (float)(1.0 / h);
+    int dims[3];
+    for (int tries = 0; tries < 8; tries++) {
+        bool ok = true;
+        for (int a = 0; a < 3; a++) {
+            const float umax = cell_u(bbox[3 + a], bbox[a], inv_h);          // the largest cell coordinate any point can get
+            const int n = std::isfinite(umax) && umax > 0.f ? (int)floorf(umax) + 1 : 1;
+            dims[a] = n;
+            if (n > GRID_MAX_DIM) ok = false;
+        }
+        if (ok) break;
+        inv_h *= 0.5f;
+    }
+    for (int a = 0; a < 3; a++) dims[a] = std::min(std::max(dims[a], 1), GRID_MAX_DIM);
+    out->ox = bbox[0]; out->oy = bbox[1]; out->oz = bbox[2];
+    out->inv_h = inv_h;
+    out->h_lo = (1.0f / inv_h) * (1.0f - 1e-5f);
+    out->nx = dims[0]; out->ny = dims[1]; out->nz = dims[2];
+}
+
+__device__ __forceinline__ int cell_index(float u, int n)
+{
+    return (int)fminf(fmaxf(floorf(u), 0.f), (float)(n - 1));
+}
+
+__device__ __forceinline__ unsigned int cell_of(const NnGridView& g, float x, float y, float z)
+{
+    const int ix = cell_index(cell_u(x, g.ox, g.inv_h), g.nx);
+    const int iy = cell_index(cell_u(y, g.oy, g.inv_h), g.ny);
+    const int iz = cell_index(cell_u(z, g.oz, g.inv_h), g.nz);
+    return ((unsigned int)iz * (unsigned int)g.ny + (unsigned int)iy) * (unsigned int)g.nx + (unsigned int)ix;
+}
+
+__global__ __launch_bounds__(256) void grid_count_kernel(NnGridView g, const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ z, int m, unsigned int* __restrict__ counts)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    atomicAdd(&counts[cell_of(g, x[j], y[j], z[j])], 1u);
+}
+
+// Exclusive prefix sum of n words, 1024 per workgroup, in three small launches (tile sums -> scan of the tile sums -> tiles).
+__global__ __launch_bounds__(256) void scan_tile_sums_kernel(const unsigned int* __restrict__ in, unsigned int n, unsigned int* __restrict__ sums)
+{
+    __shared__ unsigned int s[256];
+    const unsigned int base = blockIdx.x * 1024u + threadIdx.x * 4u;
+    unsigned int v = 0;
+#pragma unroll
+    for (unsigned int k = 0; k < 4; k++) v += base + k < n ? in[base + k] : 0u;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(1024) void scan_sums_kernel(unsigned int* __restrict__ sums, unsigned int count)
+{
+    __shared__ unsigned int s[1024];
+    __shared__ unsigned int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (unsigned int base = 0; base < count; base += 1024u) {
+        const unsigned int i = base + threadIdx.x;
+        const unsigned int v = i < count ? sums[i] : 0u;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (unsigned int off = 1; off < 1024u; off <<= 1) {      // Hillis-Steele inclusive scan
+            const unsigned int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0u;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < count) sums[i] = carry + s[threadIdx.x] - v;      // exclusive
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += s[1023];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_tiles_kernel(const unsigned int* __restrict__ in, unsigned int n, const unsigned int* __restrict__ sums,
+                                                         unsigned int* __restrict__ out, unsigned int* __restrict__ out_copy)
+{
+    __shared__ unsigned int s[256];
+    const unsigned int base = blockIdx.x * 1024u + threadIdx.x * 4u;
+    unsigned int v[4], tot = 0;
+#pragma unroll
+    for (unsigned int k = 0; k < 4; k++) { v[k] = base + k < n ? in[base + k] : 0u; tot += v[k]; }
+    s[threadIdx.x] = tot;
+    __syncthreads();
+    for (unsigned int off = 1; off < 256u; off <<= 1) {
+        const unsigned int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    unsigned int run = sums[blockIdx.x] + s[threadIdx.x] - tot;
+#pragma unroll
+    for (unsigned int k = 0; k < 4; k++) {
+        if (base + k < n) {
+            out[base + k] = run;
+            if (out_copy != nullptr) out_copy[base + k] = run;
+        }
+        run += v[k];
+    }
+}
+
+// Places point j in its cell's run.  The order inside a cell is whatever the atomics make it -- irrelevant to the result: the
+// search takes a lexicographic (distance, GLOBAL index) minimum.
+__global__ __launch_bounds__(256) void grid_scatter_kernel(NnGridView g, const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ z, int m, int index_base, unsigned int* __restrict__ fill,
+                                                           float4* __restrict__ pts)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const float px = x[j], py = y[j], pz = z[j];
+    const unsigned int pos = atomicAdd(&fill[cell_of(g, px, py, pz)], 1u);
+    pts[pos] = make_float4(px, py, pz, __int_as_float(j + index_base));
+}
+
+hipError_t grid_build(const GridBuildArgs& a, hipStream_t s)
+{
+    const NnGridView& g = a.view;
+    const unsigned int n_cells = (unsigned int)g.nx * (unsigned int)g.ny * (unsigned int)g.nz;
+    const unsigned int n_scan = n_cells + 1u;                    // the last entry becomes m
+    hipError_t e = hipMemsetAsync(a.cell_fill, 0, sizeof(unsigned int) * (size_t)n_scan, s);
+    if (e != hipSuccess) return e;
+    const int pb = (a.m + 255) / 256;
+    hipLaunchKernelGGL(grid_count_kernel, dim3(pb), dim3(256), 0, s, g, a.x, a.y, a.z, a.m, a.cell_fill);
+    const unsigned int tiles = (n_scan + 1023u) / 1024u;
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(tiles), dim3(256), 0, s, a.cell_fill, n_scan, a.scan_tmp);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, a.scan_tmp, tiles);
+    // counts -> offsets, in place in cell_fill (the scatter's running cursors) and copied to cell_start
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(256), 0, s, a.cell_fill, n_scan, a.scan_tmp, a.cell_fill, a.cell_start_out);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(pb), dim3(256), 0, s, g, a.x, a.y, a.z, a.m, a.index_base, a.cell_fill, a.pts_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// query
+// ---------------------------------------------------------------------------------------------------------------
+// gap, in cells, between cell coordinate u and the slab [i, i+1) of cells, shrunk by the slack: a lower bound
+__device__ __forceinline__ float gap_cells(float u, int i)
+{
+    const float lo = (float)i;
+    return fmaxf(fmaxf(lo - u, u - (lo + 1.f)) - 1e-3f, 0.f);
+}
+
+// k = 0, 1, 2, 3, 4 ... -> 0, -1, +1, -2, +2 ...: slabs in the order of their distance from the query's own
+__device__ __forceinline__ int centre_out(int k) { return (k & 1) ? -((k + 1) >> 1) : (k >> 1); }
+
+// Grid part of one lane's search.  Returns true if the lane gave up (it must then walk the hierarchy from (best, bidx)).
+//
+// The lane scans the cells within r2 = min(best, cap2) of the query, nearest slabs first, so that `best` -- and with it r2 --
+// shrinks at once and the outer rows are pruned with a realistic radius whatever the starting candidate was worth.  Every point
+// with d <= the FINAL r2 is met: r2 only shrinks, and each row's test and x-range use an r2 that is at least the final one.  So
+// if the final best is within cap2 the answer is exact; otherwise (nothing near: the query lies outside the fixed cloud, or has
+// no starting candidate and sits in an empty region) the lane gives up.  cap2 is the square of GRID_DU_MAX cells.
+// The row loops run in LOCKSTEP over the wave (k-th nearest slab of each lane's own position, a wave-uniform counter): a row
+// that no lane needs costs a ballot, not a trip, and a row's points are fetched four at a time.
+template <bool FMA, bool STATS>
+__device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3], float& best, unsigned int& bidx, unsigned int& n_cand,
+                                            unsigned int& n_rows)
+{
+    const float4* __restrict__ pts = g.pts;
+    const unsigned int* __restrict__ cell_start = g.cell_start;
+    const float u0 = cell_u(q[0], g.ox, g.inv_h), u1 = cell_u(q[1], g.oy, g.inv_h), u2 = cell_u(q[2], g.oz, g.inv_h);
+    const float cap = (GRID_DU_MAX - 2e-3f) * g.h_lo;          // every point within `cap` of the query lies within GRID_DU_MAX cells
+    const float cap2 = cap * cap * (1.f - 1e-5f);
+    // A starting candidate far beyond the grid's reach says the query lies well outside the fixed cloud (or its neighbourhood is
+    // empty): scanning (2 GRID_DU_MAX + 1)^2 mostly empty rows first would only delay the walk.  Speed only -- the walk is exact.
+    bool alive = !(best < __builtin_inff() && best > cap2 * (GRID_FAR_FACTOR * GRID_FAR_FACTOR));
+    // the query's own slabs, clamped into the grid (a query outside the grid starts from the nearest boundary slab)
+    const int cy = cell_index(u1, g.ny), cz = cell_index(u2, g.nz);
+    constexpr int SPAN = 2 * (int)GRID_DU_MAX + 3;             // slabs per axis that can lie within GRID_DU_MAX cells
+    int budget = GRID_CAND_BUDGET;
+    for (int kz = 0; kz < SPAN; kz++) {
+        const int iz = cz + centre_out(kz);
+        const float gz = gap_cells(u2, iz) * g.h_lo;
+        const bool zok = alive && iz >= 0 && iz < g.nz && gz * gz <= fminf(best, cap2);
+        if (__builtin_amdgcn_ballot_w64(zok) == 0ull) continue;
+        for (int ky = 0; ky < SPAN; ky++) {
+            const int iy = cy + centre_out(ky);
+            const float gy = gap_cells(u1, iy) * g.h_lo;
+            const float g2 = gy * gy + gz * gz;
+            const float r2 = fminf(best, cap2);
+            // a row is skipped only if it is strictly farther than the search radius: then it cannot win or tie
+            const float rem = fmaxf(r2 * 1.000001f - g2, 0.f);
+            const float dux = __builtin_sqrtf(rem) * g.inv_h * 1.00001f + 1e-3f;
+            const float flo = floorf(u0 - dux), fhi = floorf(u0 + dux);
+            const bool ok = zok && alive && iy >= 0 && iy < g.ny && g2 <= r2 && fhi >= 0.f && flo <= (float)(g.nx - 1);
+            if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
+            unsigned int s = 0u, e = 0u;
+            if (ok) {
+                const int x0 = (int)fmaxf(flo, 0.f), x1 = (int)fminf(fhi, (float)(g.nx - 1));
+                const unsigned int rb = ((unsigned int)iz * (unsigned int)g.ny + (unsigned int)iy) * (unsigned int)g.nx;
+                s = cell_start[rb + x0];
+                e = cell_start[rb + x1 + 1];
+                if (e - s > (unsigned int)budget) { alive = false; e = s; }   // crowded: give up, the hierarchy takes over
+                budget -= (int)(e - s);
+                if (STATS) n_rows += 1;
+            }
+            for (unsigned int p = s; p < e; p += 4) {
+                // four points per trip; past the end the last point is fetched again (testing a candidate twice changes nothing)
+                const unsigned int last = e - 1;
+                const float4 cs[4] = {pts[p], pts[min(p + 1, last)], pts[min(p + 2, last)], pts[min(p + 3, last)]};
+#pragma unroll
+                for (int j4 = 0; j4 < 4; j4++) {
+                    const float d = sq3<FMA>(cs[j4].x - q[0], cs[j4].y - q[1], cs[j4].z - q[2]);
+                    const unsigned int j = __float_as_uint(cs[j4].w);
+                    const bool better = (d < best) | ((d == best) & (j < bidx));
+                    best = better ? d : best;
+                    bidx = better ? j : bidx;
+                }
+            }
+        }
+    }
+    if (STATS) n_cand += (unsigned int)(GRID_CAND_BUDGET - budget);
+    return !alive || !(best <= cap2);
+}
+
+// One wave per workgroup, one lane per moving point: a wave's 64 Morton neighbours share cells and cache lines, and nothing has
+// to be exchanged between waves -- the lanes that give up walk the hierarchy TOGETHER right where they are (tree_walk_wave takes
+// any subset of a wave), the others wait masked off.
+template <bool FMA, bool FUSED, bool STATS>
+__global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTreeView t, GridSearchArgs a)
+{
+    static_assert(GRID_BLOCK == 64 && ICP_ROW_POINTS == 64, "one wave = one workgroup = one row of partial sums");
+    if (FUSED) {
+        if (a.state->done != 0) return;
+    } else if (a.done_flag != nullptr && *a.done_flag != 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* st_lb = reinterpret_cast<float*>(smem);             // hierarchy walk: (height + 1) bounds per lane
+
+    const int tid = (int)threadIdx.x;
+    const unsigned int chunk = xcd_chunk(blockIdx.x, gridDim.x, TREE_XCD_CHUNKS * (256 / GRID_BLOCK));
+    const int i = (int)(chunk * GRID_BLOCK) + tid;
+    const bool valid = i < a.n;
+
+    float q[3] = {0.f, 0.f, 0.f};
+    float best = __builtin_inff();
+    unsigned int bidx = 0u;
+    double e0 = 0.0, e1 = 0.0;
+    if (FUSED) {
+        float R[9], tr[3];
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = a.state->R[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) tr[k] = a.state->t[k];
+        if (valid) {
+            const float x = a.bx[i], y = a.by[i], z = a.bz[i];
+            // TransformPoint: (rotationMatrix * point) + translationVector  (common.cpp:45-49), glm operation order
+            q[0] = ((R[0] * x + R[3] * y) + R[6] * z) + tr[0];
+            q[1] = ((R[1] * x + R[4] * y) + R[7] * z) + tr[1];
+            q[2] = ((R[2] * x + R[5] * y) + R[8] * z) + tr[2];
+            const unsigned long long key = a.keys[i];
+            const int gidx = (int)(unsigned int)(key & 0xffffffffull);
+            const float d2 = __uint_as_float((unsigned int)(key >> 32));
+            if (gidx >= a.shard_lo && gidx < a.shard_hi) {      // there is a previous match (KEY_INIT carries index -1)
+                const float4 p = a.tgt4[gidx - a.shard_lo];
+                const float dx = p.x - q[0], dy = p.y - q[1], dz = p.z - q[2];
+                const float e = (dx * dx + dy * dy) + dz * dz;   // diff.LengthSquared(), common.cpp:264-265
+                const bool kept = a.filter_pairs ? (d2 < a.max_distance_squared) : true;
+                if (kept) { e0 = (double)e; e1 = 1.0; }
+                // the old match under the new transform is a real candidate, evaluated with the search's own arithmetic
+                best = FMA ? __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) : e;
+                bidx = (unsigned int)gidx;
+            }
+        }
+    } else if (valid) {
+        q[0] = a.sx[i]; q[1] = a.sy[i]; q[2] = a.sz[i];
+        unpack_start(a.keys[i], best, bidx);
+    }
+
+    bool hard = false;
+    unsigned long long walk_cycles = 0;
+    unsigned int n_cand = 0u, n_rows = 0u, n_nodes = 0u, n_leaves = 0u;
+    if (valid) hard = grid_search<FMA, STATS>(g, q, best, bidx, n_cand, n_rows);
+    const bool walked = __builtin_amdgcn_ballot_w64(hard) != 0ull;
+#ifndef MISLAM_DEV_SKIP_WALK          // timing experiments only (tools/build_variant.sh): wrong answers for the lanes concerned
+    if (hard) {
+#ifdef MISLAM_DEV_WALK_CLOCK
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+        tree_walk_wave<FMA, STATS>(t, q, best, bidx, st_lb, GRID_BLOCK, tid, n_nodes, n_leaves);
+#ifdef MISLAM_DEV_WALK_CLOCK
+        walk_cycles = __builtin_amdgcn_s_memtime() - t0;
+#endif
+    }
+#endif
+    if (valid && best < __builtin_inff()) a.keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
+    // measurement hook (mi_profile_search_stats).  Kept BEHIND the walk: a global atomic ahead of it would stop the compiler from
+    // using scalar loads for the hierarchy (it can no longer prove those arrays unwritten)
+    if (STATS) {
+        // spread over GRID_STATS_ROWS rows of 8 counters (64 bytes apart): atomics on one line serialise at ~10 ns each
+        unsigned long long* srow = a.stats + (size_t)(blockIdx.x % GRID_STATS_ROWS) * 8;
+        unsigned int c0 = valid ? n_cand : 0u, c1 = valid ? n_rows : 0u;
+        unsigned int v0 = hard ? n_nodes : 0u, v1 = hard ? n_leaves : 0u;
+        unsigned long long wc = hard ? walk_cycles : 0ull;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+            c0 += __shfl_xor(c0, m, 64); c1 += __shfl_xor(c1, m, 64);
+            v0 = max(v0, (unsigned int)__shfl_xor(v0, m, 64)); v1 = max(v1, (unsigned int)__shfl_xor(v1, m, 64));
+            wc = max(wc, (unsigned long long)__shfl_xor(wc, m, 64));
+        }
+        const unsigned long long nh = __builtin_popcountll(__builtin_amdgcn_ballot_w64(hard)), nv = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid));
+        if (tid == 0) {                                         // one set of atomics per wave
+            atomicAdd(&srow[0], (unsigned long long)c0);
+            atomicAdd(&srow[1], (unsigned long long)c1);
+            atomicAdd(&srow[2], nh);
+            atomicAdd(&srow[3], nv);
+            if (walked) {                                       // hierarchy nodes and leaves visited, waves walking
+                atomicAdd(&srow[4], (unsigned long long)v0);
+                atomicAdd(&srow[5], (unsigned long long)v1);
+                atomicAdd(&srow[6], 1ull);
+                atomicAdd(&srow[7], wc);
+            }
+        }
+    }
+    if (FUSED) {
+        double mom[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) mom[k] = 0.0;
+        if (valid && best < __builtin_inff()) {
+            const int gidx = (int)bidx;
+            const bool mine = gidx >= a.shard_lo && gidx < a.shard_hi;
+            const bool kept = a.filter_pairs ? (best < a.max_distance_squared) : true;
+            if (mine && kept) {
+                const float4 p = a.tgt4[gidx - a.shard_lo];
+                pair_moments(mom, q[0], q[1], q[2], p.x, p.y, p.z);
+            }
+        }
+        double* row = a.rows + (size_t)chunk * ICP_ROW;
+        row_store_moments(mom, row, nullptr);
+        row_store_error(e0, e1, row, nullptr);
+    }
+}
+
+const char* nn_grid_kernel_name(bool) { return "nn_grid_kernel"; }
+
+hipError_t nn_grid_query(const NnGridView& g, const NnTreeView& t, const GridSearchArgs& a, int fma, hipStream_t s)
+{
+    if (a.n <= 0) return hipSuccess;
+    const dim3 grid((a.n + GRID_BLOCK - 1) / GRID_BLOCK), block(GRID_BLOCK);
+    const size_t lds = (size_t)(t.height + 1) * GRID_BLOCK * sizeof(float);
+    const bool fused = a.state != nullptr;
+#define MI_GRID_LAUNCH(F, U, S) hipLaunchKernelGGL((nn_grid_kernel<F, U, S>), grid, block, lds, s, g, t, a)
+    if (a.stats != nullptr) {          // counting build of the same kernel (mi_profile_search_stats)
+        if (fused) { if (fma) MI_GRID_LAUNCH(true, true, true); else MI_GRID_LAUNCH(false, true, true); }
+        else { if (fma) MI_GRID_LAUNCH(true, false, true); else MI_GRID_LAUNCH(false, false, true); }
+    } else {
+        if (fused) { if (fma) MI_GRID_LAUNCH(true, true, false); else MI_GRID_LAUNCH(false, true, false); }
+        else { if (fma) MI_GRID_LAUNCH(true, false, false); else MI_GRID_LAUNCH(false, false, false); }
+    }
+#undef MI_GRID_LAUNCH
+    return hipGetLastError();
+}
+
+__global__ void preload_nn_grid_kernel() {}
+hipError_t preload_nn_grid()
+{
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(preload_nn_grid_kernel));
+}
+
+}  // namespace mislam

@@ -49,10 +49,13 @@ enum {
 /* Execution strategy of the nearest-neighbour search.  Every mode returns the SAME idx[] and d2[] bit for bit (strict '<',
  * lowest index on ties, same fp32 arithmetic); they differ only in how many candidate pairs are evaluated. */
 enum {
-    MI_NN_AUTO = 0,         /* box hierarchy for fixed clouds of >= 24000 points per GPU, every pair below (measured crossover at N = M) */
+    MI_NN_AUTO = 0,         /* cell grid for fixed clouds of >= MI_NN_INDEX_MIN_POINTS points per GPU, every pair below (measured crossover at N = M) */
     MI_NN_BRUTEFORCE = 1,   /* every pair, like FindCorrespondences (cudacommon.cu:57-77): N*M distance evaluations */
-    MI_NN_TREE = 2          /* exact search through a box hierarchy over the Morton-sorted fixed cloud */
+    MI_NN_TREE = 2,         /* exact search through a box hierarchy over the Morton-sorted fixed cloud */
+    MI_NN_GRID = 3          /* exact search through a uniform cell grid over the fixed cloud; lanes the grid cannot serve cheaply
+                               (no starting candidate, far outliers, crowded cells) walk the box hierarchy inside the same launch */
 };
+#define MI_NN_INDEX_MIN_POINTS 24000
 
 /* What a multi-GPU context (mi_ctx_create_dist) splits across its ranks.  Same registration result either way.
  *   TARGET: rank r owns fixed points [M*r/W, M*(r+1)/W) and ALL moving points; one ncclAllReduce(ncclUint64, ncclMin) of the
@@ -378,6 +381,11 @@ int mi_profile_select(mi_ctx* ctx, unsigned int kernel_mask);
 int mi_profile_reset(mi_ctx* ctx);
 /* total_ms = sum of event-timed durations of that kernel since the last reset; launches = how many. */
 int mi_profile_get(mi_ctx* ctx, int kernel, double* total_ms, long long* launches);
+/* Work counters of the cell-grid search (MI_NN_GRID), summed over its launches while enabled: out[0] candidates tested in the
+ * grid, out[1] cell rows scanned, out[2] moving points that went on to the box hierarchy, out[3] moving points searched, out[4]
+ * hierarchy nodes and out[5] leaves visited by out[6] walking waves, out[7] reserved.
+ * enable != 0 starts counting (and zeroes the counters), 0 stops; out may be NULL.  Costs four atomics per moving point while on. */
+int mi_profile_search_stats(mi_ctx* ctx, int enable, unsigned long long out[8]);
 /* Name of the correspondence-search kernel (MI_KERNEL_NN) a search of n_moving points against m_fixed_local fixed points runs
  * with this nn_mode and the current settings -- the name a rocprofv3 kernel trace shows (static string). */
 const char* mi_nn_kernel_name(const mi_ctx* ctx, int n_moving, int m_fixed_local, int nn_mode);

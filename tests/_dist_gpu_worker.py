@@ -52,7 +52,7 @@ def main():
 
         # ICP, every way of splitting it, both searches: the same iteration count and stop reason, R|t equal to the single-GPU
         # run up to the order of the fp64 partial sums (1e-6; the correspondences themselves are identical)
-        for nn_mode in (capi.NN_BRUTEFORCE, capi.NN_TREE):
+        for nn_mode in (capi.NN_BRUTEFORCE, capi.NN_TREE, capi.NN_GRID):
             for shard_mode in (capi.SHARD_TARGET, capi.SHARD_SOURCE, capi.SHARD_AUTO):
                 for kw in (dict(eps=1e-3, max_iterations=50, max_distance_squared=400.0), dict(max_iterations=7),
                            dict(eps=1e-3, max_iterations=50, max_distance_squared=400.0, sync_every=3)):

@@ -14,6 +14,29 @@ from conftest import frob
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def mfma_ctx(capi):
+    """Contexts created under MISLAM_CPD_MFMA=0 / 1 (developer switches are read once, at context creation)."""
+    import os
+    made = {}
+
+    def get(mfma):
+        if mfma not in made:
+            old = os.environ.get("MISLAM_CPD_MFMA")
+            os.environ["MISLAM_CPD_MFMA"] = mfma
+            try:
+                made[mfma] = capi.Context(0)
+            finally:
+                if old is None:
+                    del os.environ["MISLAM_CPD_MFMA"]
+                else:
+                    os.environ["MISLAM_CPD_MFMA"] = old
+        return made[mfma]
+    yield get
+    for c in made.values():
+        c.close()
+
+
 def rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
 
@@ -29,8 +52,8 @@ def test_sigma_squared_is_the_exact_value(ctx, capi, bunny):
 
 
 @pytest.mark.parametrize("mfma", ["0", "1"])
-def test_estep_matches_golden(ctx, capi, golden, bunny, monkeypatch, mfma):
-    monkeypatch.setenv("MISLAM_CPD_MFMA", mfma)
+def test_estep_matches_golden(mfma_ctx, capi, golden, bunny, mfma):
+    ctx = mfma_ctx(mfma)
     before, after = bunny
     g = golden.json("bunny_cpd.json")
     e = golden.npz("bunny_cpd_estep0.npz")
@@ -43,8 +66,8 @@ def test_estep_matches_golden(ctx, capi, golden, bunny, monkeypatch, mfma):
 
 @pytest.mark.parametrize("mfma", ["0", "1"])
 @pytest.mark.parametrize("m,n,sigma2", [(300, 350, 8.0), (1000, 17, 0.5), (65, 1300, 0.01), (1, 1, 1.0), (4097, 4099, 0.05)])
-def test_estep_random_matches_oracle(ctx, capi, oracle, monkeypatch, mfma, m, n, sigma2):
-    monkeypatch.setenv("MISLAM_CPD_MFMA", mfma)
+def test_estep_random_matches_oracle(mfma_ctx, capi, oracle, mfma, m, n, sigma2):
+    ctx = mfma_ctx(mfma)
     rng = np.random.default_rng(m * 31 + n)
     y = rng.uniform(-5, 5, (m, 3)).astype(np.float32)
     x = (y[rng.integers(0, m, n)] + rng.normal(scale=0.2, size=(n, 3))).astype(np.float32)

@@ -161,21 +161,24 @@ def test_bunny_hybrid_run_matches_cpu_slam(ctx, capi, golden, bunny):
 
 
 def test_resumed_clustering_changes_nothing(ctx, capi, golden, bunny, monkeypatch):
+    monkeypatch.setenv("MISLAM_FGT_RESUME", "0")       # read at context creation
+    with capi.Context(0) as fresh:
+        _resumed_clustering_changes_nothing(ctx, fresh, capi, golden, bunny)
+
+
+def _resumed_clustering_changes_nothing(ctx, fresh, capi, golden, bunny):
     # the fixed cloud's K-centre sweep is resumed from one E-step to the next (K only grows as sigma^2 shrinks); switching that
     # off re-clusters from scratch every time and must give the same bits
     before, after = bunny
     g = golden.json("bunny_fgt.json")
     p = capi.cpd_params(max_iterations=50, sigma2_init=g["sigma2_init"], approximation=capi.CPD_APPROX_HYBRID)
     a = ctx.cpd_register(before, after, p)
-    monkeypatch.setenv("MISLAM_FGT_RESUME", "0")
-    b = ctx.cpd_register(before, after, p)
+    b = fresh.cpd_register(before, after, p)
     assert a[3] == b[3] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[4] == b[4]
     # full mode: sigma^2 (hence K) also moves down again once the clamp kicks in -- the sweep restarts there
-    monkeypatch.delenv("MISLAM_FGT_RESUME")
     p = capi.cpd_params(max_iterations=24, sigma2_init=g["sigma2_init"], approximation=capi.CPD_APPROX_FULL)
     a = ctx.cpd_register(before, after, p)
-    monkeypatch.setenv("MISLAM_FGT_RESUME", "0")
-    b = ctx.cpd_register(before, after, p)
+    b = fresh.cpd_register(before, after, p)
     assert a[3] == b[3] == 24 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[4] == b[4]
 
 
@@ -190,8 +193,9 @@ def test_large_cloud_sweep_and_its_resume(ctx, capi, oracle, monkeypatch):
     assert np.array_equal(ctx.fgt_kcenter(a, 60)[1], lab_o)
     p = capi.cpd_params(max_iterations=8, tolerance=0.0, approximation=capi.CPD_APPROX_HYBRID)
     r1 = ctx.cpd_register(b, a, p)
-    monkeypatch.setenv("MISLAM_FGT_RESUME", "0")
-    r2 = ctx.cpd_register(b, a, p)
+    monkeypatch.setenv("MISLAM_FGT_RESUME", "0")       # read at context creation
+    with capi.Context(0) as fresh:
+        r2 = fresh.cpd_register(b, a, p)
     assert r1[3] == r2[3] == 8 and np.array_equal(r1[0], r2[0]) and np.array_equal(r1[1], r2[1]) and r1[4] == r2[4]
     assert np.abs(r1[0] / r1[2] - Rz).max() < 0.05             # sR / s: eight iterations in, the rotation is already there
 

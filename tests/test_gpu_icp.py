@@ -107,14 +107,16 @@ def test_result_independent_of_host_check_interval(ctx, capi, bunny, sync_every)
 
 @pytest.mark.parametrize("cuda_rules", [False, True])
 def test_search_strategy_does_not_change_the_registration(ctx, capi, bunny, cuda_rules):
-    # brute force and the box hierarchy return the same keys, so the whole run is bitwise identical
+    # every pair, the box hierarchy and the cell grid return the same keys, and every path -- the grid's fused iteration
+    # included -- adds an iteration's sums in the same per-128-point rows: the whole run is bitwise identical
     before, after = bunny
     runs = []
-    for nn_mode in (capi.NN_BRUTEFORCE, capi.NN_TREE):
+    for nn_mode in (capi.NN_BRUTEFORCE, capi.NN_TREE, capi.NN_GRID):
         p = capi.icp_params(cuda_slam=cuda_rules, max_iterations=25, max_distance_squared=400.0, nn_mode=nn_mode)
         runs.append(ctx.icp_register(before, after, p))
-    a, b = runs
-    assert a[2] == b[2] and a[3] == b[3] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    a = runs[0]
+    for b in runs[1:]:
+        assert a[2] == b[2] and a[3] == b[3] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
 def test_synth2k_matches_cpu_slam(ctx, capi, golden):
@@ -214,15 +216,16 @@ def test_full_bench_size_iterations(ctx, capi):
     # bitwise the same registration, the error falls monotonically, and one iteration equals an fp64 Kabsch solve of its pairs
     before, after, Rt, tt = synth_cloud(1000000)
     runs = []
-    for nn_mode in (capi.NN_TREE, capi.NN_BRUTEFORCE):
+    for nn_mode in (capi.NN_GRID, capi.NN_TREE, capi.NN_BRUTEFORCE):
         ctx.icp_load(before, after, capi.icp_params(max_iterations=3, nn_mode=nn_mode))
         errs = []
         for _ in range(3):
             ctx.icp_run(1)
             errs.append(ctx.icp_result()[3])
         runs.append((ctx.icp_result(), errs))
-    (ra, ea), (rb, eb) = runs
-    assert ea == eb and np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+    (ra, ea) = runs[0]
+    for rb, eb in runs[1:]:
+        assert ea == eb and np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
     assert ea[0] > ea[1] > ea[2]
     R1, t1, it1, e1 = ctx.icp_register(before, after, capi.icp_params(max_iterations=1))
     idx, _ = ctx.nn_search(before, after)
@@ -268,7 +271,7 @@ def test_world1_rccl_context_matches_plain_context(capi, bunny):
     uid = capi.dist_unique_id()
     with capi.Context(0, 0, 1, uid) as dctx, capi.Context(0) as sctx:
         assert dctx.rank_world() == (0, 1)
-        for nn_mode in (capi.NN_BRUTEFORCE, capi.NN_TREE):
+        for nn_mode in (capi.NN_BRUTEFORCE, capi.NN_TREE, capi.NN_GRID):
             for shard_mode in (capi.SHARD_TARGET, capi.SHARD_SOURCE, capi.SHARD_AUTO):
                 p = capi.icp_params(max_iterations=12, max_distance_squared=400.0, nn_mode=nn_mode, shard_mode=shard_mode)
                 a = dctx.icp_register(before, after, p)

@@ -1,5 +1,5 @@
-"""GPU suite: K1 (brute-force nearest-neighbour search) through the C ABI against the oracle -- indices and distance bits
-must be IDENTICAL (strict '<', lowest index wins ties), in both distance arithmetics."""
+"""GPU suite: the correspondence search (K1 every pair, K1t box hierarchy, K1g cell grid) through the C ABI against the oracle --
+indices and distance bits must be IDENTICAL (strict '<', lowest index wins ties), in both distance arithmetics."""
 import numpy as np
 import pytest
 
@@ -9,9 +9,10 @@ pytestmark = pytest.mark.gpu
 
 
 def check(ctx, capi, oracle, src, tgt, mode):
-    # both execution strategies -- every pair (K1) and the exact box hierarchy (K1t) -- must reproduce the oracle bit for bit
+    # every execution strategy -- every pair (K1), the exact box hierarchy (K1t), the cell grid with its hierarchy fallback
+    # (K1g) -- must reproduce the oracle bit for bit
     ridx, rd2 = oracle.nn_search(src, tgt, dist_mode=mode)
-    for nn_mode in (capi.NN_BRUTEFORCE, capi.NN_TREE):
+    for nn_mode in (capi.NN_BRUTEFORCE, capi.NN_TREE, capi.NN_GRID):
         idx, d2 = ctx.nn_search(src, tgt, mode, nn_mode)
         assert np.array_equal(idx, ridx), "nn_mode %d" % nn_mode
         assert np.array_equal(d2.view(np.uint32), rd2.view(np.uint32)), "nn_mode %d" % nn_mode
@@ -56,7 +57,7 @@ def test_adversarial_order_descending_distance(ctx, capi, oracle):
     check(ctx, capi, oracle, src, tgt[order].copy(), 0)
 
 
-@pytest.mark.parametrize("nn_mode", [1, 2])
+@pytest.mark.parametrize("nn_mode", [1, 2, 3])
 def test_bunny_iter0_matches_golden(ctx, capi, golden, bunny, nn_mode):
     # bunny has every vertex ~6 times (face-corner expansion): exact ties everywhere, the lowest index must win
     before, after = bunny
@@ -82,41 +83,41 @@ def test_tree_equals_bruteforce_on_clustered_and_degenerate_clouds(ctx, capi, mo
     for tgt in clouds:
         tgt = tgt.astype(np.float32)
         a = ctx.nn_search(src, tgt, mode, capi.NN_BRUTEFORCE)
-        b = ctx.nn_search(src, tgt, mode, capi.NN_TREE)
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        for indexed in (capi.NN_TREE, capi.NN_GRID):
+            b = ctx.nn_search(src, tgt, mode, indexed)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), indexed
 
 
-@pytest.mark.parametrize("variant", ["R=-1", "R=1", "R=2", "COMPACT=0", "HALF=1", "DYNAMIC=1", "DYNAMIC=1,RESIDENT=2", "DYNAMIC=1,RESIDENT=1,REFILL=1",
-                                     "DYNAMIC=1,RESIDENT=3,REFILL=64", "DYNAMIC=1,RESIDENT=8", "DYNAMIC=1,RESIDENT=9,REFILL=1",
-                                     "DYNAMIC=1,RESIDENT=16,PARTS=1", "DYNAMIC=0", "WIDE=1", "WIDE=1,RESIDENT=2,REFILL=1",
-                                     "WIDE=1,RESIDENT=9", "NODE_STEPS=0", "NODE_STEPS=1", "XCD_CHUNKS=0", "XCD_CHUNKS=1", "XCD_CHUNKS=2",
-                                     "BLOCK=64,XCD_CHUNKS=2", "BLOCK=256",
-                                     "WIDE=1,NODE_STEPS=1",
-                                     "DYNAMIC=1,RESIDENT=2,NODE_STEPS=1"])
+@pytest.mark.parametrize("ppc", ["0.25", "1", "8", "64"])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_alternative_hierarchy_walks_are_exact_too(ctx, capi, oracle, monkeypatch, variant, mode):
-    # the alternative query forms (the default is the per-lane walk over the compact copies, register trail + bounds in LDS --
-    # with dynamic work fetching once the moving cloud exceeds the resident grid, which this small case forces on / off):
-    # R=-1 per-lane stackless trail walk over the float4 records; R=1, 2 one walk per wave (scalar loads, stack across the lanes
-    # of a VGPR); COMPACT=0 the per-lane walk with a (node, bound) stack over the float4 records; HALF=1 the default walk over
-    # half-precision sibling boxes rounded outwards; DYNAMIC=1 the fetching walk (RESIDENT = blocks in its grid, so that this
-    # small cloud is fetched in many batches -- from 8 blocks on, one range of the cloud per XCD with stealing, 9 leaves a block
-    # without a static share; REFILL = finished lanes that trigger a fetch; PARTS=1 one range for all); WIDE=1 the 4-wide walk
-    # (two binary levels per visit; this hierarchy has an odd height, so its wide root has two empty children); NODE_STEPS = node
-    # visits per round before a wave turns to its leaves (0 = no limit; the default is 5); XCD_CHUNKS = the static kernel's
-    # block-to-chunk mapping: 0 plain, 1 a contiguous eighth of the moving cloud per XCD, S runs of S chunks per XCD (default 32,
-    # which this 17-block cloud is too small for: 2 exercises the remapping here, the 1e6 / 1e7 tests below run the default)
-    for setting in variant.split(","):
-        name, value = setting.split("=")
-        monkeypatch.setenv("MISLAM_TREE_" + name, value)
-    assert ("dynamic" in ctx.nn_kernel_name(4133, 8000, capi.NN_TREE)) == variant.startswith("DYNAMIC=1")
+def test_grid_is_exact_at_every_cell_size(capi, oracle, monkeypatch, ppc, mode):
+    # the grid's cell size is a speed knob (MISLAM_GRID_PPC = mean points per cell, read at context creation): from cells far
+    # smaller than the point spacing (most rows empty, radii of many cells -> hierarchy fallback for the far queries) to cells so
+    # crowded that the candidate budget sends lanes to the hierarchy mid-scan -- the answer must not change by a bit
+    monkeypatch.setenv("MISLAM_GRID_PPC", ppc)
     rng = np.random.default_rng(31)
     base = rng.uniform(-5, 5, (6000, 3)).astype(np.float32)
     tgt = np.concatenate([base, base[:2000]])                       # duplicates: ties
     src = np.concatenate([base[100:900], (base[:3000] + rng.normal(scale=0.05, size=(3000, 3))).astype(np.float32),
                           rng.uniform(-20, 20, (333, 3)).astype(np.float32)])
-    idx, d2 = ctx.nn_search(src, tgt, mode, capi.NN_TREE)
     ridx, rd2 = oracle.nn_search(src, tgt, dist_mode=mode)
+    with capi.Context(0) as c2:
+        idx, d2 = c2.nn_search(src, tgt, mode, capi.NN_GRID)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2.view(np.uint32), rd2.view(np.uint32))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_grid_boundary_and_outside_queries(ctx, capi, oracle, mode):
+    # queries exactly on cell faces and corners, on the bounding box, just outside it and far outside it; fixed points on a
+    # lattice that coincides with cell faces (every rounding slack of nn_grid.hip is exercised)
+    g = np.arange(16, dtype=np.float32)
+    tgt = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)          # 4096 lattice points, ext 15 per axis
+    rng = np.random.default_rng(3)
+    src = np.concatenate([tgt[::7] + np.float32(0.5), tgt[::5], tgt[::11] + np.float32([0.5, 0, 0]),
+                          rng.uniform(-1, 16, (2000, 3)).astype(np.float32), rng.uniform(-40, 60, (300, 3)).astype(np.float32),
+                          np.float32([[-1e-6, 7.5, 7.5], [15.000001, 15, 15], [7.5, 7.5, 7.5], [1e4, 1e4, 1e4]])]).astype(np.float32)
+    ridx, rd2 = oracle.nn_search(src, tgt, dist_mode=mode)
+    idx, d2 = ctx.nn_search(src, tgt, mode, capi.NN_GRID)
     assert np.array_equal(idx, ridx) and np.array_equal(d2.view(np.uint32), rd2.view(np.uint32))
 
 
@@ -125,9 +126,11 @@ def test_large_sampled_rows_and_properties(ctx, capi, oracle):
     # the rest is covered by size-independent properties (self-search is the identity with d2 = 0; the reported d2 is the
     # true distance to the reported index; no sampled target is closer).
     before, after, _, _ = synth_cloud(100000)
-    idx, d2 = ctx.nn_search(before, after, 0, capi.NN_TREE)
+    idx, d2 = ctx.nn_search(before, after, 0, capi.NN_GRID)
     bidx, bd2 = ctx.nn_search(before, after, 0, capi.NN_BRUTEFORCE)
-    assert np.array_equal(idx, bidx) and np.array_equal(d2.view(np.uint32), bd2.view(np.uint32))   # all 1e10 pairs vs the tree
+    assert np.array_equal(idx, bidx) and np.array_equal(d2.view(np.uint32), bd2.view(np.uint32))   # all 1e10 pairs vs the grid
+    tidx, td2 = ctx.nn_search(before, after, 0, capi.NN_TREE)
+    assert np.array_equal(tidx, bidx) and np.array_equal(td2.view(np.uint32), bd2.view(np.uint32))
     rows = np.random.default_rng(0).choice(len(before), 256, replace=False)
     ridx, rd2 = oracle.nn_search(before[rows], after)
     assert np.array_equal(idx[rows], ridx)
@@ -140,12 +143,14 @@ def test_large_sampled_rows_and_properties(ctx, capi, oracle):
 
 
 def test_full_bench_size_properties(ctx, capi, oracle):
-    # BASELINE.json's headline size (N = M = 1e6): the box hierarchy against ALL 1e12 pairs of the every-pair kernel (which is
-    # pinned to the oracle above), sampled rows against the oracle itself, and the size-independent properties
+    # BASELINE.json's headline size (N = M = 1e6): the cell grid and the box hierarchy against ALL 1e12 pairs of the every-pair
+    # kernel (which is pinned to the oracle above), sampled rows against the oracle itself, and the size-independent properties
     before, after, Rm, tm = synth_cloud(1000000)
-    idx, d2 = ctx.nn_search(before, after, 0, capi.NN_TREE)
+    idx, d2 = ctx.nn_search(before, after, 0, capi.NN_GRID)
     bidx, bd2 = ctx.nn_search(before, after, 0, capi.NN_BRUTEFORCE)
     assert np.array_equal(idx, bidx) and np.array_equal(d2.view(np.uint32), bd2.view(np.uint32))
+    tidx, td2 = ctx.nn_search(before, after, 0, capi.NN_TREE)
+    assert np.array_equal(tidx, bidx) and np.array_equal(td2.view(np.uint32), bd2.view(np.uint32))
     rows = np.random.default_rng(1).choice(len(before), 64, replace=False)
     ridx, rd2 = oracle.nn_search(before[rows], after)
     assert np.array_equal(idx[rows], ridx) and np.array_equal(d2[rows].view(np.uint32), rd2.view(np.uint32))

@@ -1,4 +1,4 @@
-"""GPU suite: randomized soak of the box-hierarchy search against the every-pair search (tools/nn_soak.py, 40 seeded cases):
+"""GPU suite: randomized soak of the box-hierarchy and cell-grid searches against the every-pair search (tools/nn_soak.py, 40 seeded cases):
 random sizes up to 3e5, uniform / clustered / planar / duplicated clouds, both distance arithmetics -- identical bits."""
 import os
 import sys
@@ -25,5 +25,6 @@ def test_tree_equals_every_pair_on_random_problems(ctx, capi, seed):
             src[:len(take)] = tgt[take]
         mode = int(rng.integers(0, 2))
         a = ctx.nn_search(src, tgt, mode, capi.NN_BRUTEFORCE)
-        b = ctx.nn_search(src, tgt, mode, capi.NN_TREE)
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (seed, n, m, mode)
+        for indexed in (capi.NN_TREE, capi.NN_GRID):
+            b = ctx.nn_search(src, tgt, mode, indexed)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (seed, n, m, mode, indexed)
