@@ -105,6 +105,8 @@ struct mi_ctx {
     mislam::DevBuf<float4> tgt4;                         // same shard as float4 (gathers)
     mislam::DevBuf<unsigned long long> keys;
     mislam::DevBuf<double> part_mom, part_err;           // per-workgroup partial sums of the NICP / CPD drivers
+    mislam::DevBuf<int> sched_order, sched_counters;     // work order of the fused search (IcpSchedule)
+    mislam::DevBuf<unsigned char> sched_far;
     mislam::DevBuf<double> rows, rows_reduced;           // ICP: one row of 18 sums per 128 moving points (icp_rows.hpp), and <= 64 reduced rows
     mislam::DevBuf<int> idx_tmp;
     mislam::DevBuf<unsigned char> keep_tmp;
@@ -116,9 +118,10 @@ struct mi_ctx {
     mislam::DevBuf<int> torder_in, torder_out;
     mislam::DevBuf<float> tbbox;
     mislam::DevBuf<unsigned char> tsort_temp;
-    mislam::DevBuf<float4> tpts, tboxes;                 // box hierarchy (nn_tree.h): sorted points (build scratch), node boxes
-    mislam::DevBuf<float4> tpairs, tleaf;                // compact copies the walk reads (NnTreeView)
-    mislam::DevBuf<int> tidx;
+    mislam::DevBuf<float4> tpts, tboxes;                 // box hierarchy (nn_tree.h): sorted points and node boxes (build scratch)
+    mislam::DevBuf<float4> tleaf;                        // what the walk reads (NnTreeView): leaf coordinates, ...
+    mislam::DevBuf<int> tidx;                            // ... global indices ...
+    mislam::DevBuf<float> tboxes6;                       // ... and node boxes, six floats each
     mislam::NnTreeView tree{};
     bool tree_valid = false;
     mislam::DevBuf<float4> gpts;                         // cell grid (nn_grid.h): points sorted by cell

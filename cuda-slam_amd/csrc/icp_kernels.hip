@@ -114,11 +114,42 @@ __global__ __launch_bounds__(ICP_ROW_POINTS) void icp_moments_rows_kernel(IcpVie
 
 // rows [first, first + count) of ICP_ROW doubles -> out[blockIdx.x] : workgroup g sums its contiguous slice of rows in index
 // order (14 strips of rows, then the strips in order)
+// While it is at it, the kernel also deals the NEXT search its work order (sched != null): chunks whose wave walked the box
+// hierarchy in this iteration -- they will again, the flags move slowly -- go to the front, so that those long walks start at once
+// and the short grid-only chunks fill in behind them instead of the other way round (a wave that walks lives ~5x longer).  Scheduling
+// only: which workgroup handles which chunk never changes a result.
 __global__ __launch_bounds__(256) void icp_rows_reduce_kernel(const double* __restrict__ rows, int nrows, int rows_per_block,
-                                                              double* __restrict__ out)
+                                                              double* __restrict__ out, IcpSchedule sched)
 {
     constexpr int STRIPS = 256 / ICP_ROW;                      // 14
     __shared__ double lds[STRIPS * ICP_ROW];
+    if (sched.order != nullptr) {
+        __shared__ int s_far, s_near, s_base_far, s_base_near;
+        const int lo = blockIdx.x * rows_per_block;
+        const int hi = lo + rows_per_block < nrows ? lo + rows_per_block : nrows;
+        if (threadIdx.x == 0) { s_far = 0; s_near = 0; }
+        __syncthreads();
+        // two passes over the slice: count, reserve a range at each end of the order, place (ascending inside the slice)
+        int my_far = 0, my_near = 0;
+        for (int r = lo + (int)threadIdx.x; r < hi; r += 256) { if (sched.far[r]) my_far++; else my_near++; }
+        if (my_far) atomicAdd(&s_far, my_far);
+        if (my_near) atomicAdd(&s_near, my_near);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_base_far = atomicAdd(&sched.counters[0], s_far);
+            s_base_near = atomicAdd(&sched.counters[1], s_near);
+            s_far = 0; s_near = 0;
+        }
+        __syncthreads();
+        for (int r0 = lo; r0 < hi; r0 += 256) {                    // slice order kept: ballot-free, one LDS cursor per class
+            const int r = r0 + (int)threadIdx.x;
+            if (r < hi) {
+                if (sched.far[r]) sched.order[s_base_far + atomicAdd(&s_far, 1)] = r;
+                else sched.order[nrows - 1 - (s_base_near + atomicAdd(&s_near, 1))] = r;
+            }
+        }
+        __syncthreads();
+    }
     const int k = threadIdx.x % ICP_ROW, strip = threadIdx.x / ICP_ROW;
     const int lo = blockIdx.x * rows_per_block;
     const int hi = lo + rows_per_block < nrows ? lo + rows_per_block : nrows;
@@ -390,8 +421,9 @@ __device__ void finalize_iteration(IcpState* __restrict__ state, double e0, doub
 // part == null: they are already in state->mom / state->err (multi-GPU: all-reduced there).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void icp_solve_deferred_kernel(IcpState* __restrict__ state, const double* __restrict__ part, int count,
-                                                                int compose_mode, IcpRules rules, int mark_pending)
+                                                                int compose_mode, IcpRules rules, int mark_pending, int* __restrict__ sched_counters)
 {
+    if (sched_counters != nullptr && threadIdx.x < 2) sched_counters[threadIdx.x] = 0;   // the reduce kernel's range cursors (IcpSchedule)
     if (state->done != 0) return;
     __shared__ double sums[ICP_ROW];
     if (threadIdx.x < ICP_ROW) {
@@ -446,11 +478,26 @@ int icp_reduced_count(int nrows)
     return g < 1 ? 1 : g;
 }
 
-hipError_t icp_rows_reduce(const double* rows, int nrows, double* part, hipStream_t s)
+hipError_t icp_rows_reduce(const double* rows, int nrows, double* part, hipStream_t s, const IcpSchedule* sched)
 {
     const int g = icp_reduced_count(nrows);
     const int per = (nrows + g - 1) / g;
-    hipLaunchKernelGGL(icp_rows_reduce_kernel, dim3(g), dim3(256), 0, s, rows, nrows, per, part);
+    IcpSchedule sc{};
+    if (sched != nullptr) sc = *sched;
+    hipLaunchKernelGGL(icp_rows_reduce_kernel, dim3(g), dim3(256), 0, s, rows, nrows, per, part, sc);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void icp_schedule_reset_kernel(IcpSchedule sched, int nrows)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < nrows) { sched.order[r] = r; sched.far[r] = 0; }
+    if (r < 2) sched.counters[r] = 0;
+}
+
+hipError_t icp_schedule_reset(const IcpSchedule& sched, int nrows, hipStream_t s)
+{
+    hipLaunchKernelGGL(icp_schedule_reset_kernel, dim3((nrows + 255) / 256), dim3(256), 0, s, sched, nrows);
     return hipGetLastError();
 }
 
@@ -460,9 +507,10 @@ hipError_t icp_rows_to_state(IcpState* state, const double* part, int count, int
     return hipGetLastError();
 }
 
-hipError_t icp_solve_deferred(IcpState* state, const double* part, int count, int compose_mode, const IcpRules& rules, int mark_pending, hipStream_t s)
+hipError_t icp_solve_deferred(IcpState* state, const double* part, int count, int compose_mode, const IcpRules& rules, int mark_pending, hipStream_t s,
+                              int* sched_counters)
 {
-    hipLaunchKernelGGL(icp_solve_deferred_kernel, dim3(1), dim3(64), 0, s, state, part, count, compose_mode, rules, mark_pending);
+    hipLaunchKernelGGL(icp_solve_deferred_kernel, dim3(1), dim3(64), 0, s, state, part, count, compose_mode, rules, mark_pending, sched_counters);
     return hipGetLastError();
 }
 

@@ -102,14 +102,22 @@ hipError_t icp_moments_rows(const IcpView& v, double* rows, hipStream_t s);     
 // rearm 0 = leave keys, 1 = KEY_INIT, 2 = the previous match's key under the NEW transform (a real candidate: the next search
 // starts from a tight bound)
 hipError_t icp_transform_error_rows(const IcpView& v, double* rows, int rearm, hipStream_t s);
-hipError_t icp_rows_reduce(const double* rows, int nrows, double* part, hipStream_t s);         // -> part[icp_reduced_count(nrows)][18]
+// Work order of the fused search (nn_grid.hip): order[position] = chunk; the rows-reduce kernel rewrites it every iteration from
+// the flags the search left (far[chunk] != 0: its wave walked the box hierarchy), walking chunks first.  Scheduling only.
+struct IcpSchedule {
+    int* order;                            // nrows entries, always a permutation of the chunks
+    unsigned char* far;                    // nrows flags
+    int* counters;                         // 2 cursors, zeroed by the solve kernel
+};
+hipError_t icp_schedule_reset(const IcpSchedule& sched, int nrows, hipStream_t s);             // identity order, no flags
+hipError_t icp_rows_reduce(const double* rows, int nrows, double* part, hipStream_t s, const IcpSchedule* sched = nullptr);   // -> part[icp_reduced_count(nrows)][18]
 // reduced rows -> state->mom / state->err (which: 1 moments, 2 error sums, 3 both); the multi-GPU paths all-reduce them there
 hipError_t icp_rows_to_state(IcpState* state, const double* part, int count, int which, hipStream_t s);
 // K3 + K6, deferred: settles the PREVIOUS iteration's stop rule from the error sums (if state->err_pending), then -- unless it
 // fired -- solves from the moments and composes.  part != null: sums = the reduced rows; null: already in state->mom / err.
 // mark_pending: this iteration's own error will arrive with the next call (or with icp_finalize_pending).
 hipError_t icp_solve_deferred(IcpState* state, const double* part, int count, int compose_mode, const IcpRules& rules, int mark_pending,
-                              hipStream_t s);
+                              hipStream_t s, int* sched_counters = nullptr);
 hipError_t icp_finalize_pending(IcpState* state, const double* part, int count, const IcpRules& rules, hipStream_t s);
 hipError_t icp_mark_pending(IcpState* state, hipStream_t s);
 // MI_SUM_CPU_SEQUENTIAL: cpu-slam's sequential fp32 running sums, reproduced bit for bit (one wave per sum)

@@ -225,8 +225,9 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     c->idx_tmp.release(); c->keep_tmp.release();
     c->tcodes_in.release(); c->tcodes_out.release(); c->torder_in.release(); c->torder_out.release();
     c->tbbox.release(); c->tsort_temp.release(); c->tpts.release(); c->tboxes.release(); c->sorder.release(); c->sinv.release(); c->resid.release();
-    c->tpairs.release(); c->tleaf.release(); c->tidx.release(); c->nn_stats.release();
+    c->tleaf.release(); c->tidx.release(); c->tboxes6.release(); c->nn_stats.release();
     c->gpts.release(); c->gstart.release(); c->gfill.release(); c->gscan.release(); c->rows.release(); c->rows_reduced.release();
+    c->sched_order.release(); c->sched_far.release(); c->sched_counters.release();
     for (auto& s : c->spans) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->d_state) (void)hipFree(c->d_state);
@@ -415,17 +416,17 @@ static int ensure_tree(mi_ctx* c, int m_local, int index_base)
     MI_TRY(c->torder_out.reserve((size_t)m_local));
     MI_TRY(c->tpts.reserve((size_t)n_leaves * TREE_LEAF));
     MI_TRY(c->tboxes.reserve((size_t)4 * n_pad));
-    MI_TRY(c->tpairs.reserve((size_t)3 * n_pad));
     MI_TRY(c->tleaf.reserve((size_t)n_leaves * (3 * TREE_LEAF / 4)));
     MI_TRY(c->tidx.reserve((size_t)n_leaves * TREE_LEAF));
+    MI_TRY(c->tboxes6.reserve((size_t)6 * (2 * (size_t)n_pad - 1 + 8)));
     TreeBuildArgs a{};
     MI_TRY(morton_args(c, c->tx.p, c->ty.p, c->tz.p, m_local, c->torder_out.p, &a.morton));
     a.index_base = index_base; a.n_leaves = n_leaves; a.n_pad = n_pad;
     a.pts = c->tpts.p; a.boxes = c->tboxes.p;
-    a.pairs = c->tpairs.p; a.leaf_soa = c->tleaf.p; a.leaf_idx = c->tidx.p;
+    a.leaf_soa = c->tleaf.p; a.leaf_idx = c->tidx.p; a.boxes6 = c->tboxes6.p;
     MI_HIP(tree_build(a, c->stream));
-    c->tree.boxes = c->tboxes.p;
-    c->tree.pairs = c->tpairs.p; c->tree.leaf_soa = c->tleaf.p; c->tree.leaf_idx = c->tidx.p;
+    c->tree.boxes6 = c->tboxes6.p;
+    c->tree.leaf_soa = c->tleaf.p; c->tree.leaf_idx = c->tidx.p;
     c->tree.n_pad = n_pad; c->tree.height = height;
     c->tree_valid = true;
     return MI_OK;
@@ -487,7 +488,7 @@ extern "C" const char* mi_nn_kernel_name(const mi_ctx* c, int n_moving, int m_fi
     (void)n_moving;
     if (!c) return "";
     const int mode = resolve_nn_mode(c, nn_mode, m_fixed_local);
-    return mode == MI_NN_GRID ? nn_grid_kernel_name(false) : (mode == MI_NN_TREE ? "nn_tree_lane_kernel" : "nn_bruteforce_kernel");
+    return mode == MI_NN_GRID ? nn_grid_kernel_name(false) : (mode == MI_NN_TREE ? "nn_tree_kernel" : "nn_bruteforce_kernel");
 }
 
 int launch_nn(mi_ctx* c, const float* sx, const float* sy, const float* sz, int n, int m_local, int index_base, int fma,
@@ -565,7 +566,17 @@ static int reserve_rows(mi_ctx* c)
         MI_HIP(hipMemsetAsync(c->rows.p, 0, sizeof(double) * c->rows.cap, c->stream));   // columns a path never writes stay finite
     }
     MI_TRY(c->rows_reduced.reserve((size_t)64 * (ICP_MOMENTS + ICP_ERRSUMS)));
+    MI_TRY(c->sched_order.reserve((size_t)icp_row_count(c->n_pad)));
+    MI_TRY(c->sched_far.reserve((size_t)icp_row_count(c->n_pad)));
+    MI_TRY(c->sched_counters.reserve(2));
     return MI_OK;
+}
+
+static IcpSchedule make_schedule(mi_ctx* c)
+{
+    IcpSchedule s{};
+    s.order = c->sched_order.p; s.far = c->sched_far.p; s.counters = c->sched_counters.p;
+    return s;
 }
 
 static IcpView make_view(mi_ctx* c)
@@ -653,6 +664,7 @@ extern "C" int mi_icp_reset(mi_ctx* c)
     MI_HIP(hipMemcpyAsync(c->cy.p, c->by.p, bytes, hipMemcpyDeviceToDevice, c->stream));
     MI_HIP(hipMemcpyAsync(c->cz.p, c->bz.p, bytes, hipMemcpyDeviceToDevice, c->stream));
     MI_HIP(fill_keys(c->keys.p, c->n, c->stream));
+    MI_HIP(icp_schedule_reset(make_schedule(c), icp_row_count(c->n), c->stream));
     MI_HIP(hipStreamSynchronize(c->stream));
     return MI_OK;
 }
@@ -763,6 +775,7 @@ static int icp_enqueue_iteration(mi_ctx* c)
         a.tgt4 = c->tgt4.p; a.shard_lo = c->shard_lo; a.shard_hi = c->shard_hi;
         a.filter_pairs = c->icp.filter_pairs; a.max_distance_squared = c->icp.max_distance_squared;
         a.rows = c->rows.p;
+        a.order = c->sched_order.p; a.far = c->sched_far.p;
         ProfScope ps(c, MI_KERNEL_NN);
         MI_HIP(nn_grid_query(c->grid, c->tree, a, v.fma, c->stream));
     } else {
@@ -774,16 +787,18 @@ static int icp_enqueue_iteration(mi_ctx* c)
     }
     {   // K3 (+ K6 of the previous iteration)
         ProfScope ps(c, MI_KERNEL_SOLVE);
-        MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream));
+        const IcpSchedule sched = make_schedule(c);
+        MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream, c->fused ? &sched : nullptr));
+        int* cursors = c->fused ? sched.counters : nullptr;
         if (c->distributed()) {
             // ONE all-reduce per iteration: this iteration's 16 moments and the previous iteration's 2 error sums (contiguous in
             // the state block)
             static_assert(offsetof(IcpState, err) == offsetof(IcpState, mom) + sizeof(double) * ICP_MOMENTS, "mom and err must be contiguous");
             MI_HIP(icp_rows_to_state(c->d_state, c->rows_reduced.p, reduced, 3, c->stream));
             MI_TRY(allreduce_doubles(c, c->d_state->mom, ICP_MOMENTS + ICP_ERRSUMS));
-            MI_HIP(icp_solve_deferred(c->d_state, nullptr, 0, c->icp.compose_mode, rules, 1, c->stream));
+            MI_HIP(icp_solve_deferred(c->d_state, nullptr, 0, c->icp.compose_mode, rules, 1, c->stream, cursors));
         } else {
-            MI_HIP(icp_solve_deferred(c->d_state, c->rows_reduced.p, reduced, c->icp.compose_mode, rules, 1, c->stream));
+            MI_HIP(icp_solve_deferred(c->d_state, c->rows_reduced.p, reduced, c->icp.compose_mode, rules, 1, c->stream, cursors));
         }
     }
     if (!c->fused) {

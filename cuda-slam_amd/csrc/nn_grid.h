@@ -11,9 +11,15 @@ namespace mislam {
 constexpr int GRID_BLOCK = 64;             // moving points per workgroup: one wave = one row of ICP partial sums (icp_rows.hpp)
 constexpr int GRID_MAX_DIM = 1024;         // cells per axis: keeps the rounding of a cell coordinate (2^-23 * 1024) far below the 1e-3 slack
 constexpr float GRID_POINTS_PER_CELL = 2.0f;
-constexpr float GRID_DU_MAX = 2.0f;        // the grid answers queries whose neighbour lies within this many cells; the others walk the hierarchy
+#ifndef MISLAM_GRID_DU_MAX
+#define MISLAM_GRID_DU_MAX 2.0f
+#endif
+constexpr float GRID_DU_MAX = MISLAM_GRID_DU_MAX;        // the grid answers queries whose neighbour lies within this many cells; the others walk the hierarchy
 constexpr int GRID_STATS_ROWS = 1024;         // mi_profile_search_stats: the counters are kept in this many copies
-constexpr float GRID_FAR_FACTOR = 2.0f;    // a starting candidate farther than this many times GRID_DU_MAX cells: straight to the hierarchy
+#ifndef MISLAM_GRID_FAR_FACTOR
+#define MISLAM_GRID_FAR_FACTOR 2.0f
+#endif
+constexpr float GRID_FAR_FACTOR = MISLAM_GRID_FAR_FACTOR;    // a starting candidate farther than this many times GRID_DU_MAX cells: straight to the hierarchy
 constexpr int GRID_CAND_BUDGET = 640;      // candidates a lane may test in the grid before it walks the hierarchy instead
 
 struct NnGridView {
@@ -60,6 +66,8 @@ struct GridSearchArgs {
     int filter_pairs;
     float max_distance_squared;
     double* rows;                          // [ceil(n / GRID_BLOCK)][ICP_ROW] partial sums (icp_rows.hpp)
+    const int* order;                      // work order (IcpSchedule): workgroup at position p takes chunk order[p]; null = identity
+    unsigned char* far;                    // out: far[chunk] = this chunk's wave walked the hierarchy
 };
 hipError_t nn_grid_query(const NnGridView& g, const NnTreeView& t, const GridSearchArgs& a, int fma, hipStream_t s);
 const char* nn_grid_kernel_name(bool fused);

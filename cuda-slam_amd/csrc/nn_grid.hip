@@ -309,11 +309,9 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
     if (FUSED) {
         if (a.state->done != 0) return;
     } else if (a.done_flag != nullptr && *a.done_flag != 0) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* st_lb = reinterpret_cast<float*>(smem);             // hierarchy walk: (height + 1) bounds per lane
-
     const int tid = (int)threadIdx.x;
-    const unsigned int chunk = xcd_chunk(blockIdx.x, gridDim.x, TREE_XCD_CHUNKS * (256 / GRID_BLOCK));
+    unsigned int chunk = xcd_chunk(blockIdx.x, gridDim.x, TREE_XCD_CHUNKS * (256 / GRID_BLOCK));
+    if (FUSED && a.order != nullptr) chunk = (unsigned int)a.order[chunk];   // walking chunks first (IcpSchedule): speed only
     const int i = (int)(chunk * GRID_BLOCK) + tid;
     const bool valid = i < a.n;
 
@@ -362,7 +360,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
 #ifdef MISLAM_DEV_WALK_CLOCK
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
-        tree_walk_wave<FMA, STATS>(t, q, best, bidx, st_lb, GRID_BLOCK, tid, n_nodes, n_leaves);
+        tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves);
 #ifdef MISLAM_DEV_WALK_CLOCK
         walk_cycles = __builtin_amdgcn_s_memtime() - t0;
 #endif
@@ -413,6 +411,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
         double* row = a.rows + (size_t)chunk * ICP_ROW;
         row_store_moments(mom, row, nullptr);
         row_store_error(e0, e1, row, nullptr);
+        if (a.far != nullptr && tid == 0) a.far[chunk] = walked ? 1 : 0;
     }
 }
 
@@ -422,9 +421,8 @@ hipError_t nn_grid_query(const NnGridView& g, const NnTreeView& t, const GridSea
 {
     if (a.n <= 0) return hipSuccess;
     const dim3 grid((a.n + GRID_BLOCK - 1) / GRID_BLOCK), block(GRID_BLOCK);
-    const size_t lds = (size_t)(t.height + 1) * GRID_BLOCK * sizeof(float);
     const bool fused = a.state != nullptr;
-#define MI_GRID_LAUNCH(F, U, S) hipLaunchKernelGGL((nn_grid_kernel<F, U, S>), grid, block, lds, s, g, t, a)
+#define MI_GRID_LAUNCH(F, U, S) hipLaunchKernelGGL((nn_grid_kernel<F, U, S>), grid, block, 0, s, g, t, a)
     if (a.stats != nullptr) {          // counting build of the same kernel (mi_profile_search_stats)
         if (fused) { if (fma) MI_GRID_LAUNCH(true, true, true); else MI_GRID_LAUNCH(false, true, true); }
         else { if (fma) MI_GRID_LAUNCH(true, false, true); else MI_GRID_LAUNCH(false, false, true); }

@@ -17,15 +17,14 @@ constexpr int TREE_MAX_HEIGHT = 24;
 // (workgroups are dealt to the 8 XCDs round-robin), the XCDs taking neighbouring runs -- an XCD then walks contiguous stretches
 // of the Z-curve and its L2 fetches each part of the index about once (profiles/r01_k1t_xcd_runs.log)
 constexpr int TREE_XCD_CHUNKS = 32;
-constexpr int TREE_BLOCK_THREADS = 64;         // one wave per workgroup: a walk is wave-wide, nothing is shared between waves
+constexpr int TREE_BLOCK_THREADS = 64;         // one wave per workgroup: a walk is wave-wide, nothing is shared between waves, no LDS
 
 struct NnTreeView {
-    const float4* boxes;              // node i: boxes[2i] = lo, boxes[2i+1] = hi; implicit heap, children of i are 2i+1 and
-                                      // 2i+2, leaves start at n_pad-1 (only the root box is read by the walk)
     int n_pad;                        // leaf count padded to a power of two (padding leaves carry empty boxes)
     int height;                       // log2(n_pad)
-    const float4* pairs;              // internal node p: the boxes of its two children in 3 float4 (48 B):
-                                      //   (l.lo.x l.lo.y l.lo.z l.hi.x) (l.hi.y l.hi.z r.lo.x r.lo.y) (r.lo.z r.hi.x r.hi.y r.hi.z)
+    const float* boxes6;              // node i: lo.xyz hi.xyz, 24 bytes; implicit heap, children of i are 2i+1 and 2i+2, leaves start at
+                                      // n_pad-1, so the 2^k descendants k levels below a node are contiguous (+ 48 floats of padding: a
+                                      // step always reads eight boxes)
     const float4* leaf_soa;           // leaf f: x[TREE_LEAF], y[TREE_LEAF], z[TREE_LEAF] (3*TREE_LEAF/4 float4; no index word)
     const int* leaf_idx;              // GLOBAL index of sorted slot s (read only for the winner and on exact ties)
 };
@@ -47,8 +46,8 @@ struct TreeBuildArgs {
     int index_base;                   // global index of point 0
     int n_leaves, n_pad;
     float4* pts;                      // scratch: n_leaves * TREE_LEAF sorted points (x, y, z, global-index bits)
-    float4* boxes;                    // 2 * (2*n_pad - 1) float4
-    float4* pairs;                    // 3 * (n_pad - 1) float4
+    float4* boxes;                    // scratch: 2 * (2*n_pad - 1) float4 (lo, hi per node)
+    float* boxes6;                    // 6 * (2*n_pad - 1) + 48 floats
     float4* leaf_soa;                 // n_leaves * 3 * TREE_LEAF / 4 float4
     int* leaf_idx;                    // n_leaves * TREE_LEAF
 };

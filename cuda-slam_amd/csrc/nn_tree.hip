@@ -6,15 +6,15 @@
 // Build (once per fixed cloud / shard -- the fixed cloud does not move during ICP): bounding box -> 30-bit Morton codes ->
 // radix sort (rocPRIM device primitive; one-time index build at load, never on the per-iteration path) -> leaves of TREE_LEAF
 // consecutive points -> implicit binary heap of boxes over the leaves, padded to a power of two with empty boxes.  The walk
-// reads compact copies: a node's two child boxes as one 48-byte record, a leaf as x[8] y[8] z[8], the global indices in a side
-// array that is read only for the winner and on exact ties.
+// reads compact copies: a node's box as six floats (eight consecutive boxes per step), a leaf as x[8] y[8] z[8], the global
+// indices in a side array that is read only for the winner and on exact ties.
 //
-// Query: one lane per moving point (nn_walk.hpp tree_walk).  Round 1 measured 0.49 ms per search at N = M = 1e6 with it -- a chain
-// of a few hundred dependent, divergent 16-byte loads per lane (~325 L1 line accesses per query, 24.7 of 64 lanes active).  Since
-// round 2 the default search is the cell grid (nn_grid.hip) and this walk is its in-kernel fallback for the lanes the grid cannot
-// serve cheaply (no starting candidate yet, far outliers, crowded cells); MI_NN_TREE still runs it for every point.  The walk
-// forms that lost in round 1 (wave-cooperative, float4 records, stackless, dynamically fetching, 4-wide, half-precision boxes)
-// are gone; their measurements stay in DESIGN.md.
+// Query: one wave per 64 moving points, ONE cooperative walk per wave (nn_walk.hpp tree_walk_wide).  Round 1 walked per lane: a
+// chain of a few hundred dependent, divergent 16-byte loads per lane (~325 L1 line accesses per query, 24.7 of 64 lanes active,
+// 0.49 ms per search at N = M = 1e6).  Since round 2 the default search is the cell grid (nn_grid.hip) and the walk is its
+// in-kernel fallback for the lanes the grid cannot serve cheaply (no starting candidate yet, far outside the fixed cloud,
+// crowded cells); MI_NN_TREE still runs it for every point.  The per-lane walk forms of round 1 are gone; their measurements stay
+// in DESIGN.md.
 #include <hip/hip_runtime.h>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -179,16 +179,16 @@ __global__ __launch_bounds__(256) void tree_level_kernel(int first, int count, f
     boxes[2 * node + 1] = make_float4(fmaxf(c.x, d.x), fmaxf(c.y, d.y), fmaxf(c.z, d.z), 0.f);
 }
 
-// compact copies for the per-lane walk (layouts: NnTreeView)
-__global__ __launch_bounds__(256) void tree_pack_pairs_kernel(const float4* __restrict__ boxes, int n_internal, float4* __restrict__ pairs)
+// node boxes as 6 floats (the wide walk reads eight consecutive ones per step); the tail padding gets empty boxes
+__global__ __launch_bounds__(256) void tree_pack_boxes6_kernel(const float4* __restrict__ boxes, int n_nodes, int n_out, float* __restrict__ boxes6)
 {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= n_internal) return;
-    const int l = 2 * p + 1;
-    const float4 llo = boxes[2 * (size_t)l], lhi = boxes[2 * (size_t)l + 1], rlo = boxes[2 * (size_t)l + 2], rhi = boxes[2 * (size_t)l + 3];
-    pairs[3 * (size_t)p] = make_float4(llo.x, llo.y, llo.z, lhi.x);
-    pairs[3 * (size_t)p + 1] = make_float4(lhi.y, lhi.z, rlo.x, rlo.y);
-    pairs[3 * (size_t)p + 2] = make_float4(rlo.z, rhi.x, rhi.y, rhi.z);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    float4 lo = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
+    float4 hi = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), 0.f);
+    if (i < n_nodes) { lo = boxes[2 * (size_t)i]; hi = boxes[2 * (size_t)i + 1]; }
+    float* o = boxes6 + 6 * (size_t)i;
+    o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = hi.x; o[4] = hi.y; o[5] = hi.z;
 }
 
 __global__ __launch_bounds__(256) void tree_pack_leaves_kernel(const float4* __restrict__ pts, int n_slots, float* __restrict__ soa,
@@ -214,8 +214,8 @@ hipError_t tree_build(const TreeBuildArgs& a, hipStream_t s)
     hipLaunchKernelGGL(tree_leaf_box_kernel, dim3((a.n_pad + 255) / 256), dim3(256), 0, s, a.pts, a.n_leaves, a.n_pad, a.boxes);
     for (int count = a.n_pad / 2; count >= 1; count /= 2)   // levels bottom-up: nodes [count-1, 2*count-1)
         hipLaunchKernelGGL(tree_level_kernel, dim3((count + 255) / 256), dim3(256), 0, s, count - 1, count, a.boxes);
-    if (a.n_pad > 1)
-        hipLaunchKernelGGL(tree_pack_pairs_kernel, dim3((a.n_pad - 1 + 255) / 256), dim3(256), 0, s, a.boxes, a.n_pad - 1, a.pairs);
+    const int n_nodes = 2 * a.n_pad - 1;
+    hipLaunchKernelGGL(tree_pack_boxes6_kernel, dim3((n_nodes + 8 + 255) / 256), dim3(256), 0, s, a.boxes, n_nodes, n_nodes + 8, a.boxes6);
     hipLaunchKernelGGL(tree_pack_leaves_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, a.pts, n_slots, reinterpret_cast<float*>(a.leaf_soa),
                        a.leaf_idx);
     return hipGetLastError();
@@ -225,13 +225,11 @@ hipError_t tree_build(const TreeBuildArgs& a, hipStream_t s)
 // query: one lane per moving point, one wave per workgroup (nn_walk.hpp tree_walk_wave)
 // ---------------------------------------------------------------------------------------------------------------
 template <bool FMA>
-__global__ __launch_bounds__(TREE_BLOCK_THREADS) void nn_tree_lane_kernel(NnTreeView t, const float* __restrict__ sx, const float* __restrict__ sy,
+__global__ __launch_bounds__(TREE_BLOCK_THREADS) void nn_tree_kernel(NnTreeView t, const float* __restrict__ sx, const float* __restrict__ sy,
                                                                           const float* __restrict__ sz, int n, unsigned long long* __restrict__ keys,
                                                                           const int* __restrict__ done_flag)
 {
     if (done_flag != nullptr && *done_flag != 0) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* st_lb = reinterpret_cast<float*>(smem);             // (height + 1) bounds per lane
     const unsigned int chunk = xcd_chunk(blockIdx.x, gridDim.x, TREE_XCD_CHUNKS * (256 / TREE_BLOCK_THREADS));
     const int i = (int)(chunk * TREE_BLOCK_THREADS + threadIdx.x);
     if (i >= n) return;
@@ -240,7 +238,7 @@ __global__ __launch_bounds__(TREE_BLOCK_THREADS) void nn_tree_lane_kernel(NnTree
     unsigned int bidx;
     unpack_start(keys[i], best, bidx);
     unsigned int n_nodes = 0u, n_leaves = 0u;
-    tree_walk_wave<FMA, false>(t, p, best, bidx, st_lb, TREE_BLOCK_THREADS, (int)threadIdx.x, n_nodes, n_leaves);
+    tree_walk_wide<FMA, false>(t, p, best, bidx, n_nodes, n_leaves);
     if (best < __builtin_inff()) keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
 }
 
@@ -249,9 +247,8 @@ hipError_t nn_tree_query(const NnTreeView& t, const float* sx, const float* sy, 
 {
     if (n <= 0) return hipSuccess;
     const dim3 grid((n + TREE_BLOCK_THREADS - 1) / TREE_BLOCK_THREADS), block(TREE_BLOCK_THREADS);
-    const size_t lds = (size_t)(t.height + 1) * TREE_BLOCK_THREADS * sizeof(float);
-    if (fma) hipLaunchKernelGGL(nn_tree_lane_kernel<true>, grid, block, lds, s, t, sx, sy, sz, n, keys, done_flag);
-    else hipLaunchKernelGGL(nn_tree_lane_kernel<false>, grid, block, lds, s, t, sx, sy, sz, n, keys, done_flag);
+    if (fma) hipLaunchKernelGGL(nn_tree_kernel<true>, grid, block, 0, s, t, sx, sy, sz, n, keys, done_flag);
+    else hipLaunchKernelGGL(nn_tree_kernel<false>, grid, block, 0, s, t, sx, sy, sz, n, keys, done_flag);
     return hipGetLastError();
 }
 

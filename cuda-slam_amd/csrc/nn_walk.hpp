@@ -55,47 +55,45 @@ __device__ __forceinline__ void unpack_start(unsigned long long k0, float& best,
     bidx = hi0 < 0x7f800000u ? (unsigned int)(k0 & 0xffffffffull) : 0u;
 }
 
-// The hierarchy walk: ONE walk per wave for the (up to 64) points of its active lanes, nearer child first, each lane starting
-// from its own candidate (best, bidx) -- a REAL candidate's key or (inf, 0) -- and ending with the lexicographic minimum over it
-// and every point of the hierarchy.  Node, level and trail are wave-uniform, so a node's record and a leaf's points arrive
-// through SCALAR loads and feed the VALU as SGPR operands (like the every-pair kernel), control flow is uniform, and all active
-// lanes are busy on every box and every point.  Pending subtrees: WHICH ones is a 32-bit trail (bit l set = the sibling of the
-// wave's level-l ancestor is still to be visited; the heap numbering makes it computable), their per-lane BOUNDS sit in LDS, one
-// word per level and lane: st_lb[level * stride + slot].  The winner is tracked by its sorted SLOT; the global index is fetched
-// once at the end -- and on an exact tie, where the lower GLOBAL index must win (rare: duplicates, or the starting candidate
-// met again).  What keeps it tight is that pruning stays PER LANE: every lane computes its own bound of
-// each child box against its own best, and a subtree is entered iff at least one lane needs it (a ballot), its per-lane bounds
-// parked in LDS for the re-check at pop time.  The wave therefore visits the UNION of its lanes' walks -- for 64 Morton
-// neighbours little more than one lane's walk -- and a wave that straddles a jump of the Z-curve pays for two compact groups, not
-// for the box around both (round 1's wave-cooperative form pruned against the group's box and worst best: 77 ms).  Lanes that do
-// not need a visited leaf test its points anyway: harmless for a lexicographic minimum.  Exactness is the per-lane rule
-// unchanged: a lane's true neighbour lies in a subtree that lane needs at every level, so the wave enters it.
-// Call with any subset of a wave's lanes active; `slot` is the lane's column in st_lb.
-template <bool FMA, bool STATS>
-__device__ __forceinline__ void tree_walk_wave(const NnTreeView& t, const float p[3], float& best, unsigned int& bidx,
-                                               float* __restrict__ st_lb, int stride, int slot, unsigned int& n_nodes, unsigned int& n_leaves)
+// The hierarchy walk: ONE walk per wave for the (up to 64) points of its active lanes, each lane starting from its own candidate
+// (best, bidx) -- a REAL candidate's key or (inf, 0) -- and ending with the lexicographic minimum over it and every point of the
+// hierarchy.  Node and level are wave-uniform, so boxes and leaf points arrive through SCALAR loads and feed the VALU as SGPR
+// operands (like the every-pair kernel), control flow is uniform, and all active lanes are busy on every box and every point.
+// What keeps it tight is that pruning stays PER LANE: every lane computes its own bound of each child box against its own best,
+// and a subtree is entered iff at least one lane needs it (a ballot).  The wave therefore visits the UNION of its lanes' walks --
+// for 64 Morton neighbours a few times one lane's walk -- and a wave that straddles a jump of the Z-curve pays for two compact
+// groups, not for the box around both (round 1's wave-cooperative form pruned against the group's box and worst best: 77 ms
+// per search).  Lanes that do not need a visited leaf test its points anyway: harmless for a lexicographic minimum.
+// EIGHT children per step: the implicit heap keeps the 2^k descendants k levels below a node CONTIGUOUS (nodes ((n + 1) << k) - 1
+// ...), so one step fetches eight boxes (192 bytes, three s_load_dwordx16), tests them all per lane and goes three levels down.
+// (A binary step per level -- 48-byte sibling records, per-lane bounds parked in LDS -- measured the same time with three times
+// the dependent loads: the walk is bound by vector-instruction issue, ~180 per wide step and ~150 per leaf, not by latency.)
+// State: node and wide level (wave-uniform) and, per wide level, an 8-bit mask of the children still to visit (one 64-bit
+// scalar: no LDS at all).  The winner is tracked by its sorted SLOT; the global index is fetched once at the end -- and on an
+// exact tie, where the lower GLOBAL index must win (rare: duplicates, or the starting candidate met again).  Children that are
+// leaves are scanned inside the step that tested their boxes, each re-checked against the bests as they stand then; interior children wait in the mask and are entered without a re-check (their own step
+// prunes).  First the child that is nearest for most lanes, then the others in index order.  Exactness is the per-lane rule
+// unchanged: a lane's true neighbour lies in a child that lane needs at every step, needed children are never dropped, skipped
+// ones have a bound strictly above that lane's best.  Call with any subset of a wave's lanes active.
+template <bool FMA>
+__device__ __forceinline__ float box6_bound(const float* __restrict__ b, const float s[3])
 {
-    const float4* __restrict__ pairs = t.pairs;
+    const float ex = fmaxf(fmaxf(b[0] - s[0], s[0] - b[3]), 0.f);
+    const float ey = fmaxf(fmaxf(b[1] - s[1], s[1] - b[4]), 0.f);
+    const float ez = fmaxf(fmaxf(b[2] - s[2], s[2] - b[5]), 0.f);
+    return sq3<FMA>(ex, ey, ez);
+}
+
+template <bool FMA, bool STATS>
+__device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float p[3], float& best, unsigned int& bidx,
+                                               unsigned int& n_nodes, unsigned int& n_leaves)
+{
+    const float* __restrict__ boxes6 = t.boxes6;
     const float4* __restrict__ leaf_soa = t.leaf_soa;
     const int* __restrict__ leaf_idx = t.leaf_idx;
-    const int first_leaf = t.n_pad - 1;
+    const int H = t.height, first_leaf = t.n_pad - 1;
     const float inf = __builtin_inff();
     int bslot = -1;                                            // >= 0: the winner's sorted slot; < 0: bidx is the winner
-    unsigned int trail = 0;                                    // wave-uniform from here on
-    int node = 0, level = 0;
-    const float root_lb = box_bound<FMA>(t.boxes[0], t.boxes[1], p);
-    bool have = __builtin_amdgcn_ballot_w64(root_lb <= best && root_lb < inf) != 0ull;
-    auto pop = [&]() {
-        have = false;
-        while (trail != 0) {
-            const int b = 31 - __builtin_clz(trail);              // deepest pending level
-            trail &= ~(1u << b);
-            const int anc = ((node + 1) >> (level - b)) - 1;      // the wave's ancestor at level b ...
-            node = ((anc + 1) ^ 1) - 1;                           // ... its sibling is the pending subtree
-            level = b;
-            if (__builtin_amdgcn_ballot_w64(st_lb[b * stride + slot] <= best) != 0ull) { have = true; break; }
-        }
-    };
     auto offer = [&](float d, int s) {                          // s is wave-uniform
         const bool tie = d == best;
         const bool lt = d < best;
@@ -107,41 +105,98 @@ __device__ __forceinline__ void tree_walk_wave(const NnTreeView& t, const float 
             if (j < jb) bslot = s;
         }
     };
-    while (have) {
-        while (have && node < first_leaf) {
-            const int un = __builtin_amdgcn_readfirstlane(node);   // uniform by construction; say so, so the loads below are scalar
-            if (STATS) n_nodes += 1;
-            const float4* __restrict__ rec = pairs + 3 * (size_t)un;
-            const float4 a = rec[0], b = rec[1], c = rec[2];
-            const float lbl = box_bound<FMA>(make_float4(a.x, a.y, a.z, 0.f), make_float4(a.w, b.x, b.y, 0.f), p);
-            const float lbr = box_bound<FMA>(make_float4(b.z, b.w, c.x, 0.f), make_float4(c.y, c.z, c.w, 0.f), p);
-            const unsigned long long ml = __builtin_amdgcn_ballot_w64(lbl <= best && lbl < inf);
-            const unsigned long long mr = __builtin_amdgcn_ballot_w64(lbr <= best && lbr < inf);
-            if ((ml | mr) == 0ull) { pop(); continue; }
-            bool left_first = mr == 0ull;
-            if (ml != 0ull && mr != 0ull)                          // both needed: the child nearer to most lanes first
-                left_first = 2 * __builtin_popcountll(__builtin_amdgcn_ballot_w64(lbl <= lbr)) >= __builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
-            node = 2 * un + (left_first ? 1 : 2);
-            level += 1;
-            if (ml != 0ull && mr != 0ull) {
-                trail |= 1u << level;
-                st_lb[level * stride + slot] = left_first ? lbr : lbl;   // this lane's bound of the subtree left pending
-            }
-        }
-        if (have) {
-            const int leaf = __builtin_amdgcn_readfirstlane(node) - first_leaf;
-            if (STATS) n_leaves += 1;
-            const int slot0 = leaf * TREE_LEAF;
-            const float4* __restrict__ lp = leaf_soa + (size_t)leaf * (3 * TREE_LEAF / 4);
+    auto scan_leaf = [&](int leaf) {                            // leaf is wave-uniform: its points arrive through scalar loads
+        if (STATS) n_leaves += 1;
+        const int slot0 = leaf * TREE_LEAF;
+        const float4* __restrict__ lp = leaf_soa + (size_t)leaf * (3 * TREE_LEAF / 4);
 #pragma unroll
-            for (int c4 = 0; c4 < TREE_LEAF / 4; c4++) {
-                const float4 X = lp[c4], Y = lp[TREE_LEAF / 4 + c4], Z = lp[2 * (TREE_LEAF / 4) + c4];
-                offer(sq3<FMA>(X.x - p[0], Y.x - p[1], Z.x - p[2]), slot0 + 4 * c4);
-                offer(sq3<FMA>(X.y - p[0], Y.y - p[1], Z.y - p[2]), slot0 + 4 * c4 + 1);
-                offer(sq3<FMA>(X.z - p[0], Y.z - p[1], Z.z - p[2]), slot0 + 4 * c4 + 2);
-                offer(sq3<FMA>(X.w - p[0], Y.w - p[1], Z.w - p[2]), slot0 + 4 * c4 + 3);
+        for (int c4 = 0; c4 < TREE_LEAF / 4; c4++) {
+            const float4 X = lp[c4], Y = lp[TREE_LEAF / 4 + c4], Z = lp[2 * (TREE_LEAF / 4) + c4];
+            offer(sq3<FMA>(X.x - p[0], Y.x - p[1], Z.x - p[2]), slot0 + 4 * c4);
+            offer(sq3<FMA>(X.y - p[0], Y.y - p[1], Z.y - p[2]), slot0 + 4 * c4 + 1);
+            offer(sq3<FMA>(X.z - p[0], Y.z - p[1], Z.z - p[2]), slot0 + 4 * c4 + 2);
+            offer(sq3<FMA>(X.w - p[0], Y.w - p[1], Z.w - p[2]), slot0 + 4 * c4 + 3);
+        }
+    };
+    {
+        const float root_lb = box6_bound<FMA>(boxes6, p);
+        if (__builtin_amdgcn_ballot_w64(root_lb <= best && root_lb < inf) == 0ull) return;
+    }
+    if (H == 0) {
+        scan_leaf(0);
+    } else {
+        const int k0 = H % 3 == 0 ? 3 : H % 3;                  // binary levels of the root step; every later step takes three
+        unsigned long long pend = 0ull;                         // byte w: children of the wave's wide-level-w ancestor still to visit
+        int node = 0, wl = 0, level = 0;                        // wave-uniform
+        bool have = true;
+        while (have) {
+            const int un = __builtin_amdgcn_readfirstlane(node);   // uniform by construction; say so, so the loads below are scalar
+            const int k = wl == 0 ? k0 : 3;
+            const int base = ((un + 1) << k) - 1;                   // first of the 2^k descendants k levels down
+            const int clevel = level + k;
+            if (STATS) n_nodes += 1;
+            const float* __restrict__ bp = boxes6 + (size_t)base * 6;
+            float lb[8];
+            unsigned int mask = 0u;
+            // (a root step of fewer than three levels reads boxes past its children: masked off below)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                lb[j] = box6_bound<FMA>(bp + 6 * j, p);
+                // lb <= best implies lb < inf unless best is inf itself (a lane without a candidate yet): then the empty padding
+                // boxes (bound inf) must be kept out explicitly
+                if (__builtin_amdgcn_ballot_w64(lb[j] <= best && lb[j] < inf) != 0ull) mask |= 1u << j;
             }
-            pop();
+            mask &= (1u << (1 << k)) - 1u;
+            bool descend = false;
+            if (clevel == H) {
+                // the children are leaves: scan the needed ones now, each re-checked against the bests as they stand
+                // (one copy of the scan code: a loop over the set bits, the bound picked by a select chain)
+#pragma unroll 1
+                for (unsigned int m = mask; m != 0u; m &= m - 1u) {
+                    const int j = __builtin_ctz(m);
+                    float lbj = lb[0];
+#pragma unroll
+                    for (int c = 1; c < 8; c++) lbj = j == c ? lb[c] : lbj;
+                    if (__builtin_amdgcn_ballot_w64(lbj <= best) != 0ull) scan_leaf(base + j - first_leaf);
+                }
+            } else if (mask != 0u) {
+                // first the child that is the nearest one for most lanes -- worth a vote only while some lane has no candidate
+                // yet (a good first descent is all its pruning); lanes that came with one prune by it whatever the order
+                int f = __builtin_ctz(mask);
+                if (__builtin_amdgcn_ballot_w64(!(best < inf)) != 0ull) {
+                    float minb = inf;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) minb = ((mask >> j) & 1u) ? fminf(minb, lb[j]) : minb;
+                    int fv = -1;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int v = ((mask >> j) & 1u) ? (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lb[j] == minb)) : -1;
+                        if (v > fv) { fv = v; f = j; }
+                    }
+                }
+                const unsigned long long rest = (unsigned long long)(mask & ~(1u << f));
+                pend = (pend & ~(0xffull << (8 * wl))) | (rest << (8 * wl));
+                node = base + f;
+                level = clevel;
+                wl += 1;
+                descend = true;
+            }
+            if (!descend) {
+                // next pending child, deepest wide level first
+                have = pend != 0ull;
+                if (have) {
+                    const int w = (63 - __builtin_clzll(pend)) >> 3;
+                    const unsigned int slot = (unsigned int)(pend >> (8 * w)) & 0xffu;
+                    const int j = __builtin_ctz(slot);
+                    pend &= ~(1ull << (8 * w + j));
+                    const int lw = w == 0 ? 0 : k0 + 3 * (w - 1);   // binary level of wide level w
+                    const int parent = ((un + 1) >> (level - lw)) - 1;   // the wave's ancestor there
+                    const int kw = w == 0 ? k0 : 3;
+                    node = ((parent + 1) << kw) - 1 + j;
+                    level = lw + kw;
+                    wl = w + 1;
+                }
+            }
         }
     }
     if (bslot >= 0) bidx = (unsigned int)leaf_idx[bslot];
