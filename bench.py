@@ -4,20 +4,28 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--points P]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step is ONE ICP iteration of the hot path (exact nearest-neighbour search -- K1t, the box hierarchy, at this size; K1, every
-pair, with --nn brute --, moments K2, SVD solve K3, transform + error K4/K5, stop rule K6) on clouds already resident in HBM.
-The stop rule runs on the device every step but never fires (eps = 0).  With N > 1 the problem is fixed ("scaling":
-"strong"): the moving cloud is sharded over the ranks for the box hierarchy (one 18-double RCCL sum all-reduce per iteration),
-the fixed cloud for the every-pair search (plus a ncclMin all-reduce of the packed keys), all inside libmislam.so over xGMI;
-torch.distributed (gloo) is only the bootstrap / barrier / max.
+A step is ONE ICP iteration of the hot path on clouds already resident in HBM: three launches on the default path -- the fused
+search kernel (transform, previous iteration's error sums, exact nearest-neighbour search through the cell grid with the
+box-hierarchy fallback, moments of the new pairs), the rows reduction, and the solve kernel (previous iteration's stop rule,
+3x3 SVD Kabsch, compose).  The stop rule runs on the device every step but never fires (eps = 0).  With N > 1 the problem is
+fixed ("scaling": "strong"): the moving cloud is sharded over the ranks for the indexed searches (one 18-double RCCL sum
+all-reduce per iteration), the fixed cloud for the every-pair search (plus a ncclMin all-reduce of the packed keys), all inside
+libmislam.so over xGMI; torch.distributed (gloo) is only the bootstrap / barrier / max.
 
-Rank 0 prints one JSON line.  `roofline` is the search kernel of the timed steps: algorithmic bytes (20*N + 12*M_local, SURVEY
-8d) over its HIP-event-timed average launch; `bruteforce_nn` gives the every-pair kernel on the same clouds with `valu`, its
-launch against the fp32 vector-issue rate (what actually bounds a brute-force search); `cpd_bunny` is the CPD leg of the
-metric.  `cpu_baseline` times the REFERENCE's own GetCorrespondingPoints (oracle/_ref, all host threads) on a bounded sample of
-source rows and scales it to a full iteration.
+Rank 0 prints one JSON line.
+  roofline        the search kernel of the timed steps: algorithmic bytes (20*N + 12*M_local) over its HIP-event-timed
+                  average launch; `issue` beside it is what actually bounds that kernel (vector-instruction issue), from the
+                  committed counter profile of this command
+  sizes           the same measurement at N = M = 1e4, 1e5, 1e7 (BASELINE.json: "N = 10^4 ... 10^7"), a few steps each
+  bruteforce_nn   the every-pair kernel on the same clouds with `valu`, its launch against the fp32 vector-issue rate
+  target_sharded  N > 1 only: cfg 3's split -- fixed cloud sharded, every-pair search, ncclAllReduce(u64, min) of the keys
+  rccl            N > 1 only: what the communicator itself reports (ranks, bit mask of ranks seen in one all-reduce)
+  cpd_bunny       the CPD leg of the metric (cfg 4), with its own roofline object
+  cpu_baseline    the REFERENCE's own GetCorrespondingPoints (oracle/_ref, all host threads) on a bounded sample of source rows,
+                  scaled to a full iteration
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -28,7 +36,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD-32 x 2.4 GHz: fp32 lane-instructions/s (= 157.3 TFLOP/s / 2)
+VALU_WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 2  # a wave64 instruction occupies a SIMD-32 for two cycles (MI355X_MICROARCH.md constants)
 OPS_PER_PAIR = {0: 8.5, 1: 6.5}            # 3 sub + 3 mul + 2 add (or 1 mul + 2 fma) + 1/2 min3, per candidate pair
+SWEEP_SIZES = (10000, 100000, 10000000)
 
 
 def synth_cloud(np, n, seed=666):
@@ -44,18 +54,18 @@ def synth_cloud(np, n, seed=666):
     return before, after
 
 
-def committed_traffic(workload, kernel):
-    """HBM bytes per NN launch from the committed rocprofv3 --pmc summary of this same command (profiles/), if there is one
-    for this workload and kernel: bench.py cannot run the counter passes itself (they need their own rocprofv3 runs)."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_counters.json")), reverse=True):
+def committed_profile(workload, kernel, steps, warmup):
+    """The committed rocprofv3 --pmc summary (profiles/*_counters.json) for this workload and kernel, and whether it was taken
+    with THIS run's --steps / --warmup (the search's cost depends on which iterations are timed).  bench.py cannot run counter
+    passes itself: they need their own rocprofv3 runs (tools/gpu_suite_and_profiles.sh)."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
             continue
-        if d.get("workload") == workload and kernel in d:
-            return d[kernel].get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
-    return None, None
+        if d.get("workload") == workload and d.get("kernel") == kernel:
+            return d, os.path.relpath(path, ROOT), (d.get("steps") == steps and d.get("warmup") == warmup)
+    return None, None, False
 
 
 def cpu_baseline(np, before, after, target_seconds=15.0):
@@ -99,6 +109,7 @@ def cpd_bunny(np, capi, ctx, world):
         p = capi.cpd_params(max_iterations=50, sigma2_init=g["sigma2_init"], approximation=approx)
         ctx.cpd_register(before, after, p)                       # warm-up: allocations, code load
         ctx.profile_enable(True)
+        ctx.profile_select(None)
         ctx.profile_reset()
         t0 = time.perf_counter()
         sR, t, scale, it, err = ctx.cpd_register(before, after, p)
@@ -111,9 +122,21 @@ def cpd_bunny(np, capi, ctx, world):
             f = g["final_scale_free"]
             leg["frobenius_vs_cpu_slam"] = float(np.sqrt(((sR - np.array(f["sR"])) ** 2).sum() + ((t - np.array(f["t"])) ** 2).sum()))
             leg["iterations_cpu_slam"] = f["iterations"]
-            den = prof["cpd_denom"]
+            den, con = prof["cpd_denom"], prof["cpd_contract"]
             if den[1] > 0:
                 leg["estep_pairs_per_s"] = pairs / world / (den[0] / den[1] * 1e-3)   # K7a: this rank's share of the N*M affinities
+            # roofline of the E-step (K7a + K7b: the affinity is evaluated twice, P is never stored): fp32 vector issue.  Lane
+            # operations per pair are MEASURED (SQ_INSTS_VALU of the committed counter profile / pairs), not estimated.
+            prof_c, src, _ = committed_profile("cpd_bunny_14904", "cpd_estep", None, None)
+            if prof_c is not None and den[1] > 0 and con[1] > 0 and world == 1:
+                ops = prof_c["valu_lane_ops_per_pair_both_passes"]
+                t_estep = (den[0] / den[1] + con[0] / con[1]) * 1e-3
+                achieved = pairs * ops / t_estep                         # lane-operations/s
+                leg["roofline"] = {"bound": "fp32-valu-issue", "achieved": achieved, "peak": VALU_LANE_OPS_PEAK, "unit": "lane-ops/s",
+                                   "frac": achieved / VALU_LANE_OPS_PEAK, "ops_per_pair": ops, "ops_per_pair_source": src,
+                                   "kernels": "cpd_denominator_kernel + cpd_contract_mfma_kernel",
+                                   "note": "vector lane-operations per (x, y_k) pair over both passes, MEASURED (SQ_INSTS_VALU x 64 / pairs); "
+                                           "the 4 FMAs per pair of the contraction run on the matrix pipe (MFMA 4x4x1) and are not in it"}
         out[label] = leg
     return out
 
@@ -121,18 +144,18 @@ def cpd_bunny(np, capi, ctx, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # default: iterations 3..52 of one registration -- the reference's own performance set runs 50 iterations per
-    # registration (testset.cpp:101).  The search is data-dependent: early iterations (clouds far apart) cost ~1.15 ms, late
-    # ones ~0.7 ms at N = M = 1e6; a 10-step run right after the warm-up sees only the early ones.
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=2)
+    # default: iterations 6..25 of one registration (what the driver's own command line asks for); the search is data-dependent:
+    # in early iterations a third of the moving cloud still lies outside the fixed one and walks the box hierarchy
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=1000000, help="N = M, BASELINE.json: 10^6")
     ap.add_argument("--dist-mode", type=int, default=0, help="0 = cpu-slam rounding (parity default), 1 = fma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sizes", action="store_true", help="skip the N = 1e4 / 1e5 / 1e7 legs")
     ap.add_argument("--shard", choices=["auto", "target", "source"], default="auto",
-                    help="what N > 1 GPUs split: auto = moving cloud for the box hierarchy, fixed cloud for the every-pair search")
+                    help="what N > 1 GPUs split: auto = moving cloud for the indexed searches, fixed cloud for the every-pair search")
     ap.add_argument("--brute-ref-steps", type=int, default=2,
-                    help="untimed every-pair steps measured after the timed region when the box hierarchy was used (0 = skip)")
+                    help="untimed every-pair steps measured after the timed region when an indexed search was used (0 = skip)")
     ap.add_argument("--nn", choices=["auto", "brute", "tree", "grid"], default="auto",
                     help="search strategy (identical results): auto = the library default (cell grid at this size)")
     args = ap.parse_args()
@@ -159,9 +182,6 @@ def main():
     import numpy as np
     from __graft_entry__ import load_package
     capi = load_package().capi
-
-    before, after = synth_cloud(np, args.points)
-    n, m = len(before), len(after)
 
     # Rehearsal of the N > 1 flow on a box with ONE GPU (tools/gpu_dist_rehearsal.sh): MISLAM_BENCH_DEVICE pins every rank to
     # that device and MISLAM_BENCH_TRANSPORT=gloo swaps RCCL (which refuses two ranks on one device) for the caller's-transport
@@ -194,45 +214,68 @@ def main():
             dist.barrier()
         ctx.synchronize()
 
-    # eps = 0: the device-side stop rule is evaluated every step and never fires -> every step is a full iteration
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        import torch
+        tt = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     nn_mode = {"auto": capi.NN_AUTO, "brute": capi.NN_BRUTEFORCE, "tree": capi.NN_TREE, "grid": capi.NN_GRID}[args.nn]
     shard_mode = {"auto": capi.SHARD_AUTO, "target": capi.SHARD_TARGET, "source": capi.SHARD_SOURCE}[args.shard]
-    # what the library will do with these settings (mi_slam.h MI_NN_AUTO / MI_SHARD_AUTO), for the report below
-    per_rank_m = m // world
-    tree_if = lambda mm: args.nn in ("tree", "grid") or (args.nn == "auto" and mm >= capi.NN_INDEX_MIN_POINTS)
-    source_sharded = use_dist and (args.shard == "source" or (args.shard == "auto" and tree_if(m)))
-    if source_sharded:
-        slo, shi = capi.shard_range(n, rank, world)
-        n_local, m_local = shi - slo, m
-    else:
-        lo, hi = capi.shard_range(m, rank, world)
-        n_local, m_local = n, hi - lo
-    used_tree = tree_if(m_local)
-    tree_kernel = ctx.nn_kernel_name(n_local, m_local, capi.NN_TREE if args.nn == "tree" else capi.NN_GRID)
-    params = capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=nn_mode, shard_mode=shard_mode)
-    ctx.icp_load(before, after, params)            # H2D upload + SoA conversion: outside the timed region
-    if args.warmup > 0:
-        ctx.icp_run(args.warmup)
-    # HIP events around the dominant kernel (the search) only inside the timed region: the roofline figures are measured live
-    # on the very launches that are timed, without paying for ten event records per step on the small kernels
-    ctx.profile_enable(True)
-    ctx.profile_select([capi.KERNEL_NN])
-    ctx.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    done = ctx.icp_run(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    assert done == args.steps, "ran %d of %d steps" % (done, args.steps)
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
 
-    prof = {capi.KERNEL_NAMES[k]: ctx.profile_get(k) for k in range(len(capi.KERNEL_NAMES))}
+    def plan(n, m, nn_choice, shard_choice):
+        """What the library will do with these settings (mi_slam.h MI_NN_AUTO / MI_SHARD_AUTO): local sizes, kernel, split."""
+        indexed_if = lambda mm: nn_choice in ("tree", "grid") or (nn_choice == "auto" and mm >= capi.NN_INDEX_MIN_POINTS)
+        source_sharded = use_dist and (shard_choice == "source" or (shard_choice == "auto" and indexed_if(m)))
+        if source_sharded:
+            slo, shi = capi.shard_range(n, rank, world)
+            n_local, m_local = shi - slo, m
+        else:
+            lo, hi = capi.shard_range(m, rank, world)
+            n_local, m_local = n, hi - lo
+        indexed = indexed_if(m_local)
+        mode = {"auto": capi.NN_AUTO, "brute": capi.NN_BRUTEFORCE, "tree": capi.NN_TREE, "grid": capi.NN_GRID}[nn_choice]
+        return {"n_local": n_local, "m_local": m_local, "indexed": indexed, "source_sharded": source_sharded,
+                "kernel": ctx.nn_kernel_name(n_local, m_local, mode)}
+
+    def nn_figures(pl, nn_ms, nn_n):
+        nn_avg_s = nn_ms / max(nn_n, 1) * 1e-3
+        alg_bytes = 20.0 * pl["n_local"] + 12.0 * pl["m_local"]   # this rank: 12 B source xyz + 8 B packed key per moving point, 12 B per fixed point
+        achieved_gbs = alg_bytes / nn_avg_s / 1e9
+        return {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                "traffic": None, "kernel": pl["kernel"], "avg_launch_ms": nn_avg_s * 1e3, "launches": nn_n,
+                "algorithmic_bytes_per_launch": alg_bytes}
+
+    def timed_run(before, after, params, warmup, steps):
+        """load (untimed) -> warm-up iterations -> `steps` iterations between barriers, HIP events around the search kernel only."""
+        ctx.icp_load(before, after, params)            # H2D upload, SoA conversion, index build: outside the timed region
+        if warmup > 0:
+            ctx.icp_run(warmup)
+        ctx.profile_enable(True)
+        ctx.profile_select([capi.KERNEL_NN])
+        ctx.profile_reset()
+        barrier()
+        t0 = time.perf_counter()
+        done = ctx.icp_run(steps)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        assert done == steps, "ran %d of %d steps" % (done, steps)
+        nn = ctx.profile_get(capi.KERNEL_NN)
+        ctx.profile_enable(False)
+        return elapsed, nn
+
+    # ------------------------------------------------------------------------------------------------ headline: N = M = --points
+    before, after = synth_cloud(np, args.points)
+    n, m = len(before), len(after)
+    pl = plan(n, m, args.nn, args.shard)
+    # eps = 0: the device-side stop rule is evaluated every step and never fires -> every step is a full iteration
+    params = capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=nn_mode, shard_mode=shard_mode)
+    elapsed, nn_prof = timed_run(before, after, params, args.warmup, args.steps)
     R, t, iters, err, why = ctx.icp_result()
     # per-kernel breakdown of a step: a few more (untimed) iterations with events around every kernel
+    ctx.profile_enable(True)
     ctx.profile_select(None)
     ctx.profile_reset()
     extra = ctx.icp_run(min(args.steps, 5))
@@ -241,15 +284,67 @@ def main():
 
     # Outside the timed region: the same steps with the every-pair search (K1), for the brute-force roofline figures the
     # north star asks for.  Same keys, same registration -- only the number of evaluated pairs differs.
-    brute_prof = None
-    if used_tree and args.brute_ref_steps > 0:
+    brute_fig = None
+    if pl["indexed"] and args.brute_ref_steps > 0:
+        bpl = plan(n, m, "brute", "source" if pl["source_sharded"] else "target")
         ctx.icp_load(before, after, capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=capi.NN_BRUTEFORCE,
-                                                    shard_mode=capi.SHARD_SOURCE if source_sharded else capi.SHARD_TARGET))
+                                                    shard_mode=capi.SHARD_SOURCE if pl["source_sharded"] else capi.SHARD_TARGET))
         ctx.icp_run(1)
         ctx.profile_reset()
         ctx.icp_run(args.brute_ref_steps)
-        brute_prof = ctx.profile_get(capi.KERNEL_NN)
+        bp = ctx.profile_get(capi.KERNEL_NN)
+        brute_fig = nn_figures(bpl, bp[0], bp[1])
+        pairs_per_s = bpl["n_local"] * float(bpl["m_local"]) / (brute_fig["avg_launch_ms"] * 1e-3)
+        lane_ops = pairs_per_s * OPS_PER_PAIR[args.dist_mode]
+        brute_fig["valu"] = {"bound": "fp32-valu-issue", "achieved": lane_ops, "peak": VALU_LANE_OPS_PEAK, "unit": "lane-ops/s",
+                             "frac": lane_ops / VALU_LANE_OPS_PEAK, "pairs_per_s": pairs_per_s,
+                             "ops_per_pair": OPS_PER_PAIR[args.dist_mode]}
+        brute_fig["note"] = "every-pair search: fp32-VALU-bound (see valu), its compulsory HBM bytes are ~4 us of bandwidth"
     ctx.profile_enable(False)
+
+    # cfg 3 as BASELINE.json words it: fixed cloud sharded across the ranks, every-pair search, ONE ncclAllReduce(ncclUint64,
+    # ncclMin) of the N packed (min-dist, argmin) keys per iteration.  Event-timed, outside the headline (the indexed search with
+    # a sharded MOVING cloud is what the headline measures, because it is two orders of magnitude faster).
+    target_leg, rccl = None, None
+    if use_dist:
+        ctx.icp_load(before, after, capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=capi.NN_BRUTEFORCE,
+                                                    shard_mode=capi.SHARD_TARGET))
+        ctx.icp_run(1)
+        ctx.profile_enable(True)
+        ctx.profile_select(None)
+        ctx.profile_reset()
+        barrier()
+        t0 = time.perf_counter()
+        ctx.icp_run(2)
+        barrier()
+        t_leg = max_over_ranks(time.perf_counter() - t0)
+        ar, nnp = ctx.profile_get(capi.KERNEL_ALLREDUCE), ctx.profile_get(capi.KERNEL_NN)
+        ctx.profile_enable(False)
+        lo, hi = capi.shard_range(m, rank, world)
+        target_leg = {"nn": "bruteforce", "shard": "fixed cloud, rank 0 holds [%d, %d)" % (lo, hi), "steps": 2,
+                      "ms_per_step": t_leg / 2 * 1e3, "nn_kernel_ms": nnp[0] / max(nnp[1], 1),
+                      "allreduce_u64_min": {"launches": ar[1], "ms_per_launch": ar[0] / max(ar[1], 1), "payload_bytes": 8 * n,
+                                            "collective": "ncclAllReduce(ncclUint64, ncclMin) on the context's stream (mislam_api.hip allreduce_min_u64)"
+                                                          if rehearsal_transport != "gloo" else "caller's transport (gloo rehearsal)"}}
+        nr, rk, seen = ctx.dist_info()
+        rccl = {"nranks": nr, "rank0_sees_rank": rk, "ranks_seen_mask": seen, "ranks_seen": bin(seen).count("1"),
+                "transport": "rccl" if rehearsal_transport != "gloo" else "gloo exchange context (rehearsal)"}
+
+    # The other sizes BASELINE.json names, a few steps each (same recipe, same rules; 1e7 costs ~2 s of host-side generation)
+    sizes = None
+    if not args.no_sizes:
+        sizes = {}
+        for sn in SWEEP_SIZES:
+            if sn == n:
+                continue
+            sb, sa = synth_cloud(np, sn)
+            spl = plan(sn, sn, args.nn, args.shard)
+            s_el, s_nn = timed_run(sb, sa, params, 5, 10)
+            fig = nn_figures(spl, s_nn[0], s_nn[1])
+            sizes[str(sn)] = {"iterations_per_s": 10 / s_el, "ms_per_step": s_el / 10 * 1e3, "steps": 10, "warmup": 5,
+                              "nn_kernel": fig["kernel"], "nn_avg_launch_ms": fig["avg_launch_ms"], "hbm_achieved_GBs": fig["achieved"],
+                              "hbm_frac": fig["frac"]}
+            del sb, sa
 
     # Outside the timed region as well: the CPD leg of BASELINE.json's metric ("CPD E-step on bunny"), cfg 4 on the committed
     # bunny clouds from cpu-slam's own sigma^2_0 -- exact P and the parser's default hybrid mode.  One GPU by default; with
@@ -258,48 +353,54 @@ def main():
     if world == 1 or os.environ.get("MISLAM_BENCH_CPD") == "1":
         cpd = cpd_bunny(np, capi, ctx, world)
 
-    def nn_figures(nn_ms, nn_n, brute):
-        nn_avg_s = nn_ms / max(nn_n, 1) * 1e-3
-        alg_bytes = 20.0 * n_local + 12.0 * m_local    # this rank: 12 B source xyz + 8 B packed key per moving point, 12 B per fixed point
-        achieved_gbs = alg_bytes / nn_avg_s / 1e9
-        fig = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-               "traffic": None, "kernel": "nn_bruteforce_kernel" if brute else tree_kernel,
-               "avg_launch_ms": nn_avg_s * 1e3, "launches": nn_n, "algorithmic_bytes_per_launch": alg_bytes}
-        if world == 1 and args.dist_mode == 0:
-            fig["traffic"], fig["traffic_source"] = committed_traffic("icp_synthetic_uniform_n%d" % n, fig["kernel"])
-        if brute:
-            pairs_per_s = n_local * float(m_local) / nn_avg_s
-            lane_ops = pairs_per_s * OPS_PER_PAIR[args.dist_mode]
-            fig["valu"] = {"bound": "fp32-valu-issue", "achieved": lane_ops, "peak": VALU_LANE_OPS_PEAK, "unit": "lane-ops/s",
-                           "frac": lane_ops / VALU_LANE_OPS_PEAK, "pairs_per_s": pairs_per_s,
-                           "ops_per_pair": OPS_PER_PAIR[args.dist_mode]}
-            fig["note"] = "every-pair search: fp32-VALU-bound (see valu), its compulsory HBM bytes are ~4 us of bandwidth"
-        else:
-            fig["note"] = ("exact box-hierarchy search: latency/L2-bound pointer chasing; algorithmic bytes are the same "
-                           "20N+12M as for the every-pair kernel it replaces")
-        return fig
-
     if rank == 0:
+        workload = "icp_synthetic_uniform_n%d" % n
+        roof = nn_figures(pl, nn_prof[0], nn_prof[1])
+        if pl["indexed"]:
+            roof["note"] = ("exact search through the cell grid (box-hierarchy walk for the lanes whose neighbour is farther than two cells): "
+                            "bound by vector-instruction issue, not by HBM -- see `issue`; algorithmic bytes are the same 20N+12M as for "
+                            "the every-pair kernel it replaces")
+        if world == 1 and args.dist_mode == 0:
+            prof_c, src, same_cmd = committed_profile(workload, roof["kernel"], args.steps, args.warmup)
+            if prof_c is not None:
+                # HBM bytes per launch from the committed counter passes.  Attached as `traffic` only when that profile was taken
+                # with this run's --steps / --warmup; otherwise it is kept apart, labelled as what it is.
+                key = "traffic" if same_cmd else "traffic_from_committed_profile"
+                roof[key] = prof_c.get("traffic_bytes_per_launch")
+                roof["traffic_source"] = src + (" (rocprofv3 --pmc passes of this same command, means per launch; not measured by this run)"
+                                                if same_cmd else " (taken with --steps %s --warmup %s)" % (prof_c.get("steps"), prof_c.get("warmup")))
+                if "valu_wave_instructions_per_launch" in prof_c:
+                    rate = prof_c["valu_wave_instructions_per_launch"] / (prof_c["avg_launch_ms"] * 1e-3)
+                    roof["issue"] = {"bound": "valu-issue", "achieved": rate, "peak": VALU_WAVE_INSTR_PEAK, "unit": "wave-instructions/s",
+                                     "frac": rate / VALU_WAVE_INSTR_PEAK, "lanes_active_of_64": prof_c.get("lanes_active_of_64"),
+                                     "l1_line_accesses_per_launch": prof_c.get("tcp_total_cache_accesses_per_launch"),
+                                     "source": src + ": SQ_INSTS_VALU per launch over that profile's own average launch time"}
         out = {
             "metric": "icp_iterations_per_s", "value": args.steps / elapsed, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "icp_synthetic_uniform_n%d" % n, "n_before": n, "n_after": m,
-                       "nn": ("box-hierarchy (exact)" if args.nn == "tree" else "cell-grid + box-hierarchy fallback (exact)") if used_tree else "bruteforce",
+            "config": {"workload": workload, "n_before": n, "n_after": m,
+                       "nn": ({"nn_tree_kernel": "box-hierarchy (exact)", "nn_grid_kernel": "cell-grid + box-hierarchy fallback (exact)"}
+                              .get(pl["kernel"], "bruteforce")),
                        "dist_arithmetic": "cpu_rounding" if args.dist_mode == 0 else "fma",
                        "compose": "cpu_additive",
                        "parallelism": ("single GPU" if world == 1 else
                                        "moving cloud sharded x%d, fixed cloud replicated, one 18-double RCCL sum all-reduce per iteration" % world
-                                       if source_sharded else
+                                       if pl["source_sharded"] else
                                        "fixed cloud sharded x%d, RCCL u64-min all-reduce of the packed keys + one 18-double sum per iteration" % world),
                        "error_after_steps": err},
-            "roofline": nn_figures(prof["nn"][0], prof["nn"][1], not used_tree),
+            "roofline": roof,
             "kernels_ms_per_step": breakdown,     # ms per launch, from the untimed follow-up iterations (every kernel event-timed)
         }
         if use_dist and rehearsal_transport == "gloo":
             out["rehearsal"] = "ranks share device %d over the gloo exchange context: flow check only, not a measurement" % local_rank
-        if brute_prof is not None:
-            out["bruteforce_nn"] = nn_figures(brute_prof[0], brute_prof[1], True)
+        if sizes is not None:
+            out["sizes"] = sizes
+        if brute_fig is not None:
+            out["bruteforce_nn"] = brute_fig
+        if target_leg is not None:
+            out["target_sharded"] = target_leg
+            out["rccl"] = rccl
         if cpd is not None:
             out["cpd_bunny"] = cpd
         if world == 1 and not args.no_cpu_baseline:
@@ -309,7 +410,9 @@ def main():
     ctx.close()
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        destroy = getattr(dist, "destroy_process_group", None)
+        if destroy:
+            destroy()
 
 
 if __name__ == "__main__":

@@ -32,7 +32,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int) 
 # every symbol include/mi_slam.h declares (tests check that the library exports each of them)
 EXPORTS = [
     "mi_abi_version", "mi_last_error", "mi_device_count", "mi_ctx_create", "mi_dist_unique_id", "mi_ctx_create_dist",
-    "mi_ctx_create_exchange", "mi_ctx_preload", "mi_ctx_rank", "mi_shard_range", "mi_pack_key", "mi_unpack_key", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_icp_params_default", "mi_icp_params_cuda_slam",
+    "mi_ctx_create_exchange", "mi_ctx_preload", "mi_ctx_rank", "mi_dist_info", "mi_shard_range", "mi_pack_key", "mi_unpack_key", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_icp_params_default", "mi_icp_params_cuda_slam",
     "mi_icp_register", "mi_icp_load", "mi_icp_reset", "mi_icp_run", "mi_icp_result", "mi_nn_search", "mi_nn_search_ex", "mi_kabsch",
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_estep",
     "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
@@ -240,6 +240,12 @@ class Context:
         r, w = C.c_int(0), C.c_int(0)
         _check(lib().mi_ctx_rank(self._h, C.byref(r), C.byref(w)))
         return r.value, w.value
+
+    def dist_info(self):
+        """(nranks, rank) as the transport reports them and the bit mask of ranks seen in one all-reduce (collective call)."""
+        n, r, seen = C.c_int(0), C.c_int(0), C.c_ulonglong(0)
+        _check(lib().mi_dist_info(self._h, C.byref(n), C.byref(r), C.byref(seen)))
+        return n.value, r.value, int(seen.value)
 
     # ---- ICP
     def icp_register(self, before, after, params):

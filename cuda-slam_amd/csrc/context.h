@@ -126,6 +126,8 @@ struct mi_ctx {
     bool tree_valid = false;
     mislam::DevBuf<float4> gpts;                         // cell grid (nn_grid.h): points sorted by cell
     mislam::DevBuf<unsigned int> gstart, gfill, gscan;   // cell offsets, build cursors, scan scratch
+    mislam::DevBuf<unsigned int> gslot_of;               // fixed point -> its slot in gpts
+    mislam::DevBuf<unsigned int> match_slot;             // fused ICP: per moving point, the slot of its current match
     mislam::NnGridView grid{};
     bool grid_valid = false;
     mislam::DevBuf<int> sorder;                          // Morton order of the moving cloud (sorted slot -> caller's index)

@@ -185,6 +185,33 @@ extern "C" int mi_ctx_rank(const mi_ctx* ctx, int* rank, int* world)
     return MI_OK;
 }
 
+extern "C" int mi_dist_info(mi_ctx* c, int* nranks, int* rank, unsigned long long* ranks_seen)
+{
+    if (!c) { set_error("mi_dist_info: null context"); return MI_ERR_INVALID_ARG; }
+    MI_HIP(hipSetDevice(c->device));
+    int n = c->world, r = c->rank;
+    if (c->comm) {
+        MI_NCCL(ncclCommCount(c->comm, &n));
+        MI_NCCL(ncclCommUserRank(c->comm, &r));
+    }
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    if (ranks_seen) {
+        if (c->world > 52) { set_error("mi_dist_info: ranks_seen holds at most 52 ranks"); return MI_ERR_INVALID_ARG; }
+        // 2^rank is exact in a double, and so is any sum of distinct powers of two below 2^53: the SUM all-reduce of the moments
+        // path carries the mask
+        MI_TRY(c->rows_reduced.reserve(64 * 18));
+        const double mine = (double)(1ull << c->rank);
+        MI_HIP(hipMemcpyAsync(c->rows_reduced.p, &mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+        MI_TRY(allreduce_sum_f64(c, c->rows_reduced.p, 1));
+        double all = 0.0;
+        MI_HIP(hipMemcpyAsync(&all, c->rows_reduced.p, sizeof all, hipMemcpyDeviceToHost, c->stream));
+        MI_HIP(hipStreamSynchronize(c->stream));
+        *ranks_seen = (unsigned long long)all;
+    }
+    return MI_OK;
+}
+
 extern "C" int mi_shard_range(int m_total, int rank, int world, int* lo, int* hi)
 {
     if (m_total < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) { set_error("mi_shard_range: bad arguments"); return MI_ERR_INVALID_ARG; }
@@ -227,7 +254,7 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     c->tbbox.release(); c->tsort_temp.release(); c->tpts.release(); c->tboxes.release(); c->sorder.release(); c->sinv.release(); c->resid.release();
     c->tleaf.release(); c->tidx.release(); c->tboxes6.release(); c->nn_stats.release();
     c->gpts.release(); c->gstart.release(); c->gfill.release(); c->gscan.release(); c->rows.release(); c->rows_reduced.release();
-    c->sched_order.release(); c->sched_far.release(); c->sched_counters.release();
+    c->sched_order.release(); c->sched_far.release(); c->sched_counters.release(); c->gslot_of.release(); c->match_slot.release();
     for (auto& s : c->spans) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->d_state) (void)hipFree(c->d_state);
@@ -450,11 +477,14 @@ static int ensure_grid(mi_ctx* c, int m_local, int index_base)
     MI_TRY(c->gstart.reserve(n_cells + 1));
     MI_TRY(c->gfill.reserve(n_cells + 1));
     MI_TRY(c->gscan.reserve((n_cells + 1) / 1024 + 2));
+    MI_TRY(c->gslot_of.reserve((size_t)m_local));
     g.pts = c->gpts.p;
     g.cell_start = c->gstart.p;
+    g.slot_of = c->gslot_of.p;
+    g.index_base = index_base;
     GridBuildArgs a{};
     a.x = c->tx.p; a.y = c->ty.p; a.z = c->tz.p; a.m = m_local; a.index_base = index_base;
-    a.view = g; a.cell_fill = c->gfill.p; a.scan_tmp = c->gscan.p; a.pts_out = c->gpts.p; a.cell_start_out = c->gstart.p;
+    a.view = g; a.cell_fill = c->gfill.p; a.scan_tmp = c->gscan.p; a.pts_out = c->gpts.p; a.cell_start_out = c->gstart.p; a.slot_of_out = c->gslot_of.p;
     MI_HIP(grid_build(a, c->stream));
     c->grid = g;
     c->grid_valid = true;
@@ -664,6 +694,10 @@ extern "C" int mi_icp_reset(mi_ctx* c)
     MI_HIP(hipMemcpyAsync(c->cy.p, c->by.p, bytes, hipMemcpyDeviceToDevice, c->stream));
     MI_HIP(hipMemcpyAsync(c->cz.p, c->bz.p, bytes, hipMemcpyDeviceToDevice, c->stream));
     MI_HIP(fill_keys(c->keys.p, c->n, c->stream));
+    if (c->fused) {
+        MI_TRY(c->match_slot.reserve((size_t)c->n_pad));
+        MI_HIP(hipMemsetAsync(c->match_slot.p, 0xff, sizeof(unsigned int) * (size_t)c->n, c->stream));   // ~0u: no match yet
+    }
     MI_HIP(icp_schedule_reset(make_schedule(c), icp_row_count(c->n), c->stream));
     MI_HIP(hipStreamSynchronize(c->stream));
     return MI_OK;
@@ -772,7 +806,7 @@ static int icp_enqueue_iteration(mi_ctx* c)
         a.stats = c->nn_stats_on ? c->nn_stats.p : nullptr;
         a.state = c->d_state;
         a.bx = c->bx.p; a.by = c->by.p; a.bz = c->bz.p;
-        a.tgt4 = c->tgt4.p; a.shard_lo = c->shard_lo; a.shard_hi = c->shard_hi;
+        a.match_slot = c->match_slot.p; a.shard_lo = c->shard_lo; a.shard_hi = c->shard_hi;
         a.filter_pairs = c->icp.filter_pairs; a.max_distance_squared = c->icp.max_distance_squared;
         a.rows = c->rows.p;
         a.order = c->sched_order.p; a.far = c->sched_far.p;

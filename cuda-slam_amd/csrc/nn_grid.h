@@ -25,6 +25,8 @@ constexpr int GRID_CAND_BUDGET = 640;      // candidates a lane may test in the 
 struct NnGridView {
     const float4* pts;                     // the m fixed points sorted by cell (row-major: x fastest), w = GLOBAL index bits
     const unsigned int* cell_start;        // nx*ny*nz + 1 offsets into pts
+    const unsigned int* slot_of;           // local index of a fixed point (global - index_base) -> its slot in pts
+    int index_base;                        // global index of this shard's point 0
     float ox, oy, oz;                      // lower corner of the bounding box
     float inv_h;                           // cells per unit length; cell coordinate of p on an axis: floor((p - o) * inv_h)
     float h_lo;                            // a hair less than 1 / inv_h: turns a gap in cells into a safe lower bound in length
@@ -44,6 +46,7 @@ struct GridBuildArgs {
     unsigned int* scan_tmp;                // scan scratch: (n_cells + 1) / 1024 + 2 words
     float4* pts_out;
     unsigned int* cell_start_out;
+    unsigned int* slot_of_out;
 };
 hipError_t grid_build(const GridBuildArgs& a, hipStream_t s);
 
@@ -61,7 +64,9 @@ struct GridSearchArgs {
     // fused ICP iteration
     IcpState* state;
     const float *bx, *by, *bz;             // the ORIGINAL moving cloud (Morton-sorted), SoA
-    const float4* tgt4;                    // fixed cloud as float4, caller's order (local index = global - shard_lo)
+    unsigned int* match_slot;              // per moving point: slot (NnGridView::pts) of its current match, ~0u = none.  The fixed
+                                           // cloud's caller order is random, so gathering matches from it costs a cache line per
+                                           // point; pts is sorted by cell and neighbours' matches share lines
     int shard_lo, shard_hi;
     int filter_pairs;
     float max_distance_squared;

@@ -189,13 +189,14 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(const unsigned int* __r
 // search takes a lexicographic (distance, GLOBAL index) minimum.
 __global__ __launch_bounds__(256) void grid_scatter_kernel(NnGridView g, const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ z, int m, int index_base, unsigned int* __restrict__ fill,
-                                                           float4* __restrict__ pts)
+                                                           float4* __restrict__ pts, unsigned int* __restrict__ slot_of)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
     const float px = x[j], py = y[j], pz = z[j];
     const unsigned int pos = atomicAdd(&fill[cell_of(g, px, py, pz)], 1u);
     pts[pos] = make_float4(px, py, pz, __int_as_float(j + index_base));
+    slot_of[j] = pos;
 }
 
 hipError_t grid_build(const GridBuildArgs& a, hipStream_t s)
@@ -212,7 +213,7 @@ hipError_t grid_build(const GridBuildArgs& a, hipStream_t s)
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, a.scan_tmp, tiles);
     // counts -> offsets, in place in cell_fill (the scatter's running cursors) and copied to cell_start
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(256), 0, s, a.cell_fill, n_scan, a.scan_tmp, a.cell_fill, a.cell_start_out);
-    hipLaunchKernelGGL(grid_scatter_kernel, dim3(pb), dim3(256), 0, s, g, a.x, a.y, a.z, a.m, a.index_base, a.cell_fill, a.pts_out);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(pb), dim3(256), 0, s, g, a.x, a.y, a.z, a.m, a.index_base, a.cell_fill, a.pts_out, a.slot_of_out);
     return hipGetLastError();
 }
 
@@ -239,8 +240,8 @@ __device__ __forceinline__ int centre_out(int k) { return (k & 1) ? -((k + 1) >>
 // The row loops run in LOCKSTEP over the wave (k-th nearest slab of each lane's own position, a wave-uniform counter): a row
 // that no lane needs costs a ballot, not a trip, and a row's points are fetched four at a time.
 template <bool FMA, bool STATS>
-__device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3], float& best, unsigned int& bidx, unsigned int& n_cand,
-                                            unsigned int& n_rows)
+__device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3], float& best, unsigned int& bidx, unsigned int& bslot,
+                                            unsigned int& n_cand, unsigned int& n_rows)
 {
     const float4* __restrict__ pts = g.pts;
     const unsigned int* __restrict__ cell_start = g.cell_start;
@@ -291,6 +292,7 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
                     const bool better = (d < best) | ((d == best) & (j < bidx));
                     best = better ? d : best;
                     bidx = better ? j : bidx;
+                    bslot = better ? min(p + (unsigned int)j4, last) : bslot;
                 }
             }
         }
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
 
     float q[3] = {0.f, 0.f, 0.f};
     float best = __builtin_inff();
-    unsigned int bidx = 0u;
+    unsigned int bidx = 0u, bslot = ~0u;
     double e0 = 0.0, e1 = 0.0;
     if (FUSED) {
         float R[9], tr[3];
@@ -332,10 +334,11 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
             q[1] = ((R[1] * x + R[4] * y) + R[7] * z) + tr[1];
             q[2] = ((R[2] * x + R[5] * y) + R[8] * z) + tr[2];
             const unsigned long long key = a.keys[i];
-            const int gidx = (int)(unsigned int)(key & 0xffffffffull);
             const float d2 = __uint_as_float((unsigned int)(key >> 32));
-            if (gidx >= a.shard_lo && gidx < a.shard_hi) {      // there is a previous match (KEY_INIT carries index -1)
-                const float4 p = a.tgt4[gidx - a.shard_lo];
+            bslot = a.match_slot[i];
+            if (bslot != ~0u) {                                 // there is a previous match
+                const float4 p = g.pts[bslot];
+                const int gidx = __float_as_int(p.w);
                 const float dx = p.x - q[0], dy = p.y - q[1], dz = p.z - q[2];
                 const float e = (dx * dx + dy * dy) + dz * dz;   // diff.LengthSquared(), common.cpp:264-265
                 const bool kept = a.filter_pairs ? (d2 < a.max_distance_squared) : true;
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
     bool hard = false;
     unsigned long long walk_cycles = 0;
     unsigned int n_cand = 0u, n_rows = 0u, n_nodes = 0u, n_leaves = 0u;
-    if (valid) hard = grid_search<FMA, STATS>(g, q, best, bidx, n_cand, n_rows);
+    if (valid) hard = grid_search<FMA, STATS>(g, q, best, bidx, bslot, n_cand, n_rows);
     const bool walked = __builtin_amdgcn_ballot_w64(hard) != 0ull;
 #ifndef MISLAM_DEV_SKIP_WALK          // timing experiments only (tools/build_variant.sh): wrong answers for the lanes concerned
     if (hard) {
@@ -403,11 +406,13 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
             const int gidx = (int)bidx;
             const bool mine = gidx >= a.shard_lo && gidx < a.shard_hi;
             const bool kept = a.filter_pairs ? (best < a.max_distance_squared) : true;
+            if (hard) bslot = g.slot_of[gidx - g.index_base];   // a walk's winner: the hierarchy keeps its own order
+            a.match_slot[i] = bslot;
             if (mine && kept) {
-                const float4 p = a.tgt4[gidx - a.shard_lo];
+                const float4 p = g.pts[bslot];
                 pair_moments(mom, q[0], q[1], q[2], p.x, p.y, p.z);
             }
-        }
+        } else if (valid) a.match_slot[i] = ~0u;
         double* row = a.rows + (size_t)chunk * ICP_ROW;
         row_store_moments(mom, row, nullptr);
         row_store_error(e0, e1, row, nullptr);

@@ -126,6 +126,11 @@ int mi_ctx_preload(mi_ctx* ctx);
 int mi_dist_unique_id(void* out_unique_id);
 int mi_ctx_create_dist(int device, int rank, int world, const void* unique_id, mi_ctx** out);
 int mi_ctx_rank(const mi_ctx* ctx, int* rank, int* world);
+/* What the TRANSPORT says about this context (measurement hook: bench.py prints it as proof that the ranks really met):
+ * *nranks / *rank as the RCCL communicator reports them (ncclCommCount / ncclCommUserRank; world / rank of an exchange context,
+ * 1 / 0 of a single-GPU one), *ranks_seen the sum over all ranks of 2^rank carried through one all-reduce on the context's
+ * stream -- bit r set = rank r took part.  Collective: every rank calls it.  Any output may be NULL. */
+int mi_dist_info(mi_ctx* ctx, int* nranks, int* rank, unsigned long long* ranks_seen);
 
 /* The same multi-GPU path over the CALLER's transport instead of RCCL (MPI between nodes, a test harness ...; no reference
  * counterpart either).  Wherever the RCCL context issues an all-reduce, this one drains its stream, copies the operand to

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for cfg in "$@"; do
   echo "== $cfg"
-  env $cfg timeout -k 10 300 python bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --brute-ref-steps 0 ${BENCH_ARGS} 2>&1 | python -c "
+  env $cfg timeout -k 10 300 python bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --no-sizes --brute-ref-steps 0 ${BENCH_ARGS} 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

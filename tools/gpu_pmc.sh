@@ -9,7 +9,7 @@ i=0
 dirs=""
 for set in "$@"; do
   i=$((i+1)); d=gpurun_out/pmc_pass$i; rm -rf $d
-  timeout -k 10 300 rocprofv3 --pmc $set -d $d --output-format csv -- python3 bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --brute-ref-steps 0 $BENCH_ARGS > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc $set -d $d --output-format csv -- python3 bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --no-sizes --brute-ref-steps 0 $BENCH_ARGS > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
   dirs="$dirs $d"
 done
 python3 - $out $k "$*" $dirs <<'PY'
@@ -26,7 +26,7 @@ for d in sys.argv[4:]:
     for c, v in agg.items():
         res[c] = sum(v) / len(v)
         launches = len(v)
-json.dump({"kernel": kern, "launches_per_pass": launches, "command": "rocprofv3 --pmc <one pass per counter set: %s> -- python3 bench.py --steps N --warmup W --no-cpu-baseline --brute-ref-steps 0" % sets,
+json.dump({"kernel": kern, "launches_per_pass": launches, "command": "rocprofv3 --pmc <one pass per counter set: %s> -- python3 bench.py --steps N --warmup W --no-cpu-baseline --no-sizes --brute-ref-steps 0" % sets,
            "per_launch_mean": res}, open(out, "w"), indent=1)
 for c in sorted(res): print("%-32s %.4g" % (c, res[c]))
 PY
