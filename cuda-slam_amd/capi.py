@@ -18,6 +18,7 @@ COMPOSE_CPU_ADDITIVE, COMPOSE_EXACT = 0, 1
 NN_AUTO, NN_BRUTEFORCE, NN_TREE, NN_GRID = 0, 1, 2, 3
 SHARD_AUTO, SHARD_TARGET, SHARD_SOURCE = 0, 1, 2
 SUM_EXACT, SUM_CPU_SEQUENTIAL = 0, 1
+SIGMA2_EXACT, SIGMA2_CPU_SEQUENTIAL = 0, 1
 NN_INDEX_MIN_POINTS = 24000         # MI_NN_AUTO switches to the cell grid at this many fixed points (mi_slam.h MI_NN_INDEX_MIN_POINTS)
 NN_TREE_MIN_POINTS = NN_INDEX_MIN_POINTS
 STOP_RUNNING, STOP_CONVERGED, STOP_MAX_ITERATIONS, STOP_NO_PAIRS, STOP_ERROR_INCREASED, STOP_TOLERANCE, STOP_SIGMA = range(7)
@@ -34,7 +35,7 @@ EXPORTS = [
     "mi_abi_version", "mi_last_error", "mi_device_count", "mi_ctx_create", "mi_dist_unique_id", "mi_ctx_create_dist",
     "mi_ctx_create_exchange", "mi_ctx_preload", "mi_ctx_rank", "mi_dist_info", "mi_shard_range", "mi_pack_key", "mi_unpack_key", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_icp_params_default", "mi_icp_params_cuda_slam",
     "mi_icp_register", "mi_icp_load", "mi_icp_reset", "mi_icp_run", "mi_icp_result", "mi_nn_search", "mi_nn_search_ex", "mi_kabsch",
-    "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_estep",
+    "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_sigma_squared_mode", "mi_cpd_estep",
     "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
     "mi_prepare_params_default", "mi_prepare_cloud",
     "mi_cpd_mstep", "mi_profile_enable", "mi_profile_select", "mi_profile_reset", "mi_profile_get", "mi_profile_search_stats", "mi_nn_kernel_name",
@@ -52,7 +53,7 @@ class CpdParams(C.Structure):
     _fields_ = [("eps", C.c_float), ("weight", C.c_float), ("const_scale", C.c_int), ("max_iterations", C.c_int),
                 ("tolerance", C.c_float), ("sigma2_init", C.c_float), ("sync_every", C.c_int), ("verbose", C.c_int),
                 ("approximation", C.c_int), ("fgt_ratio_of_far_field", C.c_float), ("fgt_order_of_truncation", C.c_int),
-                ("reserved", C.c_int * 5)]
+                ("sigma2_mode", C.c_int), ("reserved", C.c_int * 4)]
 
 
 class NicpParams(C.Structure):
@@ -330,10 +331,10 @@ class Context:
         sR, t = _T_to_Rt(T)
         return sR, t, sc.value, it.value, err.value
 
-    def cpd_sigma_squared(self, before, after):
+    def cpd_sigma_squared(self, before, after, mode=SIGMA2_EXACT):
         before, after = _cloud(before), _cloud(after)
         s = C.c_float(0)
-        _check(lib().mi_cpd_sigma_squared(self._h, _fp(before), before.shape[0], _fp(after), after.shape[0], C.byref(s)))
+        _check(lib().mi_cpd_sigma_squared_mode(self._h, _fp(before), before.shape[0], _fp(after), after.shape[0], mode, C.byref(s)))
         return s.value
 
     def cpd_estep(self, y, x, constant, sigma2):

@@ -200,18 +200,23 @@ static int cpd_fetch(mi_ctx* c, CpdWorkspace* w)
     return MI_OK;
 }
 
-static int cpd_init(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const CpdRules& rules, float sigma2_override)
+static int cpd_init(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const CpdRules& rules, float sigma2_override, int sigma2_mode)
 {
     const int nb = icp_reduce_blocks(std::max(w->m, w->n));
     MI_HIP(cpd_init_sums(v, w->part_init.p, nb, c->stream));
+    const int seq = sigma2_mode == MI_SIGMA2_CPU_SEQUENTIAL && !(sigma2_override > 0.f);
+    if (seq) {
+        if (c->distributed()) { set_error("CPD: MI_SIGMA2_CPU_SEQUENTIAL needs a single-GPU context (one running sum over all pairs)"); return MI_ERR_INVALID_ARG; }
+        MI_HIP(cpd_sigma2_sequential(v, c->stream));
+    }
     if (!c->distributed()) {
-        MI_HIP(cpd_init_state(w->d_state, w->part_init.p, nb, rules, sigma2_override, c->stream));
+        MI_HIP(cpd_init_state(w->d_state, w->part_init.p, nb, rules, sigma2_override, seq, c->stream));
         return MI_OK;
     }
     // sharded fixed cloud: its four sums (init[0..3]) are added over the ranks; the moving cloud's (init[4..7]) are replicated
     MI_HIP(cpd_reduce_init(w->d_state, w->part_init.p, nb, c->stream));
     MI_TRY(allreduce_sum_f64(c, w->d_state->init, 4));
-    MI_HIP(cpd_init_state(w->d_state, nullptr, 0, rules, sigma2_override, c->stream));
+    MI_HIP(cpd_init_state(w->d_state, nullptr, 0, rules, sigma2_override, 0, c->stream));
     return MI_OK;
 }
 
@@ -385,7 +390,8 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
     w->n_total = n_after;
     const CpdView v = cpd_view(c, w);
     const CpdRules rules = cpd_rules(w, params);
-    MI_TRY(cpd_init(c, w, v, rules, params->sigma2_init));
+    if (params->sigma2_mode != MI_SIGMA2_EXACT && params->sigma2_mode != MI_SIGMA2_CPU_SEQUENTIAL) { set_error("mi_cpd_register: bad sigma2_mode %d", params->sigma2_mode); return MI_ERR_INVALID_ARG; }
+    MI_TRY(cpd_init(c, w, v, rules, params->sigma2_init, params->sigma2_mode));
     MI_TRY(cpd_fetch(c, w));
     int batch = params->sync_every;
     if (batch <= 0) {
@@ -441,8 +447,15 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
 
 extern "C" int mi_cpd_sigma_squared(mi_ctx* c, const float* before_xyz, int m, const float* after_xyz, int n, float* sigma2)
 {
+    return mi_cpd_sigma_squared_mode(c, before_xyz, m, after_xyz, n, MI_SIGMA2_EXACT, sigma2);
+}
+
+extern "C" int mi_cpd_sigma_squared_mode(mi_ctx* c, const float* before_xyz, int m, const float* after_xyz, int n, int sigma2_mode,
+                                         float* sigma2)
+{
     MI_TRY(cpd_check(c, before_xyz, m, after_xyz, n));
     if (!sigma2) { set_error("mi_cpd_sigma_squared: null output"); return MI_ERR_INVALID_ARG; }
+    if (sigma2_mode != MI_SIGMA2_EXACT && sigma2_mode != MI_SIGMA2_CPU_SEQUENTIAL) { set_error("mi_cpd_sigma_squared: bad sigma2_mode %d", sigma2_mode); return MI_ERR_INVALID_ARG; }
     MI_HIP(hipSetDevice(c->device));
     CpdWorkspace* w = nullptr;
     MI_TRY(cpd_workspace(c, &w));
@@ -451,7 +464,7 @@ extern "C" int mi_cpd_sigma_squared(mi_ctx* c, const float* before_xyz, int m, c
     mi_cpd_params p;
     mi_cpd_params_default(&p);
     p.max_iterations = 1;
-    MI_TRY(cpd_init(c, w, v, cpd_rules(w, &p), 0.f));
+    MI_TRY(cpd_init(c, w, v, cpd_rules(w, &p), 0.f, sigma2_mode));
     MI_TRY(cpd_fetch(c, w));
     *sigma2 = w->h_state->sigma2_init;
     return MI_OK;

@@ -64,7 +64,13 @@ struct CpdView {
 };
 
 hipError_t cpd_init_sums(const CpdView& v, double* partials, int nblocks, hipStream_t s);
-hipError_t cpd_init_state(CpdState* state, const double* partials, int nblocks, const CpdRules& rules, float sigma2_override, hipStream_t s);
+// sigma2_override > 0: use it; sigma2_from_state: use the value cpd_sigma2_sequential left in state->sigma2_init; else the exact
+// closed form from the sums
+hipError_t cpd_init_state(CpdState* state, const double* partials, int nblocks, const CpdRules& rules, float sigma2_override,
+                          int sigma2_from_state, hipStream_t s);
+// cpu-slam's own sigma^2_0 bit for bit (coherentpointdrift.cpp:126-139): ONE sequential fp32 running sum over all m*n squared
+// distances, before-major -- into state->sigma2_init.  One wave; ~8 cycles per term (0.7 s for the bunny clouds).
+hipError_t cpd_sigma2_sequential(const CpdView& v, hipStream_t s);
 hipError_t cpd_denominators(const CpdView& v, hipStream_t s);                                  // K7a
 hipError_t cpd_post_denominators(const CpdView& v, hipStream_t s);                             //   den, w, Pt1, xw4
 hipError_t cpd_contract(const CpdView& v, int use_mfma, hipStream_t s);                        // K7b

@@ -77,8 +77,32 @@ __global__ __launch_bounds__(256) void cpd_init_sums_kernel(CpdView v, double* _
     block_sum_store<CPD_INIT_SUMS>(acc, partials + (size_t)blockIdx.x * CPD_INIT_SUMS);
 }
 
+// CalculateSigmaSquared of cpu-slam (coherentpointdrift.cpp:126-139): `sum += (before[i] - after[j]).LengthSquared()` over i, then
+// j, in ONE fp32 running sum that saturates once it dwarfs its terms (3.604 instead of 12.943 on the bunny clouds) -- and cpu-slam's
+// whole EM trajectory starts from that number.  A sequential fp32 sum cannot be re-associated, so it is retraced: one wave, 64
+// terms per step evaluated by the lanes, added one by one through v_readlane (a missing term adds +0.0f: no effect on a sum >= 0).
+__global__ __launch_bounds__(64) void cpd_sigma2_seq_kernel(CpdView v)
+{
+    const int lane = threadIdx.x;
+    float acc = 0.f;
+    for (int i = 0; i < v.m; i++) {
+        const float bx = v.bx[i], by = v.by[i], bz = v.bz[i];
+        for (int j0 = 0; j0 < v.n; j0 += 64) {
+            const int j = j0 + lane;
+            float term = 0.f;
+            if (j < v.n) {
+                const float dx = bx - v.ax[j], dy = by - v.ay[j], dz = bz - v.az[j];   // Point operator-, then x*x + y*y + z*z (point.h:49-51)
+                term = (dx * dx + dy * dy) + dz * dz;
+            }
+            acc = seq_add64(acc, term);
+        }
+    }
+    // sum /= (float)(DIMENSION * cloudBefore.size() * cloudAfter.size())   (:137: a size_t product, converted once)
+    if (lane == 0) v.state->sigma2_init = acc / (float)((size_t)3 * (size_t)v.m * (size_t)v.n);
+}
+
 __global__ __launch_bounds__(256) void cpd_init_state_kernel(CpdState* __restrict__ st, const double* __restrict__ partials, int nblocks,
-                                                             CpdRules rules, float sigma2_override)
+                                                             CpdRules rules, float sigma2_override, int sigma2_from_state)
 {
     __shared__ double lds[256];
     double s[CPD_INIT_SUMS];
@@ -91,6 +115,7 @@ __global__ __launch_bounds__(256) void cpd_init_state_kernel(CpdState* __restric
     const double total = N * s[7] + M * s[3] - 2.0 * (s[0] * s[4] + s[1] * s[5] + s[2] * s[6]);
     float sigma2 = (float)(total / (3.0 * M * N));
     if (sigma2_override > 0.f) sigma2 = sigma2_override;
+    else if (sigma2_from_state) sigma2 = st->sigma2_init;
     for (int i = 0; i < 9; i++) st->R[i] = (i % 4 == 0) ? 1.f : 0.f;
     st->t[0] = st->t[1] = st->t[2] = 0.f;
     st->scale = 1.f;
@@ -414,9 +439,16 @@ hipError_t cpd_init_sums(const CpdView& v, double* partials, int nblocks, hipStr
     return hipGetLastError();
 }
 
-hipError_t cpd_init_state(CpdState* state, const double* partials, int nblocks, const CpdRules& rules, float sigma2_override, hipStream_t s)
+hipError_t cpd_init_state(CpdState* state, const double* partials, int nblocks, const CpdRules& rules, float sigma2_override,
+                          int sigma2_from_state, hipStream_t s)
 {
-    hipLaunchKernelGGL(cpd_init_state_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks, rules, sigma2_override);
+    hipLaunchKernelGGL(cpd_init_state_kernel, dim3(1), dim3(256), 0, s, state, partials, nblocks, rules, sigma2_override, sigma2_from_state);
+    return hipGetLastError();
+}
+
+hipError_t cpd_sigma2_sequential(const CpdView& v, hipStream_t s)
+{
+    hipLaunchKernelGGL(cpd_sigma2_seq_kernel, dim3(1), dim3(64), 0, s, v);
     return hipGetLastError();
 }
 

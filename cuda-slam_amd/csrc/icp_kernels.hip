@@ -28,6 +28,7 @@
 
 #include "icp_rows.hpp"
 #include "kernels.h"
+#include "reduce.hpp"
 #include "svd3.hpp"
 
 namespace mislam {
@@ -321,13 +322,6 @@ __global__ __launch_bounds__(ICP_ROW_POINTS) void icp_transform_error_rows_kerne
 // added one by one from lane registers via v_readlane.  A dropped pair contributes +0.0f, which leaves an fp32 sum
 // unchanged, so no flags are needed.  ~8 cycles per term: 3.3 ms per million points, paid only in this mode.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float seq_add64(float acc, float term)
-{
-#pragma unroll
-    for (int j = 0; j < 64; j++) acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(term), j));
-    return acc;
-}
-
 // 6 waves: wave w < 3 sums component w of the kept moving points, wave w >= 3 component w-3 of their matched fixed points
 __global__ __launch_bounds__(384) void icp_seq_centroid_kernel(IcpView v)
 {

@@ -57,4 +57,13 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
 }
 
 
+// acc + t_0 + t_1 + ... + t_63 added ONE BY ONE in lane order, the terms read out of the lanes' registers (v_readlane): how
+// the reference's sequential fp32 running sums (std::accumulate, `sum +=` loops) are retraced bit for bit, 64 terms per step.
+__device__ __forceinline__ float seq_add64(float acc, float term)
+{
+#pragma unroll
+    for (int j = 0; j < 64; j++) acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(term), j));
+    return acc;
+}
+
 }  // namespace mislam

@@ -238,16 +238,26 @@ typedef struct {
     int   max_iterations;  /* loop runs while iterations < max_iterations; NB -1 therefore runs NO iteration (:106) */
     float tolerance;       /* "cpd-tolerance" (default 1e-3) */
     float sigma2_init;     /* > 0: use this initial sigma^2.  <= 0: computed on the device as the exact
-                              sum_ij |b_i - a_j|^2 / (3MN) in fp64.  cpu-slam's own value is a single sequential fp32
-                              running sum (coherentpointdrift.cpp:126-139) that saturates for M*N >~ 1e7
-                              (3.604 instead of 12.943 on the bunny clouds); pass that number here to retrace cpu-slam. */
+                              sum_ij |b_i - a_j|^2 / (3MN) in fp64, or as sigma2_mode says.  cpu-slam's own value is a single
+                              sequential fp32 running sum (coherentpointdrift.cpp:126-139) that saturates for M*N >~ 1e7
+                              (3.604 instead of 12.943 on the bunny clouds): MI_SIGMA2_CPU_SEQUENTIAL reproduces it. */
     int   sync_every;      /* as in mi_icp_params */
     int   verbose;
     int   approximation;   /* MI_CPD_APPROX_*: "approximation-type" (configparser.cpp:221-230).  0 = the exact Gaussian P. */
     float fgt_ratio_of_far_field;    /* "fgt-ratio-of-far-field" e (default 10): cells farther than sqrt(e)*sigma are skipped */
     int   fgt_order_of_truncation;   /* "fgt-order-of-truncation" p (default 8): monomials of total degree < p, 1..16 */
-    int   reserved[5];
+    int   sigma2_mode;               /* MI_SIGMA2_*: how the initial sigma^2 is computed when sigma2_init <= 0 */
+    int   reserved[4];
 } mi_cpd_params;
+
+/* The initial sigma^2 = sum_ij |b_i - a_j|^2 / (3MN) (CalculateSigmaSquared, coherentpointdrift.cpp:126-139 / cpdcuda.cu:65-78).
+ *   EXACT:          closed form from the clouds' sums, fp64 (what cuda-slam's thrust reduction approximates).
+ *   CPU_SEQUENTIAL: cpu-slam's own arithmetic bit for bit -- ONE sequential fp32 running sum over all M*N squared distances, which
+ *                   saturates once it dwarfs its terms (3.604 instead of 12.943 on the bunny clouds).  cpu-slam's whole EM
+ *                   trajectory starts from that number, so this is the mode in which mi_cpd_register retraces cpu-slam without
+ *                   being handed a constant.  A sequential sum cannot be re-associated: one wave, ~3.4 ns per pair (0.75 s for
+ *                   the bunny clouds, once per registration); single-GPU contexts only. */
+enum { MI_SIGMA2_EXACT = 0, MI_SIGMA2_CPU_SEQUENTIAL = 1 };
 
 /* "approximation-type" of the reference (common/enumerators.h:18-23, coherentpointdrift.cpp:141-167):
  *   FULL    every E-step is the Fast Gauss Transform (common/fgt.cpp) and sigma^2 is clamped to >= 0.05;
@@ -265,8 +275,9 @@ void mi_cpd_params_default(mi_cpd_params* p);
 int mi_cpd_register(mi_ctx* ctx, const float* before_xyz, int m_before, const float* after_xyz, int n_after,
                     const mi_cpd_params* params, float out_sR_t[16], float* out_scale, int* iterations, float* error);
 
-/* CalculateSigmaSquared (cpdcuda.cu:65-78 / coherentpointdrift.cpp:126-139), exact value (see sigma2_init above). */
+/* CalculateSigmaSquared (cpdcuda.cu:65-78 / coherentpointdrift.cpp:126-139): the exact value, or with an explicit MI_SIGMA2_* mode. */
 int mi_cpd_sigma_squared(mi_ctx* ctx, const float* before_xyz, int m, const float* after_xyz, int n, float* sigma2);
+int mi_cpd_sigma_squared_mode(mi_ctx* ctx, const float* before_xyz, int m, const float* after_xyz, int n, int sigma2_mode, float* sigma2);
 
 /* ComputePMatrix, no truncation (cpdcuda.cu:80-116 / coherentpointdrift.cpp:168-221):
  * p_xk = exp(-|x - y_k|^2 / (2 sigma^2)); den_x = sum_k p_xk + c; Pt1[x] = 1 - c/den_x; P1[k] = sum_x p_xk/den_x;

@@ -54,8 +54,16 @@ std::pair<glm::mat3, glm::vec3> GetCudaCpdTransformationMatrix(
     p.approximation = (int)fgt;                       // enumerators.h:18-23 and MI_CPD_APPROX_* share the numbering
     p.fgt_ratio_of_far_field = ratioOfFarField;       // the FGT E-step runs on the device too (the reference runs it on the CPU)
     p.fgt_order_of_truncation = (int)orderOfTruncation;
-    // p.sigma2_init <= 0: exact sigma^2 on the device (what cuda-slam's thrust reduction approximates, cpdcuda.cu:65-78).
-    // cpu-slam's sequential fp32 sum saturates (3.604 vs 12.943 on bunny); pass that number to retrace cpu-slam.
+    // The initial sigma^2.  cpu-slam's is a sequential fp32 running sum that saturates (3.604 instead of 12.943 on bunny,
+    // coherentpointdrift.cpp:126-139) and its whole trajectory starts there; cuda-slam's thrust reduction (cpdcuda.cu:65-78) gives
+    // roughly the exact value.  The parity target of this build is cpu-slam, so that is the default here, up to the size at which
+    // retracing the sequential sum costs about two seconds; MI355X_CPD_SIGMA=exact / =cpu forces either.
+    {
+        const char* mode = getenv("MI355X_CPD_SIGMA");
+        const double pairs = (double)cloudBefore.size() * (double)cloudAfter.size();
+        const bool cpu = mode ? (mode[0] == 'c') : pairs <= 6e8;
+        p.sigma2_mode = cpu ? MI_SIGMA2_CPU_SEQUENTIAL : MI_SIGMA2_EXACT;
+    }
     glm::mat4 sRt;
     if (mi_cpd_register(Ctx(), reinterpret_cast<const float*>(cloudBefore.data()), (int)cloudBefore.size(),
                         reinterpret_cast<const float*>(cloudAfter.data()), (int)cloudAfter.size(),

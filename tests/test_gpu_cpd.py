@@ -105,6 +105,50 @@ def test_bunny_cpd_matches_cpu_slam(ctx, capi, golden, bunny):
     assert abs(err - f["error"]) < 1e-4
 
 
+def test_sigma_squared_cpu_sequential_is_cpu_slams_own_number(ctx, capi, oracle, golden, bunny):
+    # MI_SIGMA2_CPU_SEQUENTIAL retraces cpu-slam's single sequential fp32 running sum (coherentpointdrift.cpp:126-139) bit for
+    # bit: == the value the reference build produced on the bunny clouds (fixture), == the restatement on small, ragged and
+    # saturating cases (and == the reference build itself where it is present)
+    before, after = bunny
+    g = golden.json("bunny_cpd.json")
+    s2 = ctx.cpd_sigma_squared(before, after, capi.SIGMA2_CPU_SEQUENTIAL)
+    assert np.float32(s2) == np.float32(g["sigma2_init"]), (s2, g["sigma2_init"])
+    assert abs(s2 - 3.604) < 1e-3                      # the saturated sum, not the exact 12.943
+    rng = np.random.default_rng(12)
+    for m, n, scale in ((1, 1, 1.0), (3, 70, 5.0), (65, 64, 0.01), (200, 1000, 30.0), (2500, 3100, 12.0)):
+        b = (rng.normal(size=(m, 3)) * scale).astype(np.float32)
+        a = (rng.normal(size=(n, 3)) * scale + 1.5).astype(np.float32)
+        assert np.float32(ctx.cpd_sigma_squared(b, a, capi.SIGMA2_CPU_SEQUENTIAL)) == np.float32(oracle.cpd_sigma_squared(b, a)), (m, n)
+    from oracle import refbind
+    if refbind.available():
+        b, a = before[:3000], after[:2800]
+        assert np.float32(ctx.cpd_sigma_squared(b, a, capi.SIGMA2_CPU_SEQUENTIAL)) == np.float32(refbind.cpd_sigma_squared(b, a))
+
+
+def test_bunny_cpd_matches_cpu_slam_without_an_injected_constant(ctx, capi, golden, bunny):
+    # cfg 4 as a caller runs it: nothing but the two clouds and the parser's defaults.  With sigma2_mode = CPU_SEQUENTIAL the
+    # device starts from cpu-slam's own sigma^2_0 and lands on cpu-slam's result: same 27 iterations, < 1e-4 Frobenius
+    before, after = bunny
+    f = golden.json("bunny_cpd.json")["final_scale_free"]
+    p = capi.cpd_params(max_iterations=50, const_scale=0, sigma2_mode=capi.SIGMA2_CPU_SEQUENTIAL)
+    assert p.sigma2_init <= 0
+    sR, t, scale, it, err = ctx.cpd_register(before, after, p)
+    assert it == f["iterations"]
+    d = frob(sR, t, f["sR"], f["t"])
+    print("bunny CPD (device-computed cpu-slam sigma^2_0) |d(sR|t)|_F vs cpu-slam = %.3e" % d)
+    assert d < 1e-4
+    # bitwise the run that is handed the fixture's constant
+    g = golden.json("bunny_cpd.json")
+    ref = ctx.cpd_register(before, after, capi.cpd_params(max_iterations=50, const_scale=0, sigma2_init=g["sigma2_init"]))
+    assert np.array_equal(sR, ref[0]) and np.array_equal(t, ref[1]) and it == ref[3]
+    # hybrid (the parser's default approximation) the same way
+    h = golden.json("bunny_fgt.json")
+    ph = capi.cpd_params(max_iterations=50, approximation=capi.CPD_APPROX_HYBRID, sigma2_mode=capi.SIGMA2_CPU_SEQUENTIAL)
+    hr = ctx.cpd_register(before, after, ph)
+    hi = ctx.cpd_register(before, after, capi.cpd_params(max_iterations=50, approximation=capi.CPD_APPROX_HYBRID, sigma2_init=h["sigma2_init"]))
+    assert hr[3] == hi[3] and np.array_equal(hr[0], hi[0]) and np.array_equal(hr[1], hi[1])
+
+
 def test_bunny_cpd_const_scale(ctx, capi, golden, bunny):
     # "cpd-const-scale": true.  The reference's own run ends in a rounding-noise-dominated regime: its last five
     # sigma^2 values fall 5e-3 -> 2.5e-4 through the cancelling difference |sub + den - 2 num| of ~1e5-sized fp32 sums, and a

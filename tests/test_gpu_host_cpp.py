@@ -69,7 +69,7 @@ def test_mi_slam_cpd(tmp_path, capi, ctx):
     res = json.loads((tmp_path / "result.json").read_text())
     before, after = read_dump(tmp_path / "clouds.bin")
     assert before.shape == (2000, 3) and after.shape == (2000, 3)
-    sR, t, sc, it, err = ctx.cpd_register(before, after, capi.cpd_params(max_iterations=40))
+    sR, t, sc, it, err = ctx.cpd_register(before, after, capi.cpd_params(max_iterations=40, sigma2_mode=capi.SIGMA2_CPU_SEQUENTIAL))
     Rc = np.array(res["R_colmajor"], np.float32).reshape(3, 3).T
     assert res["iterations"] == it and np.array_equal(Rc, sR) and np.array_equal(np.array(res["t"], np.float32), t)
 
@@ -85,11 +85,11 @@ def test_mi_slam_cpd_default_approximation_is_hybrid(tmp_path, capi, ctx):
     assert "Approximation type: hybrid" in r.stdout
     res = json.loads((tmp_path / "result.json").read_text())
     before, after = read_dump(tmp_path / "clouds.bin")
-    p = capi.cpd_params(max_iterations=40, approximation=capi.CPD_APPROX_HYBRID)
+    p = capi.cpd_params(max_iterations=40, approximation=capi.CPD_APPROX_HYBRID, sigma2_mode=capi.SIGMA2_CPU_SEQUENTIAL)
     sR, t, sc, it, err = ctx.cpd_register(before, after, p)
     Rc = np.array(res["R_colmajor"], np.float32).reshape(3, 3).T
     assert res["iterations"] == it and np.array_equal(Rc, sR) and np.array_equal(np.array(res["t"], np.float32), t)
-    exact = ctx.cpd_register(before, after, capi.cpd_params(max_iterations=40))
+    exact = ctx.cpd_register(before, after, capi.cpd_params(max_iterations=40, sigma2_mode=capi.SIGMA2_CPU_SEQUENTIAL))
     assert not np.array_equal(exact[0], sR)                # the approximation really ran
 
 

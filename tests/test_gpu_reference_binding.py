@@ -48,7 +48,8 @@ def test_icp_entry_point(tmp_path, ctx, capi, bunny):
 def test_cpd_entry_point_default_approximation(tmp_path, ctx, capi, bunny):
     before, after = bunny
     R, t, it, err, out = run(tmp_path, before, after, "cpd", 1e-3, 50, 0.3, 1e-3, 2)
-    p = capi.cpd_params(eps=1e-3, max_iterations=50, weight=0.3, tolerance=1e-3, approximation=capi.CPD_APPROX_HYBRID)
+    p = capi.cpd_params(eps=1e-3, max_iterations=50, weight=0.3, tolerance=1e-3, approximation=capi.CPD_APPROX_HYBRID,
+                        sigma2_mode=capi.SIGMA2_CPU_SEQUENTIAL)   # the adapter's default at this size: cpu-slam's own sigma^2_0
     sR, tl, sc, itl, errl = ctx.cpd_register(before, after, p)
     assert it == itl and np.array_equal(R, sR) and np.array_equal(t, tl)
 
