@@ -20,12 +20,10 @@ namespace mislam {
 // Buffers of one clustered cloud (FgtClusters, cpd_fgt.h)
 struct FgtSide {
     DevBuf<float> dist, xc;
-    DevBuf<int> indx, iota, memb, off;
-    DevBuf<unsigned int> keys;
+    DevBuf<int> indx, memb, off;
     DevBuf<unsigned char> sweep;   // scratch of the grid-wide sweep (large clouds)
-    int iota_n = 0;
     int swept_K = 0;            // the fixed cloud only: centres of the sweep dist/indx currently hold (0 = none); see fgt_kcenter_kernel
-    void release() { dist.release(); xc.release(); indx.release(); iota.release(); memb.release(); off.release(); keys.release(); sweep.release(); iota_n = 0; swept_K = 0; }
+    void release() { dist.release(); xc.release(); indx.release(); memb.release(); off.release(); sweep.release(); swept_K = 0; }
 };
 
 // Fast-Gauss-Transform E-step workspace ("approximation-type" full / hybrid)
@@ -268,14 +266,13 @@ static int fgt_tables(mi_ctx* c, FgtWork* f, int p, FgtTables* out)
 
 static int fgt_side(mi_ctx* c, FgtWork* f, FgtSide* sd, const float* x, const float* y, const float* z, int n, int K, FgtClusters* out)
 {
-    MI_TRY(sd->dist.reserve(n)); MI_TRY(sd->indx.reserve(n)); MI_TRY(sd->iota.reserve(n)); MI_TRY(sd->memb.reserve(n));
-    MI_TRY(sd->keys.reserve(n)); MI_TRY(sd->off.reserve((size_t)K + 1)); MI_TRY(sd->xc.reserve(3 * (size_t)K));
-    if (sd->iota_n < n) { MI_HIP(fgt_fill_iota(sd->iota.p, n, c->stream)); sd->iota_n = n; }
+    MI_TRY(sd->dist.reserve(n)); MI_TRY(sd->indx.reserve(n)); MI_TRY(sd->memb.reserve(n));
+    MI_TRY(sd->off.reserve((size_t)K + 1)); MI_TRY(sd->xc.reserve(3 * (size_t)K));
     MI_TRY(f->sort_temp.reserve(std::max<size_t>(fgt_sort_temp_bytes(n), 16)));
     if (n > FGT_GRID_SWEEP_MIN_POINTS) MI_TRY(sd->sweep.reserve(FGT_SWEEP_SCRATCH_BYTES));
     out->sweep_scratch = n > FGT_GRID_SWEEP_MIN_POINTS ? sd->sweep.p : nullptr;
     out->x = x; out->y = y; out->z = z; out->n = n; out->K = K; out->k_done = 0;
-    out->dist = sd->dist.p; out->indx = sd->indx.p; out->iota = sd->iota.p; out->keys_sorted = sd->keys.p;
+    out->dist = sd->dist.p; out->indx = sd->indx.p;
     out->memb = sd->memb.p; out->off = sd->off.p; out->xc = sd->xc.p;
     return MI_OK;
 }
@@ -302,7 +299,7 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
     FgtTables t{};
     MI_TRY(fgt_tables(c, f, order, &t));
     const int K = fgt_cluster_count(w->m, w->n, sigma2, sigma2_init);
-    if (K < 1 || K >= (1 << FGT_KEY_BITS)) { set_error("FGT E-step: %d cells outside [1, %d)", K, 1 << FGT_KEY_BITS); return MI_ERR_INVALID_ARG; }
+    if (K < 1 || K > FGT_MAX_CLUSTERS) { set_error("FGT E-step: %d cells outside [1, %d]", K, FGT_MAX_CLUSTERS); return MI_ERR_INVALID_ARG; }
     const float hsigma = std::sqrt(2.0f * sigma2);                 // cpdutils.cpp:31
     const float ndi = fgt_ndi(sigma2, weight, w->m, w->n);
     FgtClusters cy{}, ca{};
@@ -538,7 +535,7 @@ extern "C" int mi_fgt_kcenter(mi_ctx* c, const float* cloud_xyz, int n, int K, f
 {
     if (!c) { set_error("mi_fgt_kcenter: null context"); return MI_ERR_INVALID_ARG; }
     if (!cloud_xyz || !centers_xyz || !cluster) { set_error("mi_fgt_kcenter: null argument"); return MI_ERR_INVALID_ARG; }
-    if (n < 2 || K < 1 || K >= (1 << FGT_KEY_BITS)) { set_error("mi_fgt_kcenter: need n >= 2 and 1 <= K < %d (n=%d, K=%d)", 1 << FGT_KEY_BITS, n, K); return MI_ERR_INVALID_ARG; }
+    if (n < 2 || K < 1 || K > FGT_MAX_CLUSTERS) { set_error("mi_fgt_kcenter: need n >= 2 and 1 <= K <= %d (n=%d, K=%d)", FGT_MAX_CLUSTERS, n, K); return MI_ERR_INVALID_ARG; }
     MI_HIP(hipSetDevice(c->device));
     CpdWorkspace* w = nullptr;
     MI_TRY(cpd_workspace(c, &w));

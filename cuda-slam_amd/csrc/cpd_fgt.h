@@ -7,7 +7,7 @@
 namespace mislam {
 
 constexpr int FGT_MAX_ORDER = 16;          // p: monomials of total degree < p; exponents are packed in 8 bits each
-constexpr int FGT_KEY_BITS = 16;           // cluster ids are sorted on this many bits: K <= 65535
+constexpr int FGT_MAX_CLUSTERS = 65535;    // K <= this (the member-list sort's scratch is sized for it)
 constexpr int FGT_GRID_SWEEP_MIN_POINTS = 65536;   // above this the K-centre sweep runs one grid-wide launch per step
 constexpr int FGT_GRID_SWEEP_BLOCKS = 1024;
 constexpr size_t FGT_SWEEP_SCRATCH_BYTES = (size_t)(FGT_GRID_SWEEP_BLOCKS + 1) * 20;   // current centre + per-workgroup arg-max records
@@ -28,16 +28,13 @@ struct FgtClusters {
     int k_done;                 // > 0: dist/indx hold a finished sweep of this cloud with k_done < K centres -- resume it
     float* dist;                // [n]   squared distance to the nearest centre so far (kept: the sweep can be resumed)
     int* indx;                  // [n]   cluster of each point
-    int* iota;                  // [n]   0..n-1 (sort values in)
-    unsigned int* keys_sorted;  // [n]
     int* memb;                  // [n]   point ids grouped by cluster, ascending inside a cluster
     int* off;                   // [K+1] cluster k owns memb[off[k] .. off[k+1])
     float* xc;                  // [K][3] cluster means
     void* sweep_scratch;        // FGT_SWEEP_SCRATCH_BYTES, used by the grid-wide sweep (may be null for small clouds)
 };
 
-size_t fgt_sort_temp_bytes(int n);
-hipError_t fgt_fill_iota(int* iota, int n, hipStream_t s);
+size_t fgt_sort_temp_bytes(int n);     // scratch fgt_cluster needs for its member-list sort
 // K-centre clustering + member lists + cluster means; everything a model build needs
 hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
 // coefficients B[w][k][hpos] = C_k * sum_{i in cluster k} weight_w(i) exp(-|dx|^2) dx^alpha, dx = (pt - xc_k) / sigma.

@@ -20,7 +20,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "cpd_fgt.h"
 
@@ -199,23 +198,102 @@ __global__ __launch_bounds__(256) void fgt_sweep_pick_kernel(const ArgMax* __res
     }
 }
 
-__global__ __launch_bounds__(256) void fgt_iota_kernel(int* __restrict__ iota, int n)
+// ---------------------------------------------------------------------------------------------------------------
+// member lists: memb = point ids grouped by cluster, ASCENDING inside a cluster (the order fgt.cpp:195-210 sums the cell means
+// in), off[k] = start of cluster k.  A stable counting sort on the labels, in three small launches and no library call:
+// the cloud is cut into G chunks of consecutive ids, one wave each; (1) per-chunk label counts H[g][k]; (2) per label, the
+// exclusive prefix of the counts over the chunks, and the cluster starts off[k]; (3) every wave places its chunk, 64 points per
+// step in id order: the lanes holding the same label are found with ballots, ranked by lane, and take the next slots of that
+// label's run -- the chunk-private cursor H[g][k] is advanced by one atomic per distinct label and step.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int FGT_LIST_LDS_LABELS = 8192;   // up to this many labels a chunk's cursors live in LDS (32 KB per wave)
+
+template <bool SCATTER>
+__global__ __launch_bounds__(64) void fgt_lists_pass_kernel(const int* __restrict__ indx, int n, int K, int chunk, int* __restrict__ H,
+                                                            const int* __restrict__ off, int* __restrict__ memb)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) iota[i] = i;
+    extern __shared__ int cur[];                                 // SCATTER with K <= FGT_LIST_LDS_LABELS: this chunk's cursor per label
+    const int lane = threadIdx.x;
+    const int lo = blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    int* __restrict__ row = H + (size_t)blockIdx.x * K;
+    const bool lds = SCATTER && K <= FGT_LIST_LDS_LABELS;
+    if (lds)
+        for (int k = lane; k < K; k += 64) cur[k] = row[k];       // one wave: LDS operations of a wave complete in order
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < hi;
+        const int lab = valid ? indx[i] : -1;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+        while (todo != 0ull) {
+            const int leader = __builtin_ctzll(todo);
+            const int first = __builtin_amdgcn_readlane(lab, leader);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(valid && lab == first);
+            todo &= ~m;
+            const int cnt = (int)__builtin_popcountll(m);
+            if (!SCATTER) {
+                if (lane == leader) atomicAdd(&row[first], cnt);  // result unused: fire and forget
+            } else {
+                int before = 0;
+                if (lane == leader) {
+                    if (lds) { before = cur[first]; cur[first] = before + cnt; }
+                    else before = atomicAdd(&row[first], cnt);    // very many labels: the wave's own cursor in memory (uncontended, L2-coherent)
+                }
+                before = __builtin_amdgcn_readlane(before, leader);
+                if (valid && lab == first) {
+                    const int rank = (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    memb[off[first] + before + rank] = i;
+                }
+            }
+        }
+    }
 }
 
-// off[k] = first sorted position whose label is >= k (k = 0..K)
-__global__ __launch_bounds__(256) void fgt_offsets_kernel(const unsigned int* __restrict__ keys, int n, int K, int* __restrict__ off)
+// per label: H[g][k] <- sum of the counts of the chunks before g; tot[k] <- the label's total.  One wave per label, 64 chunks per
+// step (a wave-wide exclusive scan), the carry in a scalar.
+__global__ __launch_bounds__(256) void fgt_lists_columns_kernel(int* __restrict__ H, int G, int K, int* __restrict__ tot)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k > K) return;
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (keys[mid] < (unsigned int)k) lo = mid + 1; else hi = mid;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= K) return;
+    int carry = 0;
+    for (int g0 = 0; g0 < G; g0 += 64) {
+        const int g = g0 + lane;
+        const int c = g < G ? H[(size_t)g * K + k] : 0;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (g < G) H[(size_t)g * K + k] = carry + incl - c;
+        carry += __shfl(incl, 63, 64);
     }
-    off[k] = lo;
+    if (lane == 0) tot[k] = carry;
+}
+
+// off[0..K] <- exclusive prefix of tot[0..K) (one workgroup)
+__global__ __launch_bounds__(1024) void fgt_lists_offsets_kernel(const int* __restrict__ tot, int K, int* __restrict__ off)
+{
+    __shared__ int s[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < K; base += 1024) {
+        const int k = base + (int)threadIdx.x;
+        const int v = k < K ? tot[k] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int t = (int)threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (k < K) off[k] = carry + s[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += s[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[K] = carry;
 }
 
 constexpr int FGT_TILE = 128;   // members staged through LDS per step of the centre / model kernels (= their block size)
@@ -435,20 +513,9 @@ __global__ __launch_bounds__(256) void fgt_post_px_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
-size_t fgt_sort_temp_bytes(int n)
-{
-    size_t bytes = 0;
-    unsigned int* k = nullptr;
-    int* v = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)n, 0u, (unsigned)FGT_KEY_BITS, (hipStream_t)0, false);
-    return bytes;
-}
-
-hipError_t fgt_fill_iota(int* iota, int n, hipStream_t s)
-{
-    hipLaunchKernelGGL(fgt_iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, iota, n);
-    return hipGetLastError();
-}
+// scratch of the member-list sort: chunk counters H[G][K] (G * K <= 2^22) + the K label totals
+constexpr size_t FGT_LIST_MAX_COUNTERS = (size_t)1 << 22;
+size_t fgt_sort_temp_bytes(int) { return sizeof(int) * (FGT_LIST_MAX_COUNTERS + 65536 + 16); }
 
 hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_bytes, hipStream_t s)
 {
@@ -471,11 +538,19 @@ hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_b
     else hipLaunchKernelGGL(fgt_kcenter_kernel<0>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, c.K, c.dist, c.indx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    size_t temp = sort_temp_bytes;
-    e = rocprim::radix_sort_pairs(sort_temp, temp, reinterpret_cast<const unsigned int*>(c.indx), c.keys_sorted, c.iota, c.memb,
-                                  (size_t)c.n, 0u, (unsigned)FGT_KEY_BITS, s, false);
+    // member lists (stable counting sort on the labels, see fgt_lists_pass_kernel)
+    int chunk = 64, G = (c.n + chunk - 1) / chunk;                // one step per wave while the counters fit
+    while (G > 4096 || (size_t)G * (size_t)c.K > FGT_LIST_MAX_COUNTERS) { chunk *= 2; G = (c.n + chunk - 1) / chunk; }
+    if (sort_temp_bytes < sizeof(int) * ((size_t)G * c.K + c.K + 1)) return hipErrorInvalidValue;
+    int* H = reinterpret_cast<int*>(sort_temp);
+    int* tot = H + (size_t)G * c.K;
+    e = hipMemsetAsync(H, 0, sizeof(int) * (size_t)G * c.K, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fgt_offsets_kernel, dim3((c.K + 1 + 255) / 256), dim3(256), 0, s, c.keys_sorted, c.n, c.K, c.off);
+    hipLaunchKernelGGL(fgt_lists_pass_kernel<false>, dim3(G), dim3(64), 0, s, c.indx, c.n, c.K, chunk, H, nullptr, nullptr);
+    hipLaunchKernelGGL(fgt_lists_columns_kernel, dim3((c.K + 3) / 4), dim3(256), 0, s, H, G, c.K, tot);
+    hipLaunchKernelGGL(fgt_lists_offsets_kernel, dim3(1), dim3(1024), 0, s, tot, c.K, c.off);
+    const size_t cursors_lds = c.K <= FGT_LIST_LDS_LABELS ? sizeof(int) * (size_t)c.K : 0;
+    hipLaunchKernelGGL(fgt_lists_pass_kernel<true>, dim3(G), dim3(64), cursors_lds, s, c.indx, c.n, c.K, chunk, H, c.off, c.memb);
     hipLaunchKernelGGL(fgt_centers_kernel, dim3(c.K), dim3(FGT_TILE), 0, s, c.x, c.y, c.z, c.memb, c.off, c.K, c.xc);
     return hipGetLastError();
 }
