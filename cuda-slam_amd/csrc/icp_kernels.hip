@@ -114,15 +114,16 @@ __global__ __launch_bounds__(ICP_ROW_POINTS) void icp_moments_rows_kernel(IcpVie
 }
 
 // rows [first, first + count) of ICP_ROW doubles -> out[blockIdx.x] : workgroup g sums its contiguous slice of rows in index
-// order (14 strips of rows, then the strips in order)
+// order (56 strips of rows, then the strips in order)
 // While it is at it, the kernel also deals the NEXT search its work order (sched != null): chunks whose wave walked the box
 // hierarchy in this iteration -- they will again, the flags move slowly -- go to the front, so that those long walks start at once
 // and the short grid-only chunks fill in behind them instead of the other way round (a wave that walks lives ~5x longer).  Scheduling
 // only: which workgroup handles which chunk never changes a result.
-__global__ __launch_bounds__(256) void icp_rows_reduce_kernel(const double* __restrict__ rows, int nrows, int rows_per_block,
-                                                              double* __restrict__ out, IcpSchedule sched)
+constexpr int ROWS_REDUCE_THREADS = 1024;
+__global__ __launch_bounds__(ROWS_REDUCE_THREADS) void icp_rows_reduce_kernel(const double* __restrict__ rows, int nrows, int rows_per_block,
+                                                                             double* __restrict__ out, IcpSchedule sched)
 {
-    constexpr int STRIPS = 256 / ICP_ROW;                      // 14
+    constexpr int STRIPS = ROWS_REDUCE_THREADS / ICP_ROW;      // 56 strips of rows, 18 columns each
     __shared__ double lds[STRIPS * ICP_ROW];
     if (sched.order != nullptr) {
         __shared__ int s_far, s_near, s_base_far, s_base_near;
@@ -130,9 +131,9 @@ __global__ __launch_bounds__(256) void icp_rows_reduce_kernel(const double* __re
         const int hi = lo + rows_per_block < nrows ? lo + rows_per_block : nrows;
         if (threadIdx.x == 0) { s_far = 0; s_near = 0; }
         __syncthreads();
-        // two passes over the slice: count, reserve a range at each end of the order, place (ascending inside the slice)
+        // two passes over the slice: count, reserve a range at each end of the order, place
         int my_far = 0, my_near = 0;
-        for (int r = lo + (int)threadIdx.x; r < hi; r += 256) { if (sched.far[r]) my_far++; else my_near++; }
+        for (int r = lo + (int)threadIdx.x; r < hi; r += ROWS_REDUCE_THREADS) { if (sched.far[r]) my_far++; else my_near++; }
         if (my_far) atomicAdd(&s_far, my_far);
         if (my_near) atomicAdd(&s_near, my_near);
         __syncthreads();
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void icp_rows_reduce_kernel(const double* __re
             s_far = 0; s_near = 0;
         }
         __syncthreads();
-        for (int r0 = lo; r0 < hi; r0 += 256) {                    // slice order kept: ballot-free, one LDS cursor per class
+        for (int r0 = lo; r0 < hi; r0 += ROWS_REDUCE_THREADS) {    // one LDS cursor per class
             const int r = r0 + (int)threadIdx.x;
             if (r < hi) {
                 if (sched.far[r]) sched.order[s_base_far + atomicAdd(&s_far, 1)] = r;
@@ -168,21 +169,35 @@ __global__ __launch_bounds__(256) void icp_rows_reduce_kernel(const double* __re
     }
 }
 
-// sum of `count` reduced rows, column threadIdx.x (< ICP_ROW), in index order
-__device__ __forceinline__ double reduced_column(const double* __restrict__ part, int count)
+// sums[0..18) <- sum of the `count` (<= 64) reduced rows: lane g takes row g, then the fixed butterfly of icp_rows.hpp over the
+// wave.  One load round instead of a serial walk down each column.  Call with all 64 threads; sums is LDS, valid after the barrier.
+__device__ __forceinline__ void reduce_rows_wave(const double* __restrict__ part, int count, double* __restrict__ sums)
 {
-    double tot = 0.0;
-#pragma unroll 8
-    for (int g = 0; g < count; g++) tot += part[(size_t)g * ICP_ROW + threadIdx.x];
-    return tot;
+    const int lane = threadIdx.x & 63;
+    double mom[16], e0 = 0.0, e1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) mom[k] = 0.0;
+    if (lane < count) {
+        const double* __restrict__ row = part + (size_t)lane * ICP_ROW;
+#pragma unroll
+        for (int k = 0; k < 16; k++) mom[k] = row[k];
+        e0 = row[16]; e1 = row[17];
+    }
+    const double x = wave_sum16(mom, lane);
+    const double e = wave_sum2(e0, e1, lane);
+    if ((lane & 3) == 0) sums[((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1)] = x;
+    if ((lane & 31) == 0) sums[ICP_MOMENTS + (lane >> 5)] = e;
+    __syncthreads();
 }
 
 // reduced rows -> state->mom[16], state->err[2] (contiguous in the state block); which = 1 moments, 2 error sums, 3 both
 __global__ __launch_bounds__(64) void icp_rows_to_state_kernel(IcpState* __restrict__ state, const double* __restrict__ part, int count, int which)
 {
     if (state->done != 0) return;
+    __shared__ double sums[ICP_ROW];
+    reduce_rows_wave(part, count, sums);
     if (threadIdx.x >= ICP_ROW) return;
-    const double tot = reduced_column(part, count);
+    const double tot = sums[threadIdx.x];
     if (threadIdx.x < ICP_MOMENTS) { if (which & 1) state->mom[threadIdx.x] = tot; }
     else if (which & 2) state->err[threadIdx.x - ICP_MOMENTS] = tot;
 }
@@ -420,11 +435,11 @@ __global__ __launch_bounds__(64) void icp_solve_deferred_kernel(IcpState* __rest
     if (sched_counters != nullptr && threadIdx.x < 2) sched_counters[threadIdx.x] = 0;   // the reduce kernel's range cursors (IcpSchedule)
     if (state->done != 0) return;
     __shared__ double sums[ICP_ROW];
-    if (threadIdx.x < ICP_ROW) {
-        sums[threadIdx.x] = part != nullptr ? reduced_column(part, count)
-                                            : (threadIdx.x < ICP_MOMENTS ? state->mom[threadIdx.x] : state->err[threadIdx.x - ICP_MOMENTS]);
+    if (part != nullptr) reduce_rows_wave(part, count, sums);
+    else {
+        if (threadIdx.x < ICP_ROW) sums[threadIdx.x] = threadIdx.x < ICP_MOMENTS ? state->mom[threadIdx.x] : state->err[threadIdx.x - ICP_MOMENTS];
+        __syncthreads();
     }
-    __syncthreads();
     if (threadIdx.x != 0) return;
     if (state->err_pending) {            // the previous iteration's error sums have arrived with these moments
         state->err_pending = 0;
@@ -444,10 +459,11 @@ __global__ __launch_bounds__(64) void icp_finalize_pending_kernel(IcpState* __re
 {
     if (state->done != 0 || !state->err_pending) return;
     __shared__ double sums[ICP_ROW];
-    if (threadIdx.x < ICP_ROW)
-        sums[threadIdx.x] = part != nullptr ? reduced_column(part, count)
-                                            : (threadIdx.x < ICP_MOMENTS ? 0.0 : state->err[threadIdx.x - ICP_MOMENTS]);
-    __syncthreads();
+    if (part != nullptr) reduce_rows_wave(part, count, sums);
+    else {
+        if (threadIdx.x < ICP_ROW) sums[threadIdx.x] = threadIdx.x < ICP_MOMENTS ? 0.0 : state->err[threadIdx.x - ICP_MOMENTS];
+        __syncthreads();
+    }
     if (threadIdx.x != 0) return;
     state->err_pending = 0;
     state->err[0] = sums[ICP_MOMENTS];
@@ -478,7 +494,7 @@ hipError_t icp_rows_reduce(const double* rows, int nrows, double* part, hipStrea
     const int per = (nrows + g - 1) / g;
     IcpSchedule sc{};
     if (sched != nullptr) sc = *sched;
-    hipLaunchKernelGGL(icp_rows_reduce_kernel, dim3(g), dim3(256), 0, s, rows, nrows, per, part, sc);
+    hipLaunchKernelGGL(icp_rows_reduce_kernel, dim3(g), dim3(ROWS_REDUCE_THREADS), 0, s, rows, nrows, per, part, sc);
     return hipGetLastError();
 }
 

@@ -509,7 +509,8 @@ int resolve_nn_mode(const mi_ctx* c, int nn_mode, int m_local)
     const int forced = c->tune.nn_force_mode;
     if (forced == MI_NN_BRUTEFORCE || forced == MI_NN_TREE || forced == MI_NN_GRID) nn_mode = forced;
     if (nn_mode == MI_NN_BRUTEFORCE || nn_mode == MI_NN_TREE || nn_mode == MI_NN_GRID) return nn_mode;
-    // measured crossover on MI355X, every-pair against indexed search (N = M): DESIGN.md K1g
+    // measured crossover on MI355X, every-pair against the cell grid, ms per ICP step at N = M (profiles/r02_crossover.log):
+    // 8 000: 0.050 / 0.056, 12 000: 0.065 / 0.060, 16 000: 0.087 / 0.066, 24 000: 0.143 / 0.074, 50 000: 0.473 / 0.082
     return m_local >= MI_NN_INDEX_MIN_POINTS ? MI_NN_GRID : MI_NN_BRUTEFORCE;
 }
 

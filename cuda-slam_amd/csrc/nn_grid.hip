@@ -266,10 +266,13 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
             const float g2 = gy * gy + gz * gz;
             const float r2 = fminf(best, cap2);
             // a row is skipped only if it is strictly farther than the search radius: then it cannot win or tie
+            const bool near = zok && alive && iy >= 0 && iy < g.ny && g2 <= r2;
+            if (__builtin_amdgcn_ballot_w64(near) == 0ull) continue;      // (before the costlier x-range arithmetic)
             const float rem = fmaxf(r2 * 1.000001f - g2, 0.f);
-            const float dux = __builtin_sqrtf(rem) * g.inv_h * 1.00001f + 1e-3f;
+            // raw v_sqrt_f32 (1 ulp, denormals flushed): both are covered by the slack that follows
+            const float dux = __builtin_amdgcn_sqrtf(rem) * g.inv_h * 1.00001f + 1e-3f;
             const float flo = floorf(u0 - dux), fhi = floorf(u0 + dux);
-            const bool ok = zok && alive && iy >= 0 && iy < g.ny && g2 <= r2 && fhi >= 0.f && flo <= (float)(g.nx - 1);
+            const bool ok = near && fhi >= 0.f && flo <= (float)(g.nx - 1);
             if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
             unsigned int s = 0u, e = 0u;
             if (ok) {

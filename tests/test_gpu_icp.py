@@ -211,6 +211,33 @@ def test_cfg2_size_properties(ctx, capi, oracle):
     assert frob(R1, t1, R64, ca - R64 @ cb) < 5e-6
 
 
+def test_ten_million_icp_iterations(ctx, capi, oracle):
+    # cfg 5's size (N = M = 1e7) through the whole ICP loop, not just the search: three iterations on the default path (fused
+    # cell-grid search): the error falls, the registration after ONE iteration equals an fp64 Kabsch solve of its own pairs,
+    # sampled rows of those pairs are the oracle's nearest neighbours, and the loop is bitwise reproducible
+    before, after, Rt, tt = synth_cloud(10000000)
+    ctx.icp_load(before, after, capi.icp_params(max_iterations=3))
+    errs = []
+    for _ in range(3):
+        ctx.icp_run(1)
+        errs.append(ctx.icp_result()[3])
+    R3, t3, it3, e3, why = ctx.icp_result()
+    assert it3 == 3 and errs[0] > errs[1] > errs[2] > 0
+    R1, t1, it1, e1 = ctx.icp_register(before, after, capi.icp_params(max_iterations=1))
+    idx, d2 = ctx.nn_search(before, after)                       # the pairs of iteration 0 (identity start)
+    rows = np.random.default_rng(5).choice(len(before), 48, replace=False)
+    ridx, rd2 = oracle.nn_search(before[rows], after)
+    assert np.array_equal(idx[rows], ridx) and np.array_equal(d2[rows].view(np.uint32), rd2.view(np.uint32))
+    B, A = before.astype(np.float64), after[idx].astype(np.float64)
+    cb, ca = B.mean(0), A.mean(0)
+    U, S, Vt = np.linalg.svd((A - ca).T @ (B - cb))
+    R64 = U @ np.diag([1.0, 1.0, np.sign(np.linalg.det(U @ Vt))]) @ Vt
+    assert frob(R1, t1, R64, ca - R64 @ cb) < 2e-5
+    assert abs(e1 - errs[0]) == 0
+    again = ctx.icp_register(before, after, capi.icp_params(max_iterations=3))
+    assert np.array_equal(again[0], R3) and np.array_equal(again[1], t3) and again[3] == e3
+
+
 def test_full_bench_size_iterations(ctx, capi):
     # BASELINE.json's headline configuration (N = M = 1e6, the bench workload): the first iterations through both searches are
     # bitwise the same registration, the error falls monotonically, and one iteration equals an fp64 Kabsch solve of its pairs
