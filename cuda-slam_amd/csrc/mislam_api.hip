@@ -347,7 +347,7 @@ extern "C" int mi_profile_search_stats(mi_ctx* c, int enable, unsigned long long
             MI_HIP(hipMemcpyAsync(h.data(), c->nn_stats.p, sizeof(unsigned long long) * words, hipMemcpyDeviceToHost, c->stream));
             MI_HIP(hipStreamSynchronize(c->stream));
             for (size_t r = 0; r < (size_t)GRID_STATS_ROWS; r++)
-                for (int i = 0; i < 8; i++) out[i] += h[r * 8 + i];
+                for (int i = 0; i < 8; i++) out[i] = i == 7 ? std::max(out[i], h[r * 8 + i]) : out[i] + h[r * 8 + i];   // [7] is a maximum
         }
     }
     c->nn_stats_on = enable != 0;

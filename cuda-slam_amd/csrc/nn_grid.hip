@@ -397,7 +397,11 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
                 atomicAdd(&srow[4], (unsigned long long)v0);
                 atomicAdd(&srow[5], (unsigned long long)v1);
                 atomicAdd(&srow[6], 1ull);
+#ifdef MISLAM_DEV_WALK_CLOCK
                 atomicAdd(&srow[7], wc);
+#else
+                atomicMax(&srow[7], (unsigned long long)(v0 + v1));     // the longest walk, in steps
+#endif
             }
         }
     }

@@ -68,6 +68,31 @@ __device__ __forceinline__ unsigned int spread10(unsigned int v)   // 10 bits ->
     return v;
 }
 
+// Position of a 10-bit lattice point along the HILBERT curve of the bounding box (Skilling's transpose form, "Programming the
+// Hilbert curve", 2004).  Unlike the Z-order the Hilbert curve has no jumps: any run of consecutive points is spatially compact.
+// That is what the cooperative walk wants from the moving cloud -- a wave's 64 points walk TOGETHER, and a wave that straddled a
+// jump of the Z-curve paid for two distant groups (its walk, the longest of the launch, set the launch's duration) -- and what
+// the implicit heap wants from the fixed cloud (every subtree is a run of consecutive leaves).
+__device__ __forceinline__ unsigned int hilbert30(unsigned int x, unsigned int y, unsigned int z)
+{
+    unsigned int X[3] = {x, y, z};
+    for (unsigned int Q = 1u << 9; Q > 1u; Q >>= 1) {
+        const unsigned int P = Q - 1u;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (X[i] & Q) X[0] ^= P;
+            else { const unsigned int t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    X[1] ^= X[0];
+    X[2] ^= X[1];
+    unsigned int t = 0;
+    for (unsigned int Q = 1u << 9; Q > 1u; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1u;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    return (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
+}
+
 __global__ __launch_bounds__(256) void tree_morton_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                           const float* __restrict__ z, int m, const float* __restrict__ bbox,
                                                           unsigned int* __restrict__ codes, int* __restrict__ order)
@@ -82,7 +107,11 @@ __global__ __launch_bounds__(256) void tree_morton_kernel(const float* __restric
         u = fminf(fmaxf(u * 1024.f, 0.f), 1023.f);
         q[a] = (unsigned int)u;
     }
+#ifdef MISLAM_DEV_MORTON
     codes[j] = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
+#else
+    codes[j] = hilbert30(q[0], q[1], q[2]);
+#endif
     order[j] = j;
 }
 

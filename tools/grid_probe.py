@@ -26,6 +26,6 @@ with capi.Context(0) as ctx:
         ms = {capi.KERNEL_NAMES[k]: ctx.profile_get(k) for k in range(len(capi.KERNEL_NAMES))}
         err = ctx.icp_result()[3]
         ms = {k: (v[0] / max(v[1], 1), v[1]) for k, v in ms.items()}
-        print("it %2d+  nn %.3f ms  solve %.3f  flush %.3f+%.3f  err %.4g  cand/pt %.1f  rows/pt %.2f  hierarchy %.2f%%  waves %d  nodes/wave %.0f  leaves/wave %.0f  walk cycles/wave %.0f" % (
+        print("it %2d+  nn %.3f ms  solve %.3f  flush %.3f+%.3f  err %.4g  cand/pt %.1f  rows/pt %.2f  hierarchy %.2f%%  waves %d  nodes/wave %.0f  leaves/wave %.0f  longest walk %d steps" % (
             it, ms["nn"][0], ms["solve"][0], ms["transform"][0], ms["finalize"][0], err, cand / max(pts, 1), rows / max(pts, 1),
-            100.0 * hard / max(pts, 1), waves, nodes / max(waves, 1), leaves / max(waves, 1), cyc / max(waves, 1)), flush=True)
+            100.0 * hard / max(pts, 1), waves, nodes / max(waves, 1), leaves / max(waves, 1), cyc), flush=True)

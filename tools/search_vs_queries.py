@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Developer tool: what one rank of a W-GPU run sees -- the box-hierarchy search for N/W moving points against the whole 10^6
-fixed cloud (the moving cloud is what the ranks split), 50 iterations after 2 warm-up ones."""
+"""Developer tool: what one rank of a W-GPU run sees -- the default (cell-grid) search for N/W moving points against the whole 10^6
+fixed cloud (the moving cloud is what the ranks split), 20 iterations after 5 warm-up ones."""
 import json
 import os
 import sys
@@ -20,11 +20,11 @@ def main():
     for w in (1, 2, 4, 8):
         n = len(before) // w
         ctx.icp_load(before[:n], after, capi.icp_params(eps=0.0, max_iterations=-1))
-        ctx.icp_run(2)
+        ctx.icp_run(5)
         ctx.profile_enable(True)
         ctx.profile_select([capi.KERNEL_NN])
         ctx.profile_reset()
-        ctx.icp_run(50)
+        ctx.icp_run(20)
         ms, launches = ctx.profile_get(capi.KERNEL_NN)
         ctx.profile_select(None)
         ctx.profile_reset()
