@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool: randomized soak of the box-hierarchy search against the every-pair search (bit-exact indices and distances):
+"""Developer tool: randomized soak of the box-hierarchy and cell-grid searches against the every-pair search (bit-exact indices and distances):
 random sizes up to 3e5, uniform / clustered / planar / duplicated clouds, both distance arithmetics, repeated searches with
 moving sources so that warm starts (the seeds a previous search leaves) are exercised through ICP as well."""
 import os
@@ -42,13 +42,16 @@ def main():
             src[:len(take)] = tgt[take]                  # exact hits
         mode = int(rng.integers(0, 2))
         a = ctx.nn_search(src, tgt, mode, capi.NN_BRUTEFORCE)
-        b = ctx.nn_search(src, tgt, mode, capi.NN_TREE)
-        ok = np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
-        if ok and k % 4 == 0 and n >= 10 and m >= 10:    # a short ICP through both searches: bitwise the same trajectory
-            p1 = capi.icp_params(eps=0.0, max_iterations=4, nn_mode=capi.NN_BRUTEFORCE, dist_mode=mode)
-            p2 = capi.icp_params(eps=0.0, max_iterations=4, nn_mode=capi.NN_TREE, dist_mode=mode)
-            r1, r2 = ctx.icp_register(src, tgt, p1), ctx.icp_register(src, tgt, p2)
-            ok = r1[2] == r2[2] and np.array_equal(r1[0], r2[0]) and np.array_equal(r1[1], r2[1])
+        ok = True
+        for indexed in (capi.NN_TREE, capi.NN_GRID):
+            b = ctx.nn_search(src, tgt, mode, indexed)
+            ok = ok and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        if ok and k % 4 == 0 and n >= 10 and m >= 10:    # a short ICP through every search (the grid's is the fused iteration):
+            runs = []                                    # bitwise the same trajectory
+            for nn in (capi.NN_BRUTEFORCE, capi.NN_TREE, capi.NN_GRID):
+                runs.append(ctx.icp_register(src, tgt, capi.icp_params(eps=0.0, max_iterations=4, nn_mode=nn, dist_mode=mode)))
+            r1 = runs[0]
+            ok = all(r1[2] == r2[2] and r1[3] == r2[3] and np.array_equal(r1[0], r2[0]) and np.array_equal(r1[1], r2[1]) for r2 in runs[1:])
         bad += 0 if ok else 1
         if not ok or k % 20 == 0:
             print("case %d n=%d m=%d mode=%d: %s" % (k, n, m, mode, "ok" if ok else "MISMATCH"), flush=True)
