@@ -62,7 +62,8 @@ Point_f rand_point(const Point_f& lo, const Point_f& hi) { return {rand_float(lo
 
 CpuCloud subcloud(const CpuCloud& c, int size)   // common.cpp:25-37
 {
-    if (size >= (int)c.size()) return c;
+    // `int >= size_t` in the reference: the int is converted, so a NEGATIVE size compares as huge and returns the cloud whole
+    if ((size_t)size >= c.size()) return c;
     auto perm = random_permutation((int)c.size());
     perm.resize((size_t)size);
     CpuCloud out;
@@ -220,7 +221,8 @@ std::pair<CpuCloud, CpuCloud> GetCloudsFromConfigOnDevice(const Configuration& c
     } b{&raw_before, (int)raw_before.size(), {}, {}, {}, {}, {}}, a{&raw_after, (int)raw_after.size(), {}, {}, {}, {}, {}};
 
     const auto draw_subcloud = [](Side& s, const std::optional<int>& resize) {
-        if (!resize || *resize >= (int)s.raw->size()) return;          // GetSubcloud returns the cloud and draws nothing
+        // GetSubcloud returns the cloud and draws nothing (its comparison is int against size_t: a negative value counts as huge)
+        if (!resize || (size_t)*resize >= s.raw->size()) return;
         s.sub = random_permutation((int)s.raw->size());
         s.sub.resize((size_t)std::max(*resize, 0));
         s.n = (int)s.sub.size();

@@ -84,6 +84,21 @@ def test_obj_face_corner_expansion_and_transform(tmp_path):
     assert np.allclose(sorted(map(tuple, np.round(after, 5))), want, atol=2e-5)
 
 
+def test_negative_resize_returns_the_whole_cloud(tmp_path):
+    # GetSubcloud compares `int subcloudSize >= cloud.size()` (common.cpp:27): the int is converted to size_t, so a negative
+    # "cloud-*-resize" counts as huge and the cloud comes back whole, no permutation drawn; an in-range value subsamples
+    verts = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)]
+    write_obj(tmp_path / "a.obj", verts, [(1, 2, 3), (1, 2, 3, 4)])
+    whole = run(dict(BASE, **{"random-seed": 5}), tmp_path, dump=True)
+    b0, a0 = read_dump(tmp_path / "clouds.bin")
+    r = run(dict(BASE, **{"random-seed": 5, "cloud-before-resize": -3, "cloud-after-resize": -1}), tmp_path, dump=True)
+    assert whole.returncode == 0 and r.returncode == 0
+    b1, a1 = read_dump(tmp_path / "clouds.bin")
+    assert np.array_equal(b0, b1) and np.array_equal(a0, a1)
+    r = run(dict(BASE, **{"random-seed": 5, "cloud-before-resize": 4}), tmp_path, dump=True)
+    assert r.returncode == 0 and read_dump(tmp_path / "clouds.bin")[0].shape == (4, 3)
+
+
 @pytest.mark.skipif(not os.path.exists(REF_BUNNY), reason="reference data absent (build container only)")
 def test_bunny_input_stage_reproduces_the_golden_clouds(tmp_path, golden):
     # config/default.json + random-seed 666: same OBJ expansion, normalisation, shuffles and transform as the clouds the
