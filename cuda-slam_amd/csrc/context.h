@@ -101,6 +101,7 @@ struct mi_ctx {
     mislam::DevBuf<float> staging;                       // AoS upload/download staging
     mislam::DevBuf<float> bx, by, bz;                    // original moving cloud, SoA
     mislam::DevBuf<float> cx, cy, cz;                    // current (transformed) moving cloud, SoA
+    mislam::DevBuf<float> ax, ay, az;                    // multi-GPU load scratch: the whole moving cloud in Hilbert order
     mislam::DevBuf<float> tx, ty, tz;                    // this rank's fixed-cloud shard, SoA (K1 scalar streams)
     mislam::DevBuf<float4> tgt4;                         // same shard as float4 (gathers)
     mislam::DevBuf<unsigned long long> keys;

@@ -544,6 +544,27 @@ static inline int blocks_for(int n, int cap)
     return b;
 }
 
+__global__ __launch_bounds__(256) void deal_chunks_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+                                                          int n_all, int rank, int world, int n_local, int n_pad, float* __restrict__ dx,
+                                                          float* __restrict__ dy, float* __restrict__ dz)
+{
+    static_assert(ICP_CHUNK_POINTS == ICP_ROW_POINTS, "a dealt chunk is one row of partial sums");
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pad) return;
+    const int il = i < n_local ? i : n_local - 1;
+    const long long g = ((long long)(il / ICP_CHUNK_POINTS) * world + rank) * ICP_CHUNK_POINTS + il % ICP_CHUNK_POINTS;
+    const int j = g < n_all ? (int)g : n_all - 1;
+    dx[i] = sx[j]; dy[i] = sy[j]; dz[i] = sz[j];
+}
+
+hipError_t deal_chunks_soa(const float* sx, const float* sy, const float* sz, int n_all, int rank, int world, int n_local, int n_pad,
+                           float* dx, float* dy, float* dz, hipStream_t s)
+{
+    if (n_pad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(deal_chunks_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, s, sx, sy, sz, n_all, rank, world, n_local, n_pad, dx, dy, dz);
+    return hipGetLastError();
+}
+
 hipError_t fill_keys(unsigned long long* keys, int n, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;

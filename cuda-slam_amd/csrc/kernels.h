@@ -86,7 +86,12 @@ struct IcpRules {
     int seq_sums;                    // MI_SUM_CPU_SEQUENTIAL: the error comes from state->seq_sum_err
 };
 
+constexpr int ICP_CHUNK_POINTS = 64;          // moving points per wave / per row of partial sums (icp_rows.hpp ICP_ROW_POINTS)
 hipError_t fill_keys(unsigned long long* keys, int n, hipStream_t s);
+// dst[i] (i < n_local) = the i-th point of the 64-point chunks rank, rank + world, rank + 2*world ... of src (n_all points); entries
+// [n_local, n_pad) replicate the last one
+hipError_t deal_chunks_soa(const float* sx, const float* sy, const float* sz, int n_all, int rank, int world, int n_local, int n_pad,
+                           float* dx, float* dy, float* dz, hipStream_t s);
 hipError_t aos_to_soa(const float* aos, int n, int n_pad, float* x, float* y, float* z, float4* packed, hipStream_t s);
 hipError_t soa_to_aos(const float* x, const float* y, const float* z, int n, float* aos, hipStream_t s);
 hipError_t unpack_keys(const unsigned long long* keys, const int* order, int n, int* idx, float* d2, hipStream_t s);

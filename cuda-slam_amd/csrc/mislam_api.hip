@@ -246,7 +246,7 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     cpd_workspace_destroy(c);
     c->staging.release();
     c->bx.release(); c->by.release(); c->bz.release();
-    c->cx.release(); c->cy.release(); c->cz.release();
+    c->cx.release(); c->cy.release(); c->cz.release(); c->ax.release(); c->ay.release(); c->az.release();
     c->tx.release(); c->ty.release(); c->tz.release();
     c->tgt4.release(); c->keys.release(); c->part_mom.release(); c->part_err.release();
     c->idx_tmp.release(); c->keep_tmp.release();
@@ -722,22 +722,43 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
         const bool indexed = resolve_nn_mode(c, params->nn_mode, params->shard_mode == MI_SHARD_TARGET ? per_rank : n_after) != MI_NN_BRUTEFORCE;
         c->source_sharded = params->shard_mode == MI_SHARD_SOURCE || (params->shard_mode == MI_SHARD_AUTO && indexed);
     }
-    if (c->source_sharded) {
+    // Source sharding.  A rank's moving points should be (a) spatially DENSE wave by wave -- a wave's 64 points walk the box
+    // hierarchy together, and sparse waves walk longer -- and (b) the same mix of easy and hard regions on every rank.  So every
+    // rank orders the WHOLE moving cloud along the Hilbert curve (1 ms) and keeps the 64-point chunks rank, rank + W, rank + 2W ...
+    // of that order.  (Clouds too small for a few chunks per rank are cut into contiguous slices of the caller's order instead.)
+    const int n_all = n_before;
+    const bool deal_chunks = c->source_sharded && n_all >= 4 * ICP_CHUNK_POINTS * c->world;
+    if (c->source_sharded && !deal_chunks) {
         int slo = 0, shi = 0;
         shard_range(n_before, c->rank, c->world, &slo, &shi);
         before_xyz += 3 * (size_t)slo;
         n_before = shi - slo;
     }
+    if (deal_chunks) {
+        const int chunks = (n_all + ICP_CHUNK_POINTS - 1) / ICP_CHUNK_POINTS;
+        const int mine = (chunks - c->rank + c->world - 1) / c->world;             // chunks rank, rank + W, ...
+        const bool has_last = (chunks - 1) % c->world == c->rank;                    // the (possibly partial) last chunk of the cloud
+        n_before = mine * ICP_CHUNK_POINTS - (has_last ? chunks * ICP_CHUNK_POINTS - n_all : 0);
+    }
     c->n = n_before;
     c->n_pad = round_up(n_before, NN_SRC_PAD);
     const size_t np = (size_t)c->n_pad;
     MI_TRY(c->bx.reserve(np)); MI_TRY(c->by.reserve(np)); MI_TRY(c->bz.reserve(np));
-    MI_TRY(c->cx.reserve(np)); MI_TRY(c->cy.reserve(np)); MI_TRY(c->cz.reserve(np));
     MI_TRY(c->keys.reserve(np));
     MI_TRY(reserve_rows(c));
-    // moving cloud: upload in the caller's order (cx.. as scratch), keep it Morton-sorted in bx..
-    MI_TRY(upload_soa(c, before_xyz, n_before, c->n_pad, c->cx.p, c->cy.p, c->cz.p, nullptr));
-    MI_TRY(sort_sources(c, c->cx.p, c->cy.p, c->cz.p, n_before, c->n_pad, c->bx.p, c->by.p, c->bz.p));
+    if (deal_chunks) {
+        const int all_pad = round_up(n_all, NN_SRC_PAD);
+        MI_TRY(c->cx.reserve((size_t)all_pad)); MI_TRY(c->cy.reserve((size_t)all_pad)); MI_TRY(c->cz.reserve((size_t)all_pad));
+        MI_TRY(c->ax.reserve((size_t)all_pad)); MI_TRY(c->ay.reserve((size_t)all_pad)); MI_TRY(c->az.reserve((size_t)all_pad));
+        MI_TRY(upload_soa(c, before_xyz, n_all, all_pad, c->cx.p, c->cy.p, c->cz.p, nullptr));
+        MI_TRY(sort_sources(c, c->cx.p, c->cy.p, c->cz.p, n_all, all_pad, c->ax.p, c->ay.p, c->az.p));
+        MI_HIP(deal_chunks_soa(c->ax.p, c->ay.p, c->az.p, n_all, c->rank, c->world, c->n, c->n_pad, c->bx.p, c->by.p, c->bz.p, c->stream));
+    } else {
+        MI_TRY(c->cx.reserve(np)); MI_TRY(c->cy.reserve(np)); MI_TRY(c->cz.reserve(np));
+        // moving cloud: upload in the caller's order (cx.. as scratch), keep it Hilbert-sorted in bx..
+        MI_TRY(upload_soa(c, before_xyz, n_before, c->n_pad, c->cx.p, c->cy.p, c->cz.p, nullptr));
+        MI_TRY(sort_sources(c, c->cx.p, c->cy.p, c->cz.p, n_before, c->n_pad, c->bx.p, c->by.p, c->bz.p));
+    }
     if (params->sum_mode == MI_SUM_CPU_SEQUENTIAL) {   // the sequential sums run in the CALLER's point order
         MI_TRY(c->sinv.reserve((size_t)n_before));
         MI_TRY(c->resid.reserve(np));

@@ -251,15 +251,25 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
     // A starting candidate far beyond the grid's reach says the query lies well outside the fixed cloud (or its neighbourhood is
     // empty): scanning (2 GRID_DU_MAX + 1)^2 mostly empty rows first would only delay the walk.  Speed only -- the walk is exact.
     bool alive = !(best < __builtin_inff() && best > cap2 * (GRID_FAR_FACTOR * GRID_FAR_FACTOR));
+#ifdef MISLAM_DEV_SKIP_GRID           // timing experiments only (tools/build_variant.sh): wrong answers
+    if (alive) return false;
+#endif
     // the query's own slabs, clamped into the grid (a query outside the grid starts from the nearest boundary slab)
     const int cy = cell_index(u1, g.ny), cz = cell_index(u2, g.nz);
     constexpr int SPAN = 2 * (int)GRID_DU_MAX + 3;             // slabs per axis that can lie within GRID_DU_MAX cells
     int budget = GRID_CAND_BUDGET;
+    // Slabs come nearest first, alternating sides (0, -1, +1, -2, +2 ...), and a side's gaps only grow with the offset while the
+    // radius only shrinks: once no lane needs either slab of an offset, no lane needs any slab beyond it -- the loop ends there.
+    bool z_prev_none = false;
     for (int kz = 0; kz < SPAN; kz++) {
         const int iz = cz + centre_out(kz);
         const float gz = gap_cells(u2, iz) * g.h_lo;
         const bool zok = alive && iz >= 0 && iz < g.nz && gz * gz <= fminf(best, cap2);
-        if (__builtin_amdgcn_ballot_w64(zok) == 0ull) continue;
+        const bool z_none = __builtin_amdgcn_ballot_w64(zok) == 0ull;
+        if (kz > 0 && (kz & 1) == 0 && z_none && z_prev_none) break;
+        z_prev_none = z_none;
+        if (z_none) continue;
+        bool y_prev_none = false;
         for (int ky = 0; ky < SPAN; ky++) {
             const int iy = cy + centre_out(ky);
             const float gy = gap_cells(u1, iy) * g.h_lo;
@@ -267,7 +277,10 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
             const float r2 = fminf(best, cap2);
             // a row is skipped only if it is strictly farther than the search radius: then it cannot win or tie
             const bool near = zok && alive && iy >= 0 && iy < g.ny && g2 <= r2;
-            if (__builtin_amdgcn_ballot_w64(near) == 0ull) continue;      // (before the costlier x-range arithmetic)
+            const bool y_none = __builtin_amdgcn_ballot_w64(near) == 0ull;
+            if (ky > 0 && (ky & 1) == 0 && y_none && y_prev_none) break;
+            y_prev_none = y_none;
+            if (y_none) continue;                                         // (before the costlier x-range arithmetic)
             const float rem = fmaxf(r2 * 1.000001f - g2, 0.f);
             // raw v_sqrt_f32 (1 ulp, denormals flushed): both are covered by the slack that follows
             const float dux = __builtin_amdgcn_sqrtf(rem) * g.inv_h * 1.00001f + 1e-3f;

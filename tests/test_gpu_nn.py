@@ -121,6 +121,37 @@ def test_grid_boundary_and_outside_queries(ctx, capi, oracle, mode):
     assert np.array_equal(idx, ridx) and np.array_equal(d2.view(np.uint32), rd2.view(np.uint32))
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_grid_on_awkward_coordinate_ranges(ctx, capi, mode):
+    # coordinates far from the origin (the fp32 lattice is coarser than the cell size: duplicates, crowded cells), a thin slab with
+    # a huge aspect ratio, a tiny cloud (extents ~1e-6), a line stretched over 1e6 with dense knots, two far-apart clusters: the
+    # grid's plan, its slacks and the hierarchy fallback against the every-pair search, bit for bit
+    rng = np.random.default_rng(2026)
+    n = 20000
+    cases = []
+    cases.append(1.0e5 + rng.uniform(0, 1, (n, 3)))
+    cases.append(np.stack([rng.uniform(0, 1000, n), rng.uniform(0, 1000, n), rng.uniform(0, 1e-3, n)], 1))
+    cases.append(rng.uniform(-1, 1, (n, 3)) * 1e-6)
+    knots = rng.uniform(0, 1e6, 40)
+    cases.append(np.stack([knots[rng.integers(0, 40, n)] + rng.normal(scale=0.01, size=n), np.zeros(n), rng.normal(scale=1e-4, size=n)], 1))
+    cases.append(np.concatenate([rng.normal(loc=0, scale=0.1, size=(n // 2, 3)), rng.normal(loc=5e3, scale=0.1, size=(n // 2, 3))]))
+    for tgt in cases:
+        tgt = tgt.astype(np.float32)
+        lo, hi = tgt.min(0), tgt.max(0)
+        ext = np.maximum(hi - lo, 1e-9)
+        src = np.concatenate([tgt[rng.integers(0, len(tgt), 3000)] + (rng.normal(size=(3000, 3)) * ext * 1e-3).astype(np.float32),
+                              (lo + rng.uniform(-0.3, 1.3, (3000, 3)) * ext).astype(np.float32),
+                              tgt[:500]]).astype(np.float32)
+        a = ctx.nn_search(src, tgt, mode, capi.NN_BRUTEFORCE)
+        for indexed in (capi.NN_GRID, capi.NN_TREE):
+            b = ctx.nn_search(src, tgt, mode, indexed)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), indexed
+        # and through the fused ICP iteration (warm starts, match slots): same trajectory as the every-pair path
+        runs = [ctx.icp_register(src, tgt, capi.icp_params(eps=0.0, max_iterations=3, dist_mode=mode, nn_mode=nn))
+                for nn in (capi.NN_BRUTEFORCE, capi.NN_GRID)]
+        assert runs[0][2] == runs[1][2] and np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+
+
 def test_large_sampled_rows_and_properties(ctx, capi, oracle):
     # BASELINE size class (cfg 2, N = M = 1e5): full check is 1e10 pairs -- the oracle re-computes a sample of source rows;
     # the rest is covered by size-independent properties (self-search is the identity with d2 = 0; the reported d2 is the
