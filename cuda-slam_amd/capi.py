@@ -37,7 +37,7 @@ EXPORTS = [
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_sigma_squared_mode", "mi_cpd_estep",
     "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
     "mi_prepare_params_default", "mi_prepare_cloud",
-    "mi_cpd_mstep", "mi_profile_enable", "mi_profile_select", "mi_profile_reset", "mi_profile_get", "mi_profile_search_stats", "mi_nn_kernel_name",
+    "mi_cpd_mstep", "mi_profile_enable", "mi_profile_select", "mi_profile_reset", "mi_profile_get", "mi_profile_search_stats", "mi_selftest_sort_pairs", "mi_nn_kernel_name",
 ]
 
 
@@ -442,10 +442,18 @@ class Context:
 
     def search_stats(self, enable):
         """Counters of the cell-grid search since they were last enabled: (candidates, rows, to_hierarchy, points, nodes, leaves,
-        walking waves, 0)."""
+        walking waves, longest single walk)."""
         out = (C.c_ulonglong * 8)()
         _check(lib().mi_profile_search_stats(self._h, 1 if enable else 0, out))
         return tuple(int(v) for v in out)
+
+    def selftest_sort_pairs(self, keys, values, bits=30):
+        """The library's device radix sort on host arrays: (sorted keys, values carried along), stable."""
+        k = np.ascontiguousarray(keys, dtype=np.uint32).copy()
+        v = np.ascontiguousarray(values, dtype=np.int32).copy()
+        assert k.shape == v.shape and k.ndim == 1
+        _check(lib().mi_selftest_sort_pairs(self._h, k.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), int(k.size), int(bits)))
+        return k, v
 
     def nn_kernel_name(self, n_moving, m_fixed_local, nn_mode=NN_AUTO):
         lib().mi_nn_kernel_name.restype = C.c_char_p

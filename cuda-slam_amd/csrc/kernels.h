@@ -87,6 +87,10 @@ struct IcpRules {
 };
 
 constexpr int ICP_CHUNK_POINTS = 64;          // moving points per wave / per row of partial sums (icp_rows.hpp ICP_ROW_POINTS)
+// stable LSD radix sort of (key, value) pairs on the low `bits` of the keys (radix_sort.hip); the *_in arrays are scratch afterwards
+size_t radix_sort_temp_bytes(int n);
+hipError_t radix_sort_pairs_u32(void* temp, unsigned int* keys_in, unsigned int* keys_out, int* vals_in, int* vals_out, int n, int bits,
+                                hipStream_t s);
 hipError_t fill_keys(unsigned long long* keys, int n, hipStream_t s);
 // dst[i] (i < n_local) = the i-th point of the 64-point chunks rank, rank + world, rank + 2*world ... of src (n_all points); entries
 // [n_local, n_pad) replicate the last one

@@ -355,6 +355,28 @@ extern "C" int mi_profile_search_stats(mi_ctx* c, int enable, unsigned long long
     return MI_OK;
 }
 
+extern "C" int mi_selftest_sort_pairs(mi_ctx* c, unsigned int* keys, int* values, int n, int bits)
+{
+    if (!c || n < 0 || (n > 0 && (!keys || !values)) || (bits != 10 && bits != 20 && bits != 30)) {
+        set_error("mi_selftest_sort_pairs: bad argument");
+        return MI_ERR_INVALID_ARG;
+    }
+    if (n == 0) return MI_OK;
+    MI_HIP(hipSetDevice(c->device));
+    DevBuf<unsigned int> k0, k1;
+    DevBuf<int> v0, v1;
+    DevBuf<unsigned char> temp;
+    MI_TRY(k0.reserve((size_t)n)); MI_TRY(k1.reserve((size_t)n)); MI_TRY(v0.reserve((size_t)n)); MI_TRY(v1.reserve((size_t)n));
+    MI_TRY(temp.reserve(radix_sort_temp_bytes(n)));
+    MI_HIP(hipMemcpyAsync(k0.p, keys, sizeof(unsigned int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    MI_HIP(hipMemcpyAsync(v0.p, values, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    MI_HIP(radix_sort_pairs_u32(temp.p, k0.p, k1.p, v0.p, v1.p, n, bits, c->stream));
+    MI_HIP(hipMemcpyAsync(keys, k1.p, sizeof(unsigned int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP(hipMemcpyAsync(values, v1.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
 extern "C" int mi_profile_get(mi_ctx* c, int kernel, double* total_ms, long long* launches)
 {
     if (!c || kernel < 0 || kernel >= MI_KERNEL_COUNT) { set_error("mi_profile_get: bad argument"); return MI_ERR_INVALID_ARG; }

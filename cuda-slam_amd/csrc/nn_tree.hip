@@ -4,7 +4,7 @@
 // common.cpp:446-462; the result is IDENTICAL to the every-pair search, bit for bit (the two rules in nn_walk.hpp).
 //
 // Build (once per fixed cloud / shard -- the fixed cloud does not move during ICP): bounding box -> 30-bit Morton codes ->
-// radix sort (rocPRIM device primitive; one-time index build at load, never on the per-iteration path) -> leaves of TREE_LEAF
+// radix sort (radix_sort.hip, own kernels; one-time index build at load) -> leaves of TREE_LEAF
 // consecutive points -> implicit binary heap of boxes over the leaves, padded to a power of two with empty boxes.  The walk
 // reads compact copies: a node's box as six floats (eight consecutive boxes per step), a leaf as x[8] y[8] z[8], the global
 // indices in a side array that is read only for the winner and on exact ties.
@@ -16,8 +16,6 @@
 // crowded cells); MI_NN_TREE still runs it for every point.  The per-lane walk forms of round 1 are gone; their measurements stay
 // in DESIGN.md.
 #include <hip/hip_runtime.h>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "kernels.h"
 #include "nn_tree.h"
@@ -115,14 +113,7 @@ __global__ __launch_bounds__(256) void tree_morton_kernel(const float* __restric
     order[j] = j;
 }
 
-size_t tree_sort_temp_bytes(int m)
-{
-    size_t bytes = 0;
-    unsigned int* k = nullptr;
-    int* v = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)m, 0u, 30u, (hipStream_t)0, false);
-    return bytes;
-}
+size_t tree_sort_temp_bytes(int m) { return radix_sort_temp_bytes(m); }
 
 hipError_t cloud_bbox(const float* x, const float* y, const float* z, int m, float* partials, float* bbox, hipStream_t s)
 {
@@ -140,8 +131,8 @@ hipError_t morton_order(const MortonArgs& a, hipStream_t s)
     hipError_t be = cloud_bbox(a.x, a.y, a.z, m, a.bbox_partials, a.bbox, s);
     if (be != hipSuccess) return be;
     hipLaunchKernelGGL(tree_morton_kernel, dim3(blocks), dim3(256), 0, s, a.x, a.y, a.z, m, a.bbox, a.codes_in, a.order_in);
-    size_t temp = a.sort_temp_bytes;
-    return rocprim::radix_sort_pairs(a.sort_temp, temp, a.codes_in, a.codes_out, a.order_in, a.order_out, (size_t)m, 0u, 30u, s, false);
+    // order_in doubles as the ping-pong partner of order_out (three passes: the result lands in the *_out arrays)
+    return radix_sort_pairs_u32(a.sort_temp, a.codes_in, a.codes_out, a.order_in, a.order_out, m, 30, s);
 }
 
 // out[s] = in[order[min(s, m-1)]] for s < n_out (tail replicates the last sorted point)

@@ -399,9 +399,13 @@ int mi_profile_reset(mi_ctx* ctx);
 int mi_profile_get(mi_ctx* ctx, int kernel, double* total_ms, long long* launches);
 /* Work counters of the cell-grid search (MI_NN_GRID), summed over its launches while enabled: out[0] candidates tested in the
  * grid, out[1] cell rows scanned, out[2] moving points that went on to the box hierarchy, out[3] moving points searched, out[4]
- * hierarchy nodes and out[5] leaves visited by out[6] walking waves, out[7] reserved.
+ * hierarchy nodes and out[5] leaves visited by out[6] walking waves, out[7] nodes + leaves of the longest single walk (a
+ * maximum, not a sum).
  * enable != 0 starts counting (and zeroes the counters), 0 stops; out may be NULL.  Costs four atomics per moving point while on. */
 int mi_profile_search_stats(mi_ctx* ctx, int enable, unsigned long long out[8]);
+/* Self-test of the library's own device radix sort (the Hilbert ordering of the index build): sorts the n (key, value) pairs in
+ * place, stable, ascending by the low `bits` (10, 20 or 30) of the keys.  Host arrays; test use only. */
+int mi_selftest_sort_pairs(mi_ctx* ctx, unsigned int* keys, int* values, int n, int bits);
 /* Name of the correspondence-search kernel (MI_KERNEL_NN) a search of n_moving points against m_fixed_local fixed points runs
  * with this nn_mode and the current settings -- the name a rocprofv3 kernel trace shows (static string). */
 const char* mi_nn_kernel_name(const mi_ctx* ctx, int n_moving, int m_fixed_local, int nn_mode);
