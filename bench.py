@@ -230,8 +230,7 @@ def main():
         indexed_if = lambda mm: nn_choice in ("tree", "grid") or (nn_choice == "auto" and mm >= capi.NN_INDEX_MIN_POINTS)
         source_sharded = use_dist and (shard_choice == "source" or (shard_choice == "auto" and indexed_if(m)))
         if source_sharded:
-            slo, shi = capi.shard_range(n, rank, world)
-            n_local, m_local = shi - slo, m
+            n_local, m_local = capi.source_share(n, rank, world), m
         else:
             lo, hi = capi.shard_range(m, rank, world)
             n_local, m_local = n, hi - lo

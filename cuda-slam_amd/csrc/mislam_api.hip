@@ -220,6 +220,20 @@ extern "C" int mi_shard_range(int m_total, int rank, int world, int* lo, int* hi
     return MI_OK;
 }
 
+extern "C" int mi_source_share(int n_total, int rank, int world, int* count)
+{
+    if (n_total < 0 || world < 1 || rank < 0 || rank >= world || !count) { set_error("mi_source_share: bad arguments"); return MI_ERR_INVALID_ARG; }
+    if (n_total < 4 * ICP_CHUNK_POINTS * world) {                                   // too few chunks to deal: contiguous slices
+        *count = (int)((long long)n_total * (rank + 1) / world) - (int)((long long)n_total * rank / world);
+        return MI_OK;
+    }
+    const int chunks = (n_total + ICP_CHUNK_POINTS - 1) / ICP_CHUNK_POINTS;
+    const int mine = (chunks - rank + world - 1) / world;                           // chunks rank, rank + W, ...
+    const bool has_last = (chunks - 1) % world == rank;                             // the (possibly partial) last chunk of the cloud
+    *count = mine * ICP_CHUNK_POINTS - (has_last ? chunks * ICP_CHUNK_POINTS - n_total : 0);
+    return MI_OK;
+}
+
 extern "C" unsigned long long mi_pack_key(float d2, int global_index)
 {
     unsigned int bits;
@@ -756,12 +770,7 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
         before_xyz += 3 * (size_t)slo;
         n_before = shi - slo;
     }
-    if (deal_chunks) {
-        const int chunks = (n_all + ICP_CHUNK_POINTS - 1) / ICP_CHUNK_POINTS;
-        const int mine = (chunks - c->rank + c->world - 1) / c->world;             // chunks rank, rank + W, ...
-        const bool has_last = (chunks - 1) % c->world == c->rank;                    // the (possibly partial) last chunk of the cloud
-        n_before = mine * ICP_CHUNK_POINTS - (has_last ? chunks * ICP_CHUNK_POINTS - n_all : 0);
-    }
+    if (deal_chunks) MI_TRY(mi_source_share(n_all, c->rank, c->world, &n_before));
     c->n = n_before;
     c->n_pad = round_up(n_before, NN_SRC_PAD);
     const size_t np = (size_t)c->n_pad;

@@ -61,10 +61,12 @@ enum {
  *   TARGET: rank r owns fixed points [M*r/W, M*(r+1)/W) and ALL moving points; one ncclAllReduce(ncclUint64, ncclMin) of the
  *           N packed (min-dist, argmin) keys per iteration, then owner-accumulated moments/error + one 18-double sum all-reduce.
  *           The every-pair search scales perfectly this way (its work is N*M/W per rank).
- *   SOURCE: rank r owns moving points [N*r/W, N*(r+1)/W) and a replica of the fixed cloud (12 B/point: trivial at 288 GB);
- *           no per-point exchange at all, only one 18-double sum all-reduce per iteration.  The box-hierarchy search needs this
- *           split to scale: its cost per moving point hardly depends on how many fixed points a rank holds.
- *   AUTO:   SOURCE when the search runs through the box hierarchy, TARGET when it is the every-pair search. */
+ *   SOURCE: every rank holds a replica of the fixed cloud (12 B/point: trivial at 288 GB) and 1/W of the moving points -- the
+ *           64-point chunks of the moving cloud's Hilbert order dealt round-robin (rank r: chunks r, r+W, ...; contiguous
+ *           slices [N*r/W, N*(r+1)/W) of the caller's order below 256*W points).  No per-point exchange at all, only one
+ *           18-double sum all-reduce per iteration.  The indexed searches need this split to scale: their cost per moving
+ *           point hardly depends on how many fixed points a rank holds.
+ *   AUTO:   SOURCE when the search runs through an index (cell grid / box hierarchy), TARGET when it is the every-pair search. */
 enum {
     MI_SHARD_AUTO = 0,
     MI_SHARD_TARGET = 1,
@@ -144,10 +146,13 @@ int mi_ctx_create_exchange(int device, int rank, int world, mi_exchange_fn excha
 
 /* Host-side pieces of the multi-GPU protocol (pure functions, usable without a device; the CPU tests drive them over gloo):
  *   mi_shard_range  the contiguous target range [lo, hi) rank `rank` of `world` owns: lo = M*rank/world, hi = M*(rank+1)/world;
+ *   mi_source_share how many moving points rank `rank` of `world` works on under MI_SHARD_SOURCE (the 64-point chunks rank,
+ *                   rank + world, ... of the cloud's Hilbert order; n*rank/world .. n*(rank+1)/world below 256*world points);
  *   mi_pack_key     the 64-bit key the search emits per source point: IEEE bits of d2 (d2 >= 0, so they order like the
  *                   value) in the high word, the GLOBAL target index in the low word -- an unsigned min over keys is the
  *                   (min distance, lowest index) rule of cudacommon.cu:68 / common.cpp:454, across chunks and across GPUs. */
 int mi_shard_range(int m_total, int rank, int world, int* lo, int* hi);
+int mi_source_share(int n_total, int rank, int world, int* count);
 unsigned long long mi_pack_key(float d2, int global_index);
 void mi_unpack_key(unsigned long long key, float* d2, int* global_index);
 void mi_ctx_destroy(mi_ctx* ctx);

@@ -53,6 +53,19 @@ def test_shard_ranges_partition_the_target(capi):
         capi.shard_range(10, 3, 2)
 
 
+def test_source_shares_cover_the_moving_cloud(capi):
+    for n in (1, 7, 255, 256, 511, 512, 1000, 14904, 10 ** 6, 10 ** 7 + 3):
+        for world in (1, 2, 3, 4, 8):
+            shares = [capi.source_share(n, r, world) for r in range(world)]
+            assert sum(shares) == n and min(shares) >= 0
+            if n >= 256 * world:                                  # dealt 64-point chunks: every rank whole chunks, but for the last one
+                assert sum(1 for v in shares if v % 64) <= 1 and max(shares) - min(shares) <= 64
+            else:
+                assert max(shares) - min(shares) <= 1
+    with pytest.raises(capi.MiSlamError):
+        capi.source_share(10, 2, 2)
+
+
 def test_key_packing_orders_like_distance_then_index(capi):
     rng = np.random.default_rng(0)
     d = np.concatenate([rng.uniform(0, 100, 200), [0.0, 0.0, 1e-30, 3.4e38, np.inf]]).astype(np.float32)
