@@ -490,7 +490,7 @@ static int ensure_tree(mi_ctx* c, int m_local, int index_base)
     MI_HIP(tree_build(a, c->stream));
     c->tree.boxes6 = c->tboxes6.p;
     c->tree.leaf_soa = c->tleaf.p; c->tree.leaf_idx = c->tidx.p;
-    c->tree.n_pad = n_pad; c->tree.height = height;
+    c->tree.n_pad = n_pad; c->tree.height = height; c->tree.n_leaves = n_leaves;
     c->tree_valid = true;
     return MI_OK;
 }

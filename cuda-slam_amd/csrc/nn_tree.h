@@ -22,6 +22,7 @@ constexpr int TREE_BLOCK_THREADS = 64;         // one wave per workgroup: a walk
 struct NnTreeView {
     int n_pad;                        // leaf count padded to a power of two (padding leaves carry empty boxes)
     int height;                       // log2(n_pad)
+    int n_leaves;                     // real leaves: a node is empty iff the first leaf below it is >= n_leaves
     const float* boxes6;              // node i: lo.xyz hi.xyz, 24 bytes; implicit heap, children of i are 2i+1 and 2i+2, leaves start at
                                       // n_pad-1, so the 2^k descendants k levels below a node are contiguous (+ 48 floats of padding: a
                                       // step always reads eight boxes)

@@ -84,6 +84,20 @@ __device__ __forceinline__ float box6_bound(const float* __restrict__ b, const f
     return sq3<FMA>(ex, ey, ez);
 }
 
+// the bounds of two boxes at once: the squares and sums as packed fp32 operations (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 -- the
+// same IEEE operations as the single ones, two results per issue slot)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool FMA>
+__device__ __forceinline__ f32x2 box6_bound2(const float* __restrict__ b0, const float* __restrict__ b1, const float s[3])
+{
+    f32x2 ex, ey, ez;
+    ex.x = fmaxf(fmaxf(b0[0] - s[0], s[0] - b0[3]), 0.f); ex.y = fmaxf(fmaxf(b1[0] - s[0], s[0] - b1[3]), 0.f);
+    ey.x = fmaxf(fmaxf(b0[1] - s[1], s[1] - b0[4]), 0.f); ey.y = fmaxf(fmaxf(b1[1] - s[1], s[1] - b1[4]), 0.f);
+    ez.x = fmaxf(fmaxf(b0[2] - s[2], s[2] - b0[5]), 0.f); ez.y = fmaxf(fmaxf(b1[2] - s[2], s[2] - b1[5]), 0.f);
+    if constexpr (FMA) return __builtin_elementwise_fma(ez, ez, __builtin_elementwise_fma(ey, ey, ex * ex));
+    else return (ex * ex + ey * ey) + ez * ez;
+}
+
 template <bool FMA, bool STATS>
 __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float p[3], float& best, unsigned int& bidx,
                                                unsigned int& n_nodes, unsigned int& n_leaves)
@@ -91,7 +105,7 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
     const float* __restrict__ boxes6 = t.boxes6;
     const float4* __restrict__ leaf_soa = t.leaf_soa;
     const int* __restrict__ leaf_idx = t.leaf_idx;
-    const int H = t.height, first_leaf = t.n_pad - 1;
+    const int H = t.height, first_leaf = t.n_pad - 1, real_leaves = t.n_leaves;
     const float inf = __builtin_inff();
     int bslot = -1;                                            // >= 0: the winner's sorted slot; < 0: bidx is the winner
     auto offer = [&](float d, int s) {                          // s is wave-uniform
@@ -140,13 +154,22 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
             unsigned int mask = 0u;
             // (a root step of fewer than three levels reads boxes past its children: masked off below)
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                lb[j] = box6_bound<FMA>(bp + 6 * j, p);
-                // lb <= best implies lb < inf unless best is inf itself (a lane without a candidate yet): then the empty padding
-                // boxes (bound inf) must be kept out explicitly
-                if (__builtin_amdgcn_ballot_w64(lb[j] <= best && lb[j] < inf) != 0ull) mask |= 1u << j;
+            for (int j = 0; j < 8; j += 2) {
+                const f32x2 b2 = box6_bound2<FMA>(bp + 6 * j, bp + 6 * j + 6, p);
+                lb[j] = b2.x;
+                lb[j + 1] = b2.y;
+                if (__builtin_amdgcn_ballot_w64(lb[j] <= best) != 0ull) mask |= 1u << j;
+                if (__builtin_amdgcn_ballot_w64(lb[j + 1] <= best) != 0ull) mask |= 1u << (j + 1);
             }
-            mask &= (1u << (1 << k)) - 1u;
+            // The empty padding boxes (bound inf) would pass `lb <= best` for a lane that has no candidate yet (best = inf): they
+            // are kept out by position -- level clevel's node i is empty iff its first leaf i << (H - clevel) is >= real_leaves
+            {
+                const int sh = H - clevel;
+                const int real = ((real_leaves + (1 << sh) - 1) >> sh) - (base - ((1 << clevel) - 1));   // real nodes from `base` on
+                const int kids = 1 << k;
+                const int cnt = real < kids ? (real < 0 ? 0 : real) : kids;
+                mask &= (1u << cnt) - 1u;
+            }
             bool descend = false;
             if (clevel == H) {
                 // the children are leaves: scan the needed ones now, each re-checked against the bests as they stand

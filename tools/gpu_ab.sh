@@ -1,6 +1,8 @@
 #!/bin/bash
-# A/B of variant builds on the bench workload: tools/gpu_ab.sh NAME... (product build first)
+# A/B of variant builds on the bench workload: [REPS=3] tools/gpu_ab.sh NAME... (product build first; REPS rounds, interleaved:
+# one bench run differs from the next by a few per cent)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+for rep in $(seq ${REPS:-1}); do
 for v in product "$@"; do
   if [ $v = product ]; then unset MISLAM_LIB; else export MISLAM_LIB=$GRAFT_REPO_ROOT/cuda-slam_amd/variants/libmislam_$v.so; fi
   echo "== $v"
@@ -13,4 +15,5 @@ for l in sys.stdin:
     else:
         print(l, end='')
 " || exit 1
+done
 done
