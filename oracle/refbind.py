@@ -22,6 +22,11 @@ def available():
 _lib = None
 
 
+def _flush():
+    """The reference prints its per-iteration lines through C stdio: flush them while the caller's output capture is still active."""
+    C.CDLL(None).fflush(None)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -102,6 +107,7 @@ def icp(before, after, eps=1e-3, max_distance_squared=1000.0, max_iterations=-1,
     lib().ref_icp(_fp(before), before.shape[0], _fp(after), after.shape[0], C.c_float(eps),
                   C.c_float(max_distance_squared), max_iterations, 1 if parallel else 0, _fp(r), _fp(t),
                   C.byref(it), C.byref(err))
+    _flush()
     return r.reshape(3, 3).T.copy(), t, it.value, err.value
 
 
@@ -146,6 +152,7 @@ def cpd(before, after, eps=1e-3, weight=0.3, const_scale=False, max_iterations=5
     lib().ref_cpd(_fp(before), before.shape[0], _fp(after), after.shape[0], C.c_float(eps), C.c_float(weight),
                   1 if const_scale else 0, max_iterations, C.c_float(tolerance), fgt, C.c_float(ratio_of_far_field),
                   C.c_float(order_of_truncation), _fp(r), _fp(t), C.byref(it), C.byref(err))
+    _flush()
     return r.reshape(3, 3).T.copy(), t, it.value, err.value
 
 
@@ -207,6 +214,7 @@ def nicp_single(before, after):
     t = np.empty(3, np.float32)
     e = C.c_float(0)
     lib().ref_nicp_single(_fp(before), before.shape[0], _fp(after), after.shape[0], _fp(r), _fp(t), C.byref(e))
+    _flush()
     return r.reshape(3, 3).T.copy(), t, e.value
 
 
@@ -218,6 +226,7 @@ def nicp(before, after, eps=1e-3, max_repetitions=20, approximation=0, parallel=
     err = C.c_float(0)
     lib().ref_nicp(_fp(before), before.shape[0], _fp(after), after.shape[0], C.c_float(eps), max_repetitions, approximation,
                    1 if parallel else 0, subcloud_size, C.c_uint(seed), _fp(r), _fp(t), C.byref(reps), C.byref(err))
+    _flush()
     return r.reshape(3, 3).T.copy(), t, reps.value, err.value
 
 
