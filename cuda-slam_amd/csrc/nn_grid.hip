@@ -328,6 +328,10 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
         if (a.state->done != 0) return;
     } else if (a.done_flag != nullptr && *a.done_flag != 0) return;
     const int tid = (int)threadIdx.x;
+#ifdef MISLAM_DEV_WALK_CLOCK
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    unsigned long long pre_cycles = 0, life_cycles = 0;
+#endif
     unsigned int chunk = xcd_chunk(blockIdx.x, gridDim.x, TREE_XCD_CHUNKS * (256 / GRID_BLOCK));
     if (FUSED && a.order != nullptr) chunk = (unsigned int)a.order[chunk];   // walking chunks first (IcpSchedule): speed only
     const int i = (int)(chunk * GRID_BLOCK) + tid;
@@ -378,10 +382,13 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
     if (hard) {
 #ifdef MISLAM_DEV_WALK_CLOCK
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        pre_cycles = t0 - t_begin;
 #endif
         tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves);
 #ifdef MISLAM_DEV_WALK_CLOCK
-        walk_cycles = __builtin_amdgcn_s_memtime() - t0;
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        walk_cycles = t1 - t0;
+        life_cycles = t1 - t_begin;
 #endif
     }
 #endif
@@ -394,6 +401,11 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
         unsigned int c0 = valid ? n_cand : 0u, c1 = valid ? n_rows : 0u;
         unsigned int v0 = hard ? n_nodes : 0u, v1 = hard ? n_leaves : 0u;
         unsigned long long wc = hard ? walk_cycles : 0ull;
+#ifdef MISLAM_DEV_WALK_CLOCK
+        unsigned long long pc = hard ? pre_cycles : 0ull, lc = hard ? life_cycles : 0ull;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) { pc = max(pc, (unsigned long long)__shfl_xor(pc, m, 64)); lc = max(lc, (unsigned long long)__shfl_xor(lc, m, 64)); }
+#endif
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) {
             c0 += __shfl_xor(c0, m, 64); c1 += __shfl_xor(c1, m, 64);
@@ -407,12 +419,15 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
             atomicAdd(&srow[2], nh);
             atomicAdd(&srow[3], nv);
             if (walked) {                                       // hierarchy nodes and leaves visited, waves walking
+#ifdef MISLAM_DEV_WALK_CLOCK            // (developer build: [4] sum of walk times, [5] sum of times before the walk, [7] longest wave start -> end of walk)
+                atomicAdd(&srow[4], wc);
+                atomicAdd(&srow[5], pc);
+                atomicAdd(&srow[6], 1ull);
+                atomicMax(&srow[7], lc);
+#else
                 atomicAdd(&srow[4], (unsigned long long)v0);
                 atomicAdd(&srow[5], (unsigned long long)v1);
                 atomicAdd(&srow[6], 1ull);
-#ifdef MISLAM_DEV_WALK_CLOCK
-                atomicAdd(&srow[7], wc);
-#else
                 atomicMax(&srow[7], (unsigned long long)(v0 + v1));     // the longest walk, in steps
 #endif
             }
