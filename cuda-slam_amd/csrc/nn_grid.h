@@ -20,7 +20,11 @@ constexpr int GRID_STATS_ROWS = 1024;         // mi_profile_search_stats: the co
 #define MISLAM_GRID_FAR_FACTOR 2.0f
 #endif
 constexpr float GRID_FAR_FACTOR = MISLAM_GRID_FAR_FACTOR;    // a starting candidate farther than this many times GRID_DU_MAX cells: straight to the hierarchy
-constexpr int GRID_CAND_BUDGET = 640;      // candidates a lane may test in the grid before it walks the hierarchy instead
+constexpr int GRID_CAND_BUDGET = 640;
+#ifndef MISLAM_GRID_WALK_ONLY_MIN
+#define MISLAM_GRID_WALK_ONLY_MIN 32
+#endif
+constexpr int GRID_WALK_ONLY_MIN = MISLAM_GRID_WALK_ONLY_MIN;   // lanes of a chunk beyond the grid's reach from which the chunk skips the scan next time (> 64: never)      // candidates a lane may test in the grid before it walks the hierarchy instead
 
 struct NnGridView {
     const float4* pts;                     // the m fixed points sorted by cell (row-major: x fastest), w = GLOBAL index bits

@@ -376,7 +376,13 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
     bool hard = false;
     unsigned long long walk_cycles = 0;
     unsigned int n_cand = 0u, n_rows = 0u, n_nodes = 0u, n_leaves = 0u;
-    if (valid) hard = grid_search<FMA, STATS>(g, q, best, bidx, bslot, n_cand, n_rows);
+    // A chunk most of whose lanes ended beyond the grid's reach last time (they will again: the flags move slowly) skips the scan:
+    // all its lanes walk, each from its own starting candidate -- the walk is exact by itself, the few lanes the scan would have
+    // served add little to the union the wave visits anyway, and the wave's critical path loses the scan (speed only).
+    bool walk_only = false;
+    if (FUSED && a.far != nullptr) walk_only = a.far[chunk] >= 2;
+    if (walk_only) hard = valid;
+    else if (valid) hard = grid_search<FMA, STATS>(g, q, best, bidx, bslot, n_cand, n_rows);
     const bool walked = __builtin_amdgcn_ballot_w64(hard) != 0ull;
 #ifndef MISLAM_DEV_SKIP_WALK          // timing experiments only (tools/build_variant.sh): wrong answers for the lanes concerned
     if (hard) {
@@ -451,7 +457,13 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
         double* row = a.rows + (size_t)chunk * ICP_ROW;
         row_store_moments(mom, row, nullptr);
         row_store_error(e0, e1, row, nullptr);
-        if (a.far != nullptr && tid == 0) a.far[chunk] = walked ? 1 : 0;
+        if (a.far != nullptr) {
+            // next iteration's class of this chunk: 0 = no lane walked, 1 = some did, 2 = most lanes lie beyond the grid's reach
+            const float cap = (GRID_DU_MAX - 2e-3f) * g.h_lo;
+            const float cap2 = cap * cap * (1.f - 1e-5f);
+            const int beyond = (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && !(best <= cap2)));
+            if (tid == 0) a.far[chunk] = beyond >= GRID_WALK_ONLY_MIN ? 2 : (walked ? 1 : 0);
+        }
     }
 }
 
