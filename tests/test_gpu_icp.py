@@ -238,6 +238,26 @@ def test_ten_million_icp_iterations(ctx, capi, oracle):
     assert np.array_equal(again[0], R3) and np.array_equal(again[1], t3) and again[3] == e3
 
 
+def test_chunk_classes_do_not_change_the_registration(ctx, capi):
+    # The fused search keeps a class per 64-point chunk from one iteration to the next (no lane walked / some did / most lanes lie
+    # beyond the grid's reach -> the chunk skips the scan and walks): scheduling only.  A partially overlapping pair of clouds takes
+    # every chunk through the classes as the registration converges; every iteration's error and the final transform must equal
+    # the every-pair search's bit for bit.
+    before, after, Rt, tt = synth_cloud(60000)
+    after = (after + np.float32(1.5)).astype(np.float32)                 # a third of the moving cloud starts outside the fixed one
+    trail = {}
+    for nn_mode in (capi.NN_GRID, capi.NN_BRUTEFORCE):
+        ctx.icp_load(before, after, capi.icp_params(eps=0.0, max_iterations=25, nn_mode=nn_mode))
+        errs = []
+        for _ in range(25):
+            ctx.icp_run(1)
+            errs.append(ctx.icp_result()[3])
+        trail[nn_mode] = (errs, ctx.icp_result())
+    (eg, rg), (eb, rb) = trail[capi.NN_GRID], trail[capi.NN_BRUTEFORCE]
+    assert eg == eb and np.array_equal(rg[0], rb[0]) and np.array_equal(rg[1], rb[1]) and rg[2] == rb[2] == 25
+    assert eg[-1] < 0.2 * eg[0]
+
+
 def test_full_bench_size_iterations(ctx, capi):
     # BASELINE.json's headline configuration (N = M = 1e6, the bench workload): the first iterations through both searches are
     # bitwise the same registration, the error falls monotonically, and one iteration equals an fp64 Kabsch solve of its pairs
