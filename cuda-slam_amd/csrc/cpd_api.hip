@@ -54,6 +54,7 @@ struct CpdWorkspace {
     int m = 0, n = 0, m_pad = 0, n_pad = 0;   // n = this rank's share of the fixed cloud
     int n_total = 0;                          // |after| over all ranks
     int k_chunks = 1, k_chunk_len = 0, x_chunks = 1, x_chunk_len = 0;
+    bool sums_fresh = false;                  // the last exact E-step left the M-step's x-sums and k-sums in part_x / part_k
     mi_cpd_params params{};
 };
 
@@ -163,11 +164,13 @@ static int use_mfma_contraction(const mi_ctx* c) { return c->tune.cpd_mfma; }   
 
 static int cpd_estep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
 {
+    // the two post kernels also accumulate the M-step's moments of what they have just produced (two launches less per EM iteration)
+    const int nxb = icp_reduce_blocks(w->n), nkb = icp_reduce_blocks(w->m);
     { ProfScope ps(c, MI_KERNEL_CPD_DENOM); MI_HIP(cpd_denominators(v, c->stream)); }
-    MI_HIP(cpd_post_denominators(v, c->stream));
+    MI_HIP(cpd_post_denominators(v, c->stream, w->part_x.p, nxb));
     { ProfScope ps(c, MI_KERNEL_CPD_CONTRACT); MI_HIP(cpd_contract(v, use_mfma_contraction(c), c->stream)); }
-    MI_HIP(cpd_post_contract(v, c->stream));
-    (void)w;
+    MI_HIP(cpd_post_contract(v, c->stream, w->part_k.p, nkb));
+    w->sums_fresh = true;
     return MI_OK;
 }
 
@@ -175,8 +178,11 @@ static int cpd_mstep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const
 {
     const int nxb = icp_reduce_blocks(w->n), nkb = icp_reduce_blocks(w->m);
     ProfScope ps(c, MI_KERNEL_CPD_MSTEP);
-    MI_HIP(cpd_xsums(v, w->part_x.p, nxb, c->stream));
-    MI_HIP(cpd_ksums(v, w->part_k.p, nkb, c->stream));
+    if (!w->sums_fresh) {
+        MI_HIP(cpd_xsums(v, w->part_x.p, nxb, c->stream));
+        MI_HIP(cpd_ksums(v, w->part_k.p, nkb, c->stream));
+    }
+    w->sums_fresh = false;
     if (!c->distributed()) {
         MI_HIP(cpd_solve(w->d_state, w->part_x.p, nxb, w->part_k.p, nkb, rules, update_loop_state, c->stream));
         return MI_OK;
@@ -293,6 +299,7 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
                                  float ratio_of_far_field, int order)
 {
     ProfScope ps(c, MI_KERNEL_CPD_FGT);
+    w->sums_fresh = false;               // P1 / Pt1 / PX come from the transform below, not from the exact E-step's post kernels
     FgtWork* f = &w->fgt;
     if (w->m < 2 || w->n < 2) { set_error("FGT E-step needs at least 2 points per cloud (m=%d, n=%d)", w->m, w->n); return MI_ERR_INVALID_ARG; }
     if (!(sigma2 > 0.f)) { set_error("FGT E-step: sigma2 must be positive"); return MI_ERR_INVALID_ARG; }
@@ -495,6 +502,7 @@ static int estep_primitive(mi_ctx* c, const float* y_xyz, int m, const float* x_
         }
         MI_TRY(cpd_estep_enqueue(c, w, v));
     }
+    w->sums_fresh = false;               // (a stand-alone E-step: nothing of it is carried into a later M-step call)
     const int nxb = icp_reduce_blocks(n);
     MI_HIP(cpd_xsums(v, w->part_x.p, nxb, c->stream));
     MI_HIP(hipMemcpyAsync(p1, w->p1.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
@@ -577,6 +585,7 @@ extern "C" int mi_cpd_mstep(mi_ctx* c, const float* before_xyz, int m, const flo
     MI_TRY(cpd_load(c, w, before_xyz, m, after_xyz, n));
     CpdView v = cpd_view(c, w);
     v.xw4 = nullptr;   // no E-step ran: skip the log-likelihood term
+    w->sums_fresh = false;
     MI_HIP(hipMemcpyAsync(w->p1.p, p1, sizeof(float) * (size_t)m, hipMemcpyHostToDevice, c->stream));
     MI_HIP(hipMemcpyAsync(w->pt1.p, pt1, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     MI_HIP(hipMemcpyAsync(w->px.p, px, sizeof(float) * 3 * (size_t)m, hipMemcpyHostToDevice, c->stream));

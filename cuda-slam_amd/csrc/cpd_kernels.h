@@ -72,9 +72,10 @@ hipError_t cpd_init_state(CpdState* state, const double* partials, int nblocks, 
 // distances, before-major -- into state->sigma2_init.  One wave; ~8 cycles per term (0.7 s for the bunny clouds).
 hipError_t cpd_sigma2_sequential(const CpdView& v, hipStream_t s);
 hipError_t cpd_denominators(const CpdView& v, hipStream_t s);                                  // K7a
-hipError_t cpd_post_denominators(const CpdView& v, hipStream_t s);                             //   den, w, Pt1, xw4
+// (xpartials / kpartials != null: the post kernels also leave the M-step's x-sums / k-sums, as cpd_xsums / cpd_ksums would, in nblocks rows)
+hipError_t cpd_post_denominators(const CpdView& v, hipStream_t s, double* xpartials = nullptr, int nblocks = 0);                             //   den, w, Pt1, xw4
 hipError_t cpd_contract(const CpdView& v, int use_mfma, hipStream_t s);                        // K7b
-hipError_t cpd_post_contract(const CpdView& v, hipStream_t s);                                 //   P1, PX from chunk partials
+hipError_t cpd_post_contract(const CpdView& v, hipStream_t s, double* kpartials = nullptr, int nblocks = 0);                                 //   P1, PX from chunk partials
 hipError_t cpd_xsums(const CpdView& v, double* partials, int nblocks, hipStream_t s);          // K8 part 1
 hipError_t cpd_ksums(const CpdView& v, double* partials, int nblocks, hipStream_t s);          // K8 part 2
 // multi-GPU: a rank's own sums into state->xs/ks resp. state->init (all-reduced there); cpd_solve / cpd_init_state then take

@@ -181,29 +181,40 @@ __global__ __launch_bounds__(256) void cpd_denominator_kernel(CpdView v)
 }
 
 // den_x = sum of chunk partials + c; Pt1[x] = 1 - c/den (coherentpointdrift.cpp:204-206); operand of the contraction.
-__global__ __launch_bounds__(256) void cpd_post_den_kernel(CpdView v)
+// With xpartials != null the kernel also accumulates the M-step's x-sums (cpd_xsums_kernel's terms, same grid, same order: the
+// same bits) -- one launch and one gap less per EM iteration.
+__global__ __launch_bounds__(256) void cpd_post_den_kernel(CpdView v, double* __restrict__ xpartials)
 {
     if (v.state->done != 0) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= v.n) return;
     const float c = v.state->constant;
-    // the chunk partials are added in chunk order (fixed: bitwise reproducible); eight loads in flight per trip -- one load per
-    // trip made this a chain of ~140 cache round trips (32 us for a 5 us job)
-    float den = 0.f;
-    const float* __restrict__ part = v.den_part + i;
-    int ch = 0;
-    for (; ch + 8 <= v.k_chunks; ch += 8) {
-        float t[8];
+    double acc[CPD_XSUMS] = {0};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n; i += gridDim.x * 256) {
+        // the chunk partials are added in chunk order (fixed: bitwise reproducible); eight loads in flight per trip -- one load per
+        // trip made this a chain of ~140 cache round trips (32 us for a 5 us job)
+        float den = 0.f;
+        const float* __restrict__ part = v.den_part + i;
+        int ch = 0;
+        for (; ch + 8 <= v.k_chunks; ch += 8) {
+            float t[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) t[u] = part[(size_t)(ch + u) * v.n];
+            for (int u = 0; u < 8; u++) t[u] = part[(size_t)(ch + u) * v.n];
 #pragma unroll
-        for (int u = 0; u < 8; u++) den += t[u];
+            for (int u = 0; u < 8; u++) den += t[u];
+        }
+        for (; ch < v.k_chunks; ch++) den += part[(size_t)ch * v.n];
+        den += c;
+        const float w = 1.0f / den;
+        const float pt1 = 1.0f - c / den;
+        const float x = v.ax[i], y = v.ay[i], z = v.az[i];
+        v.pt1[i] = pt1;
+        v.xw4[i] = make_float4(x * w, y * w, z * w, w);
+        if (xpartials != nullptr) {
+            acc[0] += (double)logf(1.0f / w);                           // error -= log(denominator), :215
+            acc[1] += (double)x * pt1; acc[2] += (double)y * pt1; acc[3] += (double)z * pt1;
+            acc[4] += (double)(x * x) * pt1 + (double)(y * y) * pt1 + (double)(z * z) * pt1;     // :257
+        }
     }
-    for (; ch < v.k_chunks; ch++) den += part[(size_t)ch * v.n];
-    den += c;
-    const float w = 1.0f / den;
-    v.pt1[i] = 1.0f - c / den;
-    v.xw4[i] = make_float4(v.ax[i] * w, v.ay[i] * w, v.az[i] * w, w);
+    if (xpartials != nullptr) block_sum_store<CPD_XSUMS>(acc, xpartials + (size_t)blockIdx.x * CPD_XSUMS);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -304,11 +315,12 @@ __global__ __launch_bounds__(256) void cpd_contract_mfma_kernel(CpdView v)
     }
 }
 
-__global__ __launch_bounds__(256) void cpd_post_contract_kernel(CpdView v)
+// (with kpartials != null: + the M-step's k-sums, as cpd_ksums_kernel would add them)
+__global__ __launch_bounds__(256) void cpd_post_contract_kernel(CpdView v, double* __restrict__ kpartials)
 {
     if (v.state->done != 0) return;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= v.m) return;
+    double acc[CPD_KSUMS] = {0};
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < v.m; k += gridDim.x * 256) {
     float p1 = 0.f, x = 0.f, y = 0.f, z = 0.f;
     const float* __restrict__ pp = v.p1_part + k;
     const float* __restrict__ pq = v.px_part + k;
@@ -331,6 +343,18 @@ __global__ __launch_bounds__(256) void cpd_post_contract_kernel(CpdView v)
     }
     v.p1[k] = p1;
     v.px[3 * (size_t)k] = x; v.px[3 * (size_t)k + 1] = y; v.px[3 * (size_t)k + 2] = z;
+    if (kpartials != nullptr) {
+        const float b[3] = {v.bx[k], v.by[k], v.bz[k]};
+        const float px[3] = {x, y, z};
+        acc[0] += (double)p1;
+        for (int r = 0; r < 3; r++) {
+            acc[1 + r] += (double)b[r] * p1;
+            for (int c = 0; c < 3; c++) acc[4 + 3 * r + c] += (double)b[r] * px[c];
+            acc[13] += (double)(b[r] * b[r]) * p1;                                            // :259
+        }
+    }
+    }
+    if (kpartials != nullptr) block_sum_store<CPD_KSUMS>(acc, kpartials + (size_t)blockIdx.x * CPD_KSUMS);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -485,9 +509,10 @@ hipError_t cpd_denominators(const CpdView& v, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t cpd_post_denominators(const CpdView& v, hipStream_t s)
+hipError_t cpd_post_denominators(const CpdView& v, hipStream_t s, double* xpartials, int nblocks)
 {
-    hipLaunchKernelGGL(cpd_post_den_kernel, dim3((v.n + 255) / 256), dim3(256), 0, s, v);
+    const int grid = xpartials != nullptr ? nblocks : (v.n + 255) / 256;
+    hipLaunchKernelGGL(cpd_post_den_kernel, dim3(grid), dim3(256), 0, s, v, xpartials);
     return hipGetLastError();
 }
 
@@ -505,9 +530,10 @@ hipError_t cpd_contract(const CpdView& v, int use_mfma, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t cpd_post_contract(const CpdView& v, hipStream_t s)
+hipError_t cpd_post_contract(const CpdView& v, hipStream_t s, double* kpartials, int nblocks)
 {
-    hipLaunchKernelGGL(cpd_post_contract_kernel, dim3((v.m + 255) / 256), dim3(256), 0, s, v);
+    const int grid = kpartials != nullptr ? nblocks : (v.m + 255) / 256;
+    hipLaunchKernelGGL(cpd_post_contract_kernel, dim3(grid), dim3(256), 0, s, v, kpartials);
     return hipGetLastError();
 }
 
