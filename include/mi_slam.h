@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MI_SLAM_ABI_VERSION 1
+#define MI_SLAM_ABI_VERSION 2   /* 2: mi_cpd_params gained sigma2_mode; mi_dist_info, mi_source_share, mi_cpd_sigma_squared_mode, mi_profile_search_stats, mi_selftest_sort_pairs */
 
 enum {
     MI_OK = 0,
