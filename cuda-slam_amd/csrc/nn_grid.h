@@ -20,16 +20,24 @@ constexpr int GRID_STATS_ROWS = 1024;         // mi_profile_search_stats: the co
 #define MISLAM_GRID_FAR_FACTOR 2.0f
 #endif
 constexpr float GRID_FAR_FACTOR = MISLAM_GRID_FAR_FACTOR;    // a starting candidate farther than this many times GRID_DU_MAX cells: straight to the hierarchy
-constexpr int GRID_CAND_BUDGET = 640;
+constexpr int GRID_CAND_BUDGET = 640;         // candidates a lane may test in the grid before it walks the hierarchy instead
+constexpr int GRID_BATCH = 4;                 // cell rows whose offsets a lane requests together, then scans as one flat run of candidates
+constexpr int GRID_PTS_PAD = 4;               // pts carries this many copies of its last entry: a lane fetches candidates four at a time
+// cells (Chebyshev) the scan of a query can reach from the query's own (clamped) cell: its radius is capped a hair below
+// GRID_DU_MAX cells (nn_grid.hip), so floor(u +- du) stays within ceil(GRID_DU_MAX) cells
+constexpr int GRID_REACH_CELLS = (int)GRID_DU_MAX + ((float)(int)GRID_DU_MAX < GRID_DU_MAX ? 1 : 0);
 #ifndef MISLAM_GRID_WALK_ONLY_MIN
 #define MISLAM_GRID_WALK_ONLY_MIN 32
 #endif
-constexpr int GRID_WALK_ONLY_MIN = MISLAM_GRID_WALK_ONLY_MIN;   // lanes of a chunk beyond the grid's reach from which the chunk skips the scan next time (> 64: never)      // candidates a lane may test in the grid before it walks the hierarchy instead
+constexpr int GRID_WALK_ONLY_MIN = MISLAM_GRID_WALK_ONLY_MIN;   // lanes of a chunk beyond the grid's reach from which the chunk skips the scan next time (> 64: never)
 
 struct NnGridView {
-    const float4* pts;                     // the m fixed points sorted by cell (row-major: x fastest), w = GLOBAL index bits
+    const float4* pts;                     // the m fixed points sorted by cell (row-major: x fastest), w = GLOBAL index bits; + GRID_PTS_PAD
+                                           // copies of the last one
     const unsigned int* cell_start;        // nx*ny*nz + 1 offsets into pts
     const unsigned int* slot_of;           // local index of a fixed point (global - index_base) -> its slot in pts
+    const unsigned char* occupied_near;    // per cell: 1 iff some fixed point lies in a cell within GRID_REACH_CELLS (Chebyshev) of it --
+                                           // 0 tells a query in that cell that its scan cannot meet a single candidate
     int index_base;                        // global index of this shard's point 0
     float ox, oy, oz;                      // lower corner of the bounding box
     float inv_h;                           // cells per unit length; cell coordinate of p on an axis: floor((p - o) * inv_h)
@@ -51,6 +59,8 @@ struct GridBuildArgs {
     float4* pts_out;
     unsigned int* cell_start_out;
     unsigned int* slot_of_out;
+    unsigned char* near_out;               // nx*ny*nz bytes (NnGridView::occupied_near)
+    unsigned char* near_tmp;               // nx*ny*nz bytes of scratch
 };
 hipError_t grid_build(const GridBuildArgs& a, hipStream_t s);
 

@@ -199,6 +199,39 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(NnGridView g, const f
     slot_of[j] = pos;
 }
 
+// pts[m .. m + GRID_PTS_PAD) = copies of the last sorted point: the scan fetches four candidates at a time and may run up to three
+// entries past a row's end -- every entry it can meet is a real point (testing one twice, or one of another cell, changes nothing)
+__global__ void grid_pad_kernel(float4* __restrict__ pts, int m)
+{
+    if (threadIdx.x < GRID_PTS_PAD) pts[m + threadIdx.x] = pts[m - 1];
+}
+
+// occupied_near, three separable passes: a cell's run of x-neighbours is one contiguous stretch of pts (two offsets tell whether it
+// holds a point), then OR over the y- and the z-neighbours
+__global__ __launch_bounds__(256) void grid_near_x_kernel(NnGridView g, const unsigned int* __restrict__ cell_start, unsigned int n_cells,
+                                                          unsigned char* __restrict__ out)
+{
+    const unsigned int c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= n_cells) return;
+    const int x = (int)(c % (unsigned int)g.nx);
+    const unsigned int row = c - (unsigned int)x;
+    const int lo = max(x - GRID_REACH_CELLS, 0), hi = min(x + GRID_REACH_CELLS, g.nx - 1);
+    out[c] = cell_start[row + hi + 1] > cell_start[row + lo] ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void grid_near_axis_kernel(const unsigned char* __restrict__ in, unsigned int n_cells, int stride, int dim,
+                                                             unsigned char* __restrict__ out)
+{
+    const unsigned int c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= n_cells) return;
+    const int i = (int)((c / (unsigned int)stride) % (unsigned int)dim);      // this cell's coordinate on the axis
+    unsigned char v = 0;
+#pragma unroll
+    for (int d = -GRID_REACH_CELLS; d <= GRID_REACH_CELLS; d++)
+        if (i + d >= 0 && i + d < dim) v |= in[(long long)c + (long long)d * stride];
+    out[c] = v;
+}
+
 hipError_t grid_build(const GridBuildArgs& a, hipStream_t s)
 {
     const NnGridView& g = a.view;
@@ -214,6 +247,11 @@ hipError_t grid_build(const GridBuildArgs& a, hipStream_t s)
     // counts -> offsets, in place in cell_fill (the scatter's running cursors) and copied to cell_start
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(256), 0, s, a.cell_fill, n_scan, a.scan_tmp, a.cell_fill, a.cell_start_out);
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(pb), dim3(256), 0, s, g, a.x, a.y, a.z, a.m, a.index_base, a.cell_fill, a.pts_out, a.slot_of_out);
+    hipLaunchKernelGGL(grid_pad_kernel, dim3(1), dim3(64), 0, s, a.pts_out, a.m);
+    const unsigned int cb = (n_cells + 255u) / 256u;
+    hipLaunchKernelGGL(grid_near_x_kernel, dim3(cb), dim3(256), 0, s, g, a.cell_start_out, n_cells, a.near_out);
+    hipLaunchKernelGGL(grid_near_axis_kernel, dim3(cb), dim3(256), 0, s, a.near_out, n_cells, g.nx, g.ny, a.near_tmp);
+    hipLaunchKernelGGL(grid_near_axis_kernel, dim3(cb), dim3(256), 0, s, a.near_tmp, n_cells, g.nx * g.ny, g.nz, a.near_out);
     return hipGetLastError();
 }
 
@@ -230,6 +268,7 @@ __device__ __forceinline__ float gap_cells(float u, int i)
 // k = 0, 1, 2, 3, 4 ... -> 0, -1, +1, -2, +2 ...: slabs in the order of their distance from the query's own
 __device__ __forceinline__ int centre_out(int k) { return (k & 1) ? -((k + 1) >> 1) : (k >> 1); }
 
+#ifdef MISLAM_GRID_SCAN_V1
 // Grid part of one lane's search.  Returns true if the lane gave up (it must then walk the hierarchy from (best, bidx)).
 //
 // The lane scans the cells within r2 = min(best, cap2) of the query, nearest slabs first, so that `best` -- and with it r2 --
@@ -317,17 +356,241 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
     return !alive || !(best <= cap2);
 }
 
+#else
+// ---- round-3 form of the grid part -----------------------------------------------------------------------------------------
+// What round 2's scan cost (profiles/r03_timeline.log, r03_pmc_*): a launch lasts as long as its waves hold their slots, and a scan
+// wave lived ~35 us through ~18 DEPENDENT memory round trips (every cell row: its two offsets, then its points, four at a time)
+// while two thirds of its vector instructions were the bookkeeping of the lockstep slab loops.  Now:
+//   * rows are named by a per-lane BIT MASK over the (2R+1)^2 rows around the query's own (R = GRID_REACH_CELLS): building it is
+//     arithmetic (two ranges, one multiply), and the wave steps through set bits only -- a row no lane needs costs nothing;
+//   * FIRST the 2 x 2 x 2 block of cells nearest to the query (its own cell and, on each axis, the neighbour on the side the query
+//     leans to): with ~2 points per cell the neighbour is in there nine times out of ten, so the radius is tight before anything
+//     else is looked at -- whatever the starting candidate was worth; THEN the rows the shrunken radius still reaches, minus what
+//     the block covered;
+//   * GRID_BATCH rows at a time: their offsets are requested together (one round trip) and their points are scanned as ONE flat
+//     sequence of runs, four candidates per trip, hopping from run to run -- the lanes stay busy until the lane with the most
+//     candidates is done, not until the fullest row of every slab is;
+//   * a trip fetches pts[p .. p + 3] whatever is left of the run: what follows a run in pts are real points too (GRID_PTS_PAD copies
+//     of the last one at the very end), and testing ANY real point is harmless for a lexicographic minimum;
+//   * (distance, index) is ONE unsigned 64-bit key -- non-negative floats order like their bit patterns -- so "closer, or as
+//     close with a lower index" is one compare.
+constexpr int GRID_ROWS_R = GRID_REACH_CELLS;
+constexpr int GRID_ROWS_W = 2 * GRID_ROWS_R + 1;
+static_assert(GRID_ROWS_W * GRID_ROWS_W <= 32, "row masks are 32 bits wide: GRID_DU_MAX <= 2");
+constexpr unsigned int grid_rows_rep()
+{
+    unsigned int r = 0;
+    for (int k = 0; k < GRID_ROWS_W; k++) r |= 1u << (GRID_ROWS_W * k);
+    return r;
+}
+// bit (oz * W + oy) for every row offset (oy, oz) in [y0, y1] x [z0, z1] (0 <= lo <= hi < W): an outer product, i.e. one multiply
+__device__ __forceinline__ unsigned int grid_rows_mask(int y0, int y1, int z0, int z1)
+{
+    y0 = min(max(y0, 0), GRID_ROWS_W - 1); y1 = min(max(y1, -1), GRID_ROWS_W - 1);     // (shift counts stay in range whatever comes in;
+    z0 = min(max(z0, 0), GRID_ROWS_W - 1); z1 = min(max(z1, -1), GRID_ROWS_W - 1);     //  hi < lo gives an empty mask)
+    const unsigned int ym = ((1u << (y1 + 1)) - 1u) & ~((1u << y0) - 1u);
+    const unsigned int zm = grid_rows_rep() & ((1u << (GRID_ROWS_W * (z1 + 1))) - 1u) & ~((1u << (GRID_ROWS_W * z0)) - 1u);
+    return ym * zm;
+}
+
+struct GridLane {
+    float q[3];
+    float u1, u2;                        // the query's cell coordinates on y and z
+    int cy, cz;                          // its own row (clamped into the grid)
+    unsigned long long kbest;            // fp32 bits of the best distance << 32 | its global index
+    unsigned int bslot;                  // slot in pts of the best candidate met by the scan
+    int budget;
+    bool alive;
+    unsigned int n_rows;                 // (STATS)
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+    unsigned long long t_in, t_block;    // developer build: entry of the scan, end of its first batch
+    unsigned int trips_block, trips_rest, batches_rest;
+#endif
+};
+
+struct __attribute__((packed, aligned(4))) GridOffsets4 { unsigned int v[4]; };
+
+// One batch: takes up to GRID_BATCH rows off `mask`, scans cells [x0, x1] of each that lies within r2.  NARROW: x1 - x0 <= 2, so a row's
+// two offsets come out of ONE 16-byte load (cell_start carries three words of padding).
+template <bool FMA, bool STATS, bool NARROW>
+__device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, unsigned int& mask, int x0, int x1, float r2)
+{
+    const float4* __restrict__ pts = g.pts;
+    const unsigned int* __restrict__ cell_start = g.cell_start;
+    unsigned int S[GRID_BATCH];
+    int C[GRID_BATCH];
+#pragma unroll
+    for (int j = 0; j < GRID_BATCH; j++) {
+        const bool have = mask != 0u;
+        const int b = have ? __builtin_ctz(mask) : 0;
+        mask &= mask - 1u;
+        const int oz = (b * ((256 + GRID_ROWS_W - 1) / GRID_ROWS_W)) >> 8, oy = b - GRID_ROWS_W * oz;       // b / W, b % W (b < 64)
+        const int iy = s.cy + oy - GRID_ROWS_R, iz = s.cz + oz - GRID_ROWS_R;
+        const float gy = gap_cells(s.u1, iy) * g.h_lo, gz = gap_cells(s.u2, iz) * g.h_lo;
+        // a row is skipped only if it is strictly farther than the search radius: then it cannot win or tie
+        const bool ok = have && s.alive && x1 >= x0 && gy * gy + gz * gz <= r2;
+        const unsigned int rb = ((unsigned int)iz * (unsigned int)g.ny + (unsigned int)iy) * (unsigned int)g.nx;
+        if (NARROW) {
+            GridOffsets4 o;
+            __builtin_memcpy(&o, cell_start + (ok ? rb + (unsigned int)x0 : 0u), sizeof o);
+            const unsigned int e = x1 - x0 == 0 ? o.v[1] : (x1 - x0 == 1 ? o.v[2] : o.v[3]);
+            S[j] = o.v[0];
+            C[j] = ok ? (int)(e - o.v[0]) : 0;
+        } else {
+            S[j] = cell_start[ok ? rb + (unsigned int)x0 : 0u];                        // (not ok: both offsets of entry 0, an empty run)
+            C[j] = (int)(cell_start[ok ? rb + (unsigned int)x1 + 1u : 0u] - S[j]);
+        }
+        if (STATS) s.n_rows += ok ? 1u : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < GRID_BATCH; j++) {
+        if (C[j] > s.budget) s.alive = false;                  // crowded: give up, the hierarchy takes over
+        C[j] = s.alive ? C[j] : 0;
+        s.budget -= C[j];
+    }
+    // the batch's runs as ONE flat sequence of candidates, four per trip.  (Two streams of runs with eight gathers in flight per
+    // lane were measured too -- profiles/r03_scan_forms.log: the lanes whose streams had run out still fetched and tested, and the
+    // bytes returned to the registers, 16 per lane and gather whatever the addresses, are one of the things a launch waits for.)
+    static_assert(GRID_BATCH == 4, "the run queue below holds four runs");
+    unsigned int p = S[0], s1 = S[1], s2 = S[2], s3 = S[3];
+    int left = C[0], c1 = C[1], c2 = C[2], c3 = C[3];
+    unsigned long long kbest = s.kbest;
+    unsigned int bslot = s.bslot;
+    while (__builtin_amdgcn_ballot_w64((left > 0) | ((c1 | c2 | c3) > 0)) != 0ull) {
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+        if (NARROW) s.trips_block += 1; else s.trips_rest += 1;
+#endif
+#pragma unroll
+        for (int hop = 0; hop < 2; hop++)                      // next non-empty run (an empty one costs the lane a hop, rarely a trip)
+            if (left <= 0) { p = s1; left = c1; s1 = s2; c1 = c2; s2 = s3; c2 = c3; c3 = 0; }
+        if (left > 0) {
+            const float4* __restrict__ pp = pts + p;           // one address, three immediate offsets
+            const float4 cs[4] = {pp[0], pp[1], pp[2], pp[3]};
+#pragma unroll
+            for (int j4 = 0; j4 < 4; j4++) {
+                const float d = sq3<FMA>(cs[j4].x - s.q[0], cs[j4].y - s.q[1], cs[j4].z - s.q[2]);
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(cs[j4].w);
+                const bool better = key < kbest;               // d >= +0: closer, or as close with a lower index
+                kbest = better ? key : kbest;
+                bslot = better ? p + (unsigned int)j4 : bslot;
+            }
+        }
+        p += 4;
+        left -= 4;
+    }
+    s.kbest = kbest;
+    s.bslot = bslot;
+}
+
+// Grid part of one lane's search.  Returns true if the lane gave up (it must then walk the hierarchy from (best, bidx)).
+//
+// The lane tests the points of every cell row within r2 = min(best, cap2) of the query; every point with d <= the FINAL r2 is
+// met, because r2 only shrinks and every row test and cell range uses an r2 that is at least the final one.  So if the final best
+// is within cap2 the answer is exact; otherwise (nothing near: the query lies outside the fixed cloud, or has no starting
+// candidate and sits in an empty region) the lane gives up.  cap2 is the square of (a hair less than) GRID_DU_MAX cells.
+// `in_reach` = occupied_near of the query's cell: false says no cell the scan could visit holds a point.
+template <bool FMA, bool STATS>
+__device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3], bool in_reach, float& best, unsigned int& bidx,
+                                            unsigned int& bslot, unsigned int& n_cand, unsigned int& n_rows
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+                                            , unsigned long long (&dev_tl)[3]
+#endif
+                                            )
+{
+    const float u0 = cell_u(q[0], g.ox, g.inv_h), u1 = cell_u(q[1], g.oy, g.inv_h), u2 = cell_u(q[2], g.oz, g.inv_h);
+    const float cap = (GRID_DU_MAX - 2e-3f) * g.h_lo;          // every point within `cap` of the query lies within GRID_DU_MAX cells
+    const float cap2 = cap * cap * (1.f - 1e-5f);
+    GridLane s;
+    s.q[0] = q[0]; s.q[1] = q[1]; s.q[2] = q[2];
+    s.u1 = u1; s.u2 = u2;
+    s.kbest = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
+    s.bslot = bslot;
+    s.budget = GRID_CAND_BUDGET;
+    s.n_rows = 0u;
+    const int cx = cell_index(u0, g.nx);
+    s.cy = cell_index(u1, g.ny);
+    s.cz = cell_index(u2, g.nz);
+    // The cells to visit for a radius: every point within sqrt(r2) of the query on an axis has its cell coordinate within du of
+    // the query's (monotonic rounding + the slack), hence its cell index in [floor(u - du), floor(u + du)], clamped into the grid
+    // like the points' own cell indices.  raw v_sqrt_f32 (1 ulp): covered by the slack.  du < GRID_DU_MAX, so every row lies
+    // within GRID_ROWS_R rows of the query's own: the masks' width.
+    float r2 = fminf(best, cap2);
+    float du = __builtin_amdgcn_sqrtf(r2 * 1.000001f) * g.inv_h * 1.00001f + 1e-3f;
+    float fx0 = floorf(u0 - du), fx1 = floorf(u0 + du), fy0 = floorf(u1 - du), fy1 = floorf(u1 + du), fz0 = floorf(u2 - du), fz1 = floorf(u2 + du);
+    s.alive = in_reach && fx1 >= 0.f && fx0 <= (float)(g.nx - 1) && fy1 >= 0.f && fy0 <= (float)(g.ny - 1) && fz1 >= 0.f && fz0 <= (float)(g.nz - 1);
+    // ---- the nearest 2 x 2 x 2 block (what of it the starting radius reaches)
+    const int sx = u0 - (float)cx >= 0.5f ? 1 : -1, sy = u1 - (float)s.cy >= 0.5f ? 1 : -1, sz = u2 - (float)s.cz >= 0.5f ? 1 : -1;
+    const int xa0 = max(max(min(cx, cx + sx), 0), (int)fmaxf(fx0, 0.f)), xa1 = min(min(max(cx, cx + sx), g.nx - 1), (int)fminf(fx1, (float)(g.nx - 1)));
+    const int ya0 = max(max(min(s.cy, s.cy + sy), 0), (int)fmaxf(fy0, 0.f)), ya1 = min(min(max(s.cy, s.cy + sy), g.ny - 1), (int)fminf(fy1, (float)(g.ny - 1)));
+    const int za0 = max(max(min(s.cz, s.cz + sz), 0), (int)fmaxf(fz0, 0.f)), za1 = min(min(max(s.cz, s.cz + sz), g.nz - 1), (int)fminf(fz1, (float)(g.nz - 1)));
+    // (alive: the query's own clamped cell lies inside the clamped ranges, so each of the three is non-empty)
+    const unsigned int block = s.alive ? grid_rows_mask(ya0 - s.cy + GRID_ROWS_R, ya1 - s.cy + GRID_ROWS_R, za0 - s.cz + GRID_ROWS_R, za1 - s.cz + GRID_ROWS_R) : 0u;
+    unsigned int mask = block;
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+    s.t_in = wall_clock64(); s.trips_block = s.trips_rest = s.batches_rest = 0;
+#endif
+    if (__builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) grid_batch<FMA, STATS, true>(g, s, mask, xa0, xa1, r2);
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+    s.t_block = wall_clock64();
+#endif
+    // ---- what the radius as it stands now still reaches, minus the rows of the block if their cells were all covered
+    r2 = fminf(__uint_as_float((unsigned int)(s.kbest >> 32)), cap2);
+    du = __builtin_amdgcn_sqrtf(r2 * 1.000001f) * g.inv_h * 1.00001f + 1e-3f;
+    fx0 = floorf(u0 - du); fx1 = floorf(u0 + du); fy0 = floorf(u1 - du); fy1 = floorf(u1 + du); fz0 = floorf(u2 - du); fz1 = floorf(u2 + du);
+    {
+        const int x0 = (int)fmaxf(fx0, 0.f), x1 = (int)fminf(fx1, (float)(g.nx - 1));
+        const int y0 = (int)fmaxf(fy0, 0.f), y1 = (int)fminf(fy1, (float)(g.ny - 1));
+        const int z0 = (int)fmaxf(fz0, 0.f), z1 = (int)fminf(fz1, (float)(g.nz - 1));
+        const bool covered = x0 >= xa0 && x1 <= xa1;           // the block's rows need no second look
+        mask = s.alive ? grid_rows_mask(y0 - s.cy + GRID_ROWS_R, y1 - s.cy + GRID_ROWS_R, z0 - s.cz + GRID_ROWS_R, z1 - s.cz + GRID_ROWS_R) & ~(covered ? block : 0u) : 0u;
+    }
+    while (__builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) {
+        // the cells of a row from the radius as it stands now: one range for the whole batch (a superset of what each row's own
+        // gap would leave of it)
+        r2 = fminf(__uint_as_float((unsigned int)(s.kbest >> 32)), cap2);
+        du = __builtin_amdgcn_sqrtf(r2 * 1.000001f) * g.inv_h * 1.00001f + 1e-3f;
+        const float flo = floorf(u0 - du), fhi = floorf(u0 + du);
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+        s.batches_rest += 1;
+#endif
+        grid_batch<FMA, STATS, false>(g, s, mask, (int)fmaxf(flo, 0.f), (int)fminf(fhi, (float)(g.nx - 1)), r2);
+    }
+    best = __uint_as_float((unsigned int)(s.kbest >> 32));
+    bidx = (unsigned int)s.kbest;
+    bslot = s.bslot;
+    if (STATS) { n_cand += (unsigned int)(GRID_CAND_BUDGET - s.budget); n_rows += s.n_rows; }
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+    dev_tl[0] = s.t_in; dev_tl[1] = s.t_block; dev_tl[2] = s.trips_block | ((unsigned long long)s.trips_rest << 16) | ((unsigned long long)s.batches_rest << 32);
+#endif
+    return !s.alive || !(best <= cap2);
+}
+
+#endif
+
 // One wave per workgroup, one lane per moving point: a wave's 64 Morton neighbours share cells and cache lines, and nothing has
 // to be exchanged between waves -- the lanes that give up walk the hierarchy TOGETHER right where they are (tree_walk_wave takes
 // any subset of a wave), the others wait masked off.
+// waves per SIMD the register allocation must leave room for: a launch lasts as long as its waves hold their slots (the walking
+// waves hold a third of them for most of it), so slots count for more than registers here
+#ifndef MISLAM_GRID_MIN_WAVES
+#define MISLAM_GRID_MIN_WAVES 7
+#endif
+#define MI_GRID_OCC __attribute__((amdgpu_waves_per_eu(MISLAM_GRID_MIN_WAVES, 8)))
 template <bool FMA, bool FUSED, bool STATS>
-__global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTreeView t, GridSearchArgs a)
+__global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridView g, NnTreeView t, GridSearchArgs a)
 {
     static_assert(GRID_BLOCK == 64 && ICP_ROW_POINTS == 64, "one wave = one workgroup = one row of partial sums");
     if (FUSED) {
         if (a.state->done != 0) return;
     } else if (a.done_flag != nullptr && *a.done_flag != 0) return;
     const int tid = (int)threadIdx.x;
+#ifdef MISLAM_DEV_WAVE_TIMELINE        // developer build: per wave { start, end of scan, end } in 100 MHz ticks + walk steps (tools/wave_timeline.py)
+    const unsigned long long tl_start = wall_clock64();
+    unsigned long long tl_scan = 0, dev_tl[3] = {0, 0, 0}, tl_p1 = 0, tl_p2 = 0, tl_p3 = 0;
+#define MI_TL_STAMP(var, dep) do { asm volatile("" :: "v"(dep)); var = wall_clock64(); } while (0)
+#else
+#define MI_TL_STAMP(var, dep) do { } while (0)
+#endif
 #ifdef MISLAM_DEV_WALK_CLOCK
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     unsigned long long pre_cycles = 0, life_cycles = 0;
@@ -336,6 +599,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
     if (FUSED && a.order != nullptr) chunk = (unsigned int)a.order[chunk];   // walking chunks first (IcpSchedule): speed only
     const int i = (int)(chunk * GRID_BLOCK) + tid;
     const bool valid = i < a.n;
+    MI_TL_STAMP(tl_p1, i);
 
     float q[3] = {0.f, 0.f, 0.f};
     float best = __builtin_inff();
@@ -353,6 +617,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
             q[0] = ((R[0] * x + R[3] * y) + R[6] * z) + tr[0];
             q[1] = ((R[1] * x + R[4] * y) + R[7] * z) + tr[1];
             q[2] = ((R[2] * x + R[5] * y) + R[8] * z) + tr[2];
+            MI_TL_STAMP(tl_p2, q[0] + q[1] + q[2]);
             const unsigned long long key = a.keys[i];
             const float d2 = __uint_as_float((unsigned int)(key >> 32));
             bslot = a.match_slot[i];
@@ -373,6 +638,10 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
         unpack_start(a.keys[i], best, bidx);
     }
 
+    MI_TL_STAMP(tl_p3, best);
+    // occupied_near of the query's (clamped) cell: 0 = the scan could not meet a single point (requested here, ahead of the scan)
+    bool in_reach = false;
+    if (valid) in_reach = g.occupied_near[cell_of(g, q[0], q[1], q[2])] != 0;
     bool hard = false;
     unsigned long long walk_cycles = 0;
     unsigned int n_cand = 0u, n_rows = 0u, n_nodes = 0u, n_leaves = 0u;
@@ -382,15 +651,32 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
     bool walk_only = false;
     if (FUSED && a.far != nullptr) walk_only = a.far[chunk] >= 2;
     if (walk_only) hard = valid;
+#ifdef MISLAM_GRID_SCAN_V1
     else if (valid) hard = grid_search<FMA, STATS>(g, q, best, bidx, bslot, n_cand, n_rows);
+#else
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+    else hard = grid_search<FMA, STATS>(g, q, valid && in_reach, best, bidx, bslot, n_cand, n_rows, dev_tl) && valid;
+#else
+    else hard = grid_search<FMA, STATS>(g, q, valid && in_reach, best, bidx, bslot, n_cand, n_rows) && valid;   // (all lanes: the loops run in step)
+#endif
+#endif
     const bool walked = __builtin_amdgcn_ballot_w64(hard) != 0ull;
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+    tl_scan = wall_clock64();
+#endif
 #ifndef MISLAM_DEV_SKIP_WALK          // timing experiments only (tools/build_variant.sh): wrong answers for the lanes concerned
     if (hard) {
 #ifdef MISLAM_DEV_WALK_CLOCK
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         pre_cycles = t0 - t_begin;
 #endif
+#ifdef MISLAM_DEV_WALK_PRIO
+        __builtin_amdgcn_s_setprio(MISLAM_DEV_WALK_PRIO);
+#endif
         tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves);
+#ifdef MISLAM_DEV_WALK_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef MISLAM_DEV_WALK_CLOCK
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
         walk_cycles = t1 - t0;
@@ -419,6 +705,15 @@ __global__ __launch_bounds__(GRID_BLOCK) void nn_grid_kernel(NnGridView g, NnTre
             wc = max(wc, (unsigned long long)__shfl_xor(wc, m, 64));
         }
         const unsigned long long nh = __builtin_popcountll(__builtin_amdgcn_ballot_w64(hard)), nv = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid));
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+        if (tid == 0) {
+            unsigned long long* tl = a.stats + (size_t)GRID_STATS_ROWS * 8 + (size_t)blockIdx.x * 16;
+            tl[8] = tl_p1; tl[9] = tl_p2; tl[10] = tl_p3;
+            tl[0] = tl_start; tl[1] = tl_scan; tl[2] = wall_clock64();
+            tl[3] = (unsigned long long)(v0 + v1) | (nh << 16) | ((unsigned long long)(walk_only ? 1 : 0) << 32) | ((unsigned long long)chunk << 40);
+            tl[4] = dev_tl[0]; tl[5] = dev_tl[1]; tl[6] = dev_tl[2]; tl[7] = 0;
+        }
+#endif
         if (tid == 0) {                                         // one set of atomics per wave
             atomicAdd(&srow[0], (unsigned long long)c0);
             atomicAdd(&srow[1], (unsigned long long)c1);

@@ -119,6 +119,7 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
             if (j < jb) bslot = s;
         }
     };
+#ifdef MISLAM_DEV_OLD_LEAF
     auto scan_leaf = [&](int leaf) {                            // leaf is wave-uniform: its points arrive through scalar loads
         if (STATS) n_leaves += 1;
         const int slot0 = leaf * TREE_LEAF;
@@ -132,6 +133,40 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
             offer(sq3<FMA>(X.w - p[0], Y.w - p[1], Z.w - p[2]), slot0 + 4 * c4 + 3);
         }
     };
+#else
+    // A leaf's distances first (packed fp32: the same IEEE operations, two per issue slot), then ONE question to the wave: does any
+    // lane see a point at or below its best?  Mostly not -- a walk that starts from real candidates is mainly there to prove that
+    // nothing closer exists -- and then the leaf is done; otherwise the sequential offers, which settle ties by global index.
+    auto scan_leaf = [&](int leaf) {                            // leaf is wave-uniform: its points arrive through scalar loads
+        if (STATS) n_leaves += 1;
+        const int slot0 = leaf * TREE_LEAF;
+        const float4* __restrict__ lp = leaf_soa + (size_t)leaf * (3 * TREE_LEAF / 4);
+        f32x2 d[TREE_LEAF / 2];
+        float m = inf;
+#pragma unroll
+        for (int c4 = 0; c4 < TREE_LEAF / 4; c4++) {
+            const float4 X = lp[c4], Y = lp[TREE_LEAF / 4 + c4], Z = lp[2 * (TREE_LEAF / 4) + c4];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                f32x2 dx, dy, dz;
+                dx.x = (h ? X.z : X.x) - p[0]; dx.y = (h ? X.w : X.y) - p[0];
+                dy.x = (h ? Y.z : Y.x) - p[1]; dy.y = (h ? Y.w : Y.y) - p[1];
+                dz.x = (h ? Z.z : Z.x) - p[2]; dz.y = (h ? Z.w : Z.y) - p[2];
+                f32x2 dd;
+                if constexpr (FMA) dd = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                else dd = (dx * dx + dy * dy) + dz * dz;
+                d[2 * c4 + h] = dd;
+                m = fminf(m, fminf(dd.x, dd.y));
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(m <= best) == 0ull) return;
+#pragma unroll
+        for (int k = 0; k < TREE_LEAF / 2; k++) {
+            offer(d[k].x, slot0 + 2 * k);
+            offer(d[k].y, slot0 + 2 * k + 1);
+        }
+    };
+#endif
     {
         const float root_lb = box6_bound<FMA>(boxes6, p);
         if (__builtin_amdgcn_ballot_w64(root_lb <= best && root_lb < inf) == 0ull) return;

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Developer tool (needs the MISLAM_DEV_WAVE_TIMELINE variant build, run with MISLAM_LIB=.../libmislam_timeline.so): when the waves of
+ONE search launch start, end their grid scan and end, against the launch's span -- where a launch's time goes.
+    python tools/wave_timeline.py [iteration ...]"""
+import os
+import sys
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+from bench import synth_cloud  # noqa: E402
+
+capi = load_package().capi
+its = [int(a) for a in sys.argv[1:]] or [6, 12, 20]
+n = int(os.environ.get("POINTS", "1000000"))
+path = "/tmp/mislam_timeline.bin"
+os.environ["MISLAM_DEV_TIMELINE_FILE"] = path
+before, after = synth_cloud(np, n)
+with capi.Context(0) as ctx:
+    ctx.icp_load(before, after, capi.icp_params(eps=0.0, max_iterations=-1, sync_every=1))
+    done = 0
+    for it in its:
+        if it > done:
+            ctx.icp_run(it - done)
+        done = it + 1
+        ctx.search_stats(True)
+        ctx.icp_run(1)
+        ctx.search_stats(False)
+        tl = np.fromfile(path, dtype=np.uint64).reshape(-1, 16)[: (n + 63) // 64].astype(np.int64)
+        t0 = tl[:, 0].min()
+        start, scan, end = (tl[:, 0] - t0) * 0.01, (tl[:, 1] - t0) * 0.01, (tl[:, 2] - t0) * 0.01      # microseconds (100 MHz ticks)
+        steps, far_lanes, walk_only = tl[:, 3] & 0xffff, (tl[:, 3] >> 16) & 0xffff, (tl[:, 3] >> 32) & 1
+        walked = far_lanes > 0
+        span = end.max()
+        print("it %d: launch span %.1f us, %d waves, %d walked (%d of them walk-only)" % (it, span, len(tl), walked.sum(), walk_only.sum()))
+        for name, m in (("scan-only waves", ~walked), ("walking waves", walked)):
+            if m.sum() == 0:
+                continue
+            print("  %-16s start p50 %.1f p99 %.1f max %.1f | scan time mean %.1f p99 %.1f | after-scan (walk) mean %.1f p99 %.1f max %.1f | end p50 %.1f p99 %.1f max %.1f"
+                  % (name, np.percentile(start[m], 50), np.percentile(start[m], 99), start[m].max(), (scan - start)[m].mean(),
+                     np.percentile((scan - start)[m], 99), (end - scan)[m].mean(), np.percentile((end - scan)[m], 99), (end - scan)[m].max(),
+                     np.percentile(end[m], 50), np.percentile(end[m], 99), end[m].max()))
+        m = ~walked
+        t_in, t_blk = (tl[:, 4] - t0) * 0.01, (tl[:, 5] - t0) * 0.01
+        trips_b, trips_r, batches_r = tl[:, 6] & 0xffff, (tl[:, 6] >> 16) & 0xffff, (tl[:, 6] >> 32) & 0xffff
+        print("  scan-only waves, us: prologue %.1f | first batch %.1f (%.1f trips) | rest %.1f (%.1f batches, %.1f trips) | epilogue %.1f"
+              % ((t_in - start)[m].mean(), (t_blk - t_in)[m].mean(), trips_b[m].mean(), (scan - t_blk)[m].mean(), batches_r[m].mean(), trips_r[m].mean(), (end - scan)[m].mean()))
+        p1, p2, p3 = (tl[:, 8] - t0) * 0.01, (tl[:, 9] - t0) * 0.01, (tl[:, 10] - t0) * 0.01
+        print("  scan-only waves, prologue us: work order -> %.1f | state + moving point -> %.1f | key, slot, previous match -> %.1f | near flag -> %.1f"
+              % ((p1 - start)[m].mean(), (p2 - p1)[m].mean(), (p3 - p2)[m].mean(), (t_in - p3)[m].mean()))
+        if walked.sum():
+            w = np.where(walked)[0]
+            per_step = (end - scan)[w] / np.maximum(steps[w], 1)
+            print("  walk: steps mean %.1f p99 %d max %d; us per step mean %.2f (p10 %.2f p90 %.2f); far lanes per walking wave mean %.1f"
+                  % (steps[w].mean(), np.percentile(steps[w], 99), steps[w].max(), per_step.mean(), np.percentile(per_step, 10), np.percentile(per_step, 90), far_lanes[w].mean()))
+        # waves resident over time (10 us bins)
+        edges = np.arange(0, span + 10, 10)
+        res = [(int(((start <= t) & (end > t)).sum()), int(((start <= t) & (end > t) & walked).sum())) for t in edges]
+        print("  resident waves (all/walking) every 10 us:", " ".join("%d/%d" % r for r in res))
