@@ -96,6 +96,39 @@ def cpu_baseline(np, before, after, target_seconds=15.0):
             "pairs_per_s": rows * m / dt}
 
 
+def whole_call(np, capi, ctx, n, repeats=3):
+    """One registration as the reference times it (testrunner.cpp:54-56, doc/documentation.tex:397): mi_icp_register on HOST buffers,
+    upload / index builds / 50 iterations / result included, GPU-reference driver rules and sweep settings (testset.cpp:82-117).
+    `ms` = best of `repeats` calls on a context that has seen the size (the first call of a size also pays its device allocations:
+    `first_call_ms`); `breakdown` = one more call split into load stages (stream drained after each, so they add up) + iterations."""
+    before, after = synth_cloud(np, n)
+    p = capi.icp_params(cuda_slam=True, max_iterations=50, eps=1e-3, max_distance_squared=10000.0)
+    t0 = time.perf_counter()
+    R, t, it, err = ctx.icp_register(before, after, p)
+    first = (time.perf_counter() - t0) * 1e3
+    times = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        R, t, it, err = ctx.icp_register(before, after, p)
+        times.append((time.perf_counter() - t0) * 1e3)
+    ctx.profile_enable(True)
+    ctx.profile_select([])
+    t0 = time.perf_counter()
+    ctx.icp_load(before, after, p)
+    t1 = time.perf_counter()
+    done = ctx.icp_run(-1)
+    ctx.icp_result()
+    t2 = time.perf_counter()
+    stages = ctx.icp_load_times()
+    ctx.profile_enable(False)
+    ctx.profile_select(None)
+    passes = max(done, 1)
+    return {"points": n, "ms": min(times), "ms_all": times, "first_call_ms": first, "iterations": it, "loop_passes": done,
+            "ms_per_iteration_whole_call": min(times) / passes,
+            "breakdown": {"load_stages_ms": stages, "load_ms": (t1 - t0) * 1e3, "iterations_ms": (t2 - t1) * 1e3,
+                          "note": "stages drained one by one (profiling on): their sum exceeds what the same load costs inside `ms`"}}
+
+
 def cpd_bunny(np, capi, ctx, world):
     """cfg 4 (bunny 14 904 x 14 904, cpd-weight .3, scale free) through mi_cpd_register: exact P, and hybrid where one rank runs."""
     gold = os.path.join(ROOT, "tests", "golden")

@@ -37,7 +37,7 @@ EXPORTS = [
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_sigma_squared_mode", "mi_cpd_estep",
     "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
     "mi_prepare_params_default", "mi_prepare_cloud",
-    "mi_cpd_mstep", "mi_profile_enable", "mi_profile_select", "mi_profile_reset", "mi_profile_get", "mi_profile_search_stats", "mi_selftest_sort_pairs", "mi_nn_kernel_name",
+    "mi_cpd_mstep", "mi_profile_enable", "mi_profile_select", "mi_profile_reset", "mi_profile_get", "mi_icp_load_times", "mi_profile_search_stats", "mi_selftest_sort_pairs", "mi_nn_kernel_name",
 ]
 
 
@@ -473,6 +473,12 @@ class Context:
 
     def profile_reset(self):
         _check(lib().mi_profile_reset(self._h))
+
+    def icp_load_times(self):
+        """ms per stage of the last icp_load: workspace, moving upload, moving order, fixed upload, hierarchy, grid, reset, total."""
+        out = (C.c_double * 8)()
+        _check(lib().mi_icp_load_times(self._h, out))
+        return dict(zip(("workspace", "upload_moving", "order_moving", "upload_fixed", "hierarchy", "grid", "reset", "total"), list(out)))
 
     def profile_get(self, kernel):
         ms, n = C.c_double(0), C.c_longlong(0)

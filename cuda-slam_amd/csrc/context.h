@@ -42,7 +42,20 @@ void set_error(const char* fmt, ...);
         if (rc_ != MI_OK) return rc_; \
     } while (0)
 
-// grow-only device buffer
+// Device buffers that were outgrown: work already enqueued may still read them, so they are released at the next point where the
+// host has drained the stream anyway (retire_buffers, called behind the loads' and runs' own synchronisations) -- not behind a
+// device-wide synchronisation per buffer, which is what a load of forty buffers used to pay when a size was new.
+void retire_later(void* p);
+void retire_buffers();
+// Device memory comes out of the runtime's stream-ordered pool, kept whole (release threshold: never): hipFree of a plain
+// allocation costs ~0.2 ms on this machine (tools/alloc_probe.cpp) -- forty buffers outgrown by a new size were 8 ms -- the pool's
+// free is ~1 us and its memory is handed out again.  MISLAM_POOL=0 (or a runtime without the pool) falls back to hipMalloc / hipFree.
+hipError_t device_alloc(void** p, size_t bytes);
+void device_free(void* p);
+double& alloc_ms_counter();        // host ms this thread has spent in hipMalloc through DevBuf::reserve (mi_icp_load_times)
+double wall_ms();
+
+// grow-only device buffer; grows by at least half (a sweep over slowly rising sizes reallocates a few times, not every call)
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -50,19 +63,20 @@ struct DevBuf {
     int reserve(size_t count)
     {
         if (count <= cap) return MI_OK;
-        if (p) {
-            MI_HIP(hipDeviceSynchronize());   // work still reading the old buffer must drain before it is freed
-            MI_HIP(hipFree(p));
-        }
+        if (p) retire_later(p);
         p = nullptr;
+        const size_t grown = cap + cap / 2;
+        if (cap != 0 && count < grown) count = grown;
         cap = 0;
-        MI_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        const double t0 = wall_ms();
+        MI_HIP(device_alloc((void**)&p, count * sizeof(T)));
+        alloc_ms_counter() += wall_ms() - t0;
         cap = count;
         return MI_OK;
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) device_free(p);
         p = nullptr;
         cap = 0;
     }
@@ -99,6 +113,14 @@ struct mi_ctx {
 
     // ---- workspace shared by the drivers
     mislam::DevBuf<float> staging;                       // AoS upload/download staging
+    // pinned host staging of the cloud uploads (host_to_device): the runtime's own pageable-copy path stalls for 20-50 ms every
+    // few dozen calls on this machine (tools/alloc_probe.cpp: median 0.36 ms, max 27 ms for 12 MB); 1 MB pieces copied here and sent
+    // on while the next piece is being copied take 0.30 ms, every time
+    char* pin = nullptr;
+    size_t pin_cap = 0, pin_used = 0;
+    hipEvent_t pin_event = nullptr;                      // recorded behind the last transfer out of `pin`
+    bool pin_busy = false;
+    float* h_scratch = nullptr;                          // 64 pinned floats for small read-backs
     mislam::DevBuf<float> bx, by, bz;                    // original moving cloud, SoA
     mislam::DevBuf<float> cx, cy, cz;                    // current (transformed) moving cloud, SoA
     mislam::DevBuf<float> ax, ay, az;                    // multi-GPU load scratch: the whole moving cloud in Hilbert order
@@ -139,10 +161,12 @@ struct mi_ctx {
     // ---- ICP problem currently loaded
     bool icp_loaded = false;
     int n = 0, n_pad = 0;
+    int n_global = 0;                                    // moving points over ALL ranks (what rank-independent decisions are taken from)
     int m_total = 0, shard_lo = 0, shard_hi = 0;
     bool source_sharded = false;                         // MI_SHARD_SOURCE in effect: n = this rank's slice, fixed cloud replicated
     bool fused = false;                                  // the grid search carries the O(N) part of the iteration (nn_grid.hip)
     mi_icp_params icp{};
+    double load_ms[MI_LOAD_STAGES] = {0};                // mi_icp_load_times
 
     // ---- CPD workspace (allocated on first use)
     mislam::CpdWorkspace* cpd = nullptr;
@@ -177,6 +201,9 @@ struct NnPlan {
 NnPlan plan_nn(const mi_ctx* ctx, int n, int m_local);
 size_t target_alloc_len(int m_local);
 
+// Host -> device on the context's stream, through the context's pinned staging buffer for anything sizeable (returns at once;
+// the caller's buffer may be reused as soon as this returns).
+int host_to_device(mi_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 // Upload an AoS host cloud into SoA device arrays of n_pad entries (tail = copies of the last point).
 int upload_soa(mi_ctx* ctx, const float* host_aos, int n, int n_pad, float* x, float* y, float* z, float4* packed);
 // Uploads this rank's shard of the fixed cloud (SoA streams for K1 + float4 for gathers); invalidates the box hierarchy.

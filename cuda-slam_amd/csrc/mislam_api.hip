@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -28,6 +29,83 @@ void set_error(const char* fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_error, sizeof g_error, fmt, ap);
     va_end(ap);
+}
+}  // namespace mislam
+
+namespace mislam {
+static std::mutex g_retired_mutex;
+static std::vector<void*> g_retired;
+double& alloc_ms_counter()
+{
+    static thread_local double ms = 0.0;
+    return ms;
+}
+double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void retire_later(void* p)
+{
+    std::lock_guard<std::mutex> lock(g_retired_mutex);
+    g_retired.push_back(p);
+}
+// One allocation stream per device, with no work on it: the pool's stream-ordered calls complete at once there.  A buffer is only
+// ever freed behind a synchronisation of the stream that used it (retire_buffers, context destruction), so handing its memory out
+// again -- to this context or another -- is safe whatever stream the new owner works on.
+static constexpr int MAX_DEVICES = 64;
+static hipStream_t g_alloc_stream[MAX_DEVICES] = {nullptr};
+static int g_use_pool = -1;                     // -1: not decided yet
+static std::mutex g_pool_mutex;
+static hipStream_t alloc_stream()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    if (g_use_pool == -1) {
+        const char* e = getenv("MISLAM_POOL");
+        g_use_pool = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (!g_use_pool) return nullptr;
+    if (g_alloc_stream[dev] == nullptr) {
+        hipMemPool_t pool = nullptr;
+        hipStream_t s = nullptr;
+        unsigned long long keep = ~0ull;
+        if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess || hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess ||
+            hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            g_use_pool = 0;
+            return nullptr;
+        }
+        g_alloc_stream[dev] = s;
+    }
+    return g_alloc_stream[dev];
+}
+static bool g_pool_proven = false;               // a pool allocation has succeeded: the mode never changes after that
+hipError_t device_alloc(void** p, size_t bytes)
+{
+    if (hipStream_t s = alloc_stream()) {
+        hipError_t e = hipMallocAsync(p, bytes, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);          // (nothing else is ever on this stream: the memory is usable on any stream from here)
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        if (e == hipSuccess) { g_pool_proven = true; return e; }
+        (void)hipGetLastError();
+        if (g_pool_proven || e == hipErrorOutOfMemory) return e;
+        g_use_pool = 0;                          // this runtime has no working pool: plain allocations throughout
+    }
+    return hipMalloc(p, bytes);
+}
+void device_free(void* p)
+{
+    if (p == nullptr) return;
+    if (hipStream_t s = alloc_stream()) { (void)hipFreeAsync(p, s); return; }
+    (void)hipFree(p);
+}
+// (called right behind a stream synchronisation: nothing still uses these)
+void retire_buffers()
+{
+    std::vector<void*> v;
+    {
+        std::lock_guard<std::mutex> lock(g_retired_mutex);
+        v.swap(g_retired);
+    }
+    for (void* p : v) device_free(p);
 }
 }  // namespace mislam
 
@@ -92,6 +170,14 @@ static int ctx_create_common(int device, mi_ctx** out)
         c->tune.fgt_resume = env_i("MISLAM_FGT_RESUME", 1);
         if (const char* ppc = getenv("MISLAM_GRID_PPC")) { const float f = (float)atof(ppc); if (f >= 0.25f && f <= 64.f) c->tune.grid_points_per_cell = f; }
         if (env_i("MISLAM_PRELOAD", 0) == 1) MI_TRY(mi_ctx_preload(c));       // =1: mi_ctx_preload as part of every context creation
+        // pinned upload staging: pinning host memory costs ~0.25 ms per MB on this machine, so the first 32 MB (both clouds of a
+        // 1.3-million-point registration) are pinned here, once per context, not inside some registration call; it grows on demand
+        const int pin_mb = env_i("MISLAM_PIN_MB", 32);
+        if (pin_mb > 0) {
+            MI_HIP(hipHostMalloc((void**)&c->pin, (size_t)pin_mb << 20, hipHostMallocDefault));
+            c->pin_cap = (size_t)pin_mb << 20;
+        }
+        MI_HIP(hipHostMalloc((void**)&c->h_scratch, 64 * sizeof(float), hipHostMallocDefault));
         return MI_OK;
     }();
     if (rc != MI_OK) { mi_ctx_destroy(c); return rc; }
@@ -255,8 +341,12 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    retire_buffers();
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->exchange_host) (void)hipHostFree(c->exchange_host);
+    if (c->pin) (void)hipHostFree(c->pin);
+    if (c->h_scratch) (void)hipHostFree(c->h_scratch);
+    if (c->pin_event) (void)hipEventDestroy(c->pin_event);
     cpd_workspace_destroy(c);
     c->staging.release();
     c->bx.release(); c->by.release(); c->bz.release();
@@ -283,6 +373,7 @@ extern "C" int mi_ctx_synchronize(mi_ctx* c)
     if (!c) { set_error("mi_ctx_synchronize: null context"); return MI_ERR_INVALID_ARG; }
     MI_HIP(hipSetDevice(c->device));
     MI_HIP(hipStreamSynchronize(c->stream));
+    retire_buffers();
     return MI_OK;
 }
 
@@ -452,10 +543,43 @@ NnPlan plan_nn(const mi_ctx* ctx, int n, int m_local)
     return p;
 }
 
+int host_to_device(mi_ctx* c, void* dst_dev, const void* src_host, size_t bytes)
+{
+    constexpr size_t PIECE = 1u << 20;
+    if (bytes < PIECE / 4) {                          // small: the runtime's path is fine (and synchronous for pageable memory)
+        MI_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+        return MI_OK;
+    }
+    if (c->pin_used + bytes > c->pin_cap) {           // no room left: start over at the front once the transfers in flight are done
+        if (c->pin_busy) { MI_HIP(hipEventSynchronize(c->pin_event)); c->pin_busy = false; }
+        c->pin_used = 0;
+        if (bytes > c->pin_cap) {
+            if (c->pin) (void)hipHostFree(c->pin);
+    if (c->h_scratch) (void)hipHostFree(c->h_scratch);
+            c->pin = nullptr;
+            const size_t want = std::max(2 * bytes, c->pin_cap + c->pin_cap / 2);      // room for both clouds of a registration
+            c->pin_cap = 0;
+            MI_HIP(hipHostMalloc((void**)&c->pin, want, hipHostMallocDefault));
+            c->pin_cap = want;
+        }
+    }
+    if (!c->pin_event) MI_HIP(hipEventCreateWithFlags(&c->pin_event, hipEventDisableTiming));
+    char* base = c->pin + c->pin_used;
+    for (size_t o = 0; o < bytes; o += PIECE) {       // the copy of piece k overlaps the transfer of piece k - 1
+        const size_t nb = std::min(PIECE, bytes - o);
+        memcpy(base + o, (const char*)src_host + o, nb);
+        MI_HIP(hipMemcpyAsync((char*)dst_dev + o, base + o, nb, hipMemcpyHostToDevice, c->stream));
+    }
+    c->pin_used += (bytes + 255) / 256 * 256;
+    MI_HIP(hipEventRecord(c->pin_event, c->stream));
+    c->pin_busy = true;
+    return MI_OK;
+}
+
 int upload_soa(mi_ctx* c, const float* host_aos, int n, int n_pad, float* x, float* y, float* z, float4* packed)
 {
     MI_TRY(c->staging.reserve((size_t)3 * n));
-    MI_HIP(hipMemcpyAsync(c->staging.p, host_aos, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    MI_TRY(host_to_device(c, c->staging.p, host_aos, sizeof(float) * 3 * (size_t)n));
     MI_HIP(aos_to_soa(c->staging.p, n, n_pad, x, y, z, packed, c->stream));
     // the staging buffer is reused by the next upload: keep stream order, and a pageable-memory copy is already
     // synchronous with respect to the host buffer
@@ -514,8 +638,8 @@ static int ensure_grid(mi_ctx* c, int m_local, int index_base)
     MI_TRY(c->tbbox.reserve(256 * 6 + 8));
     float* d_bbox = c->tbbox.p + 256 * 6;
     MI_HIP(cloud_bbox(c->tx.p, c->ty.p, c->tz.p, m_local, c->tbbox.p, d_bbox, c->stream));
-    float bbox[6];
-    MI_HIP(hipMemcpyAsync(bbox, d_bbox, sizeof bbox, hipMemcpyDeviceToHost, c->stream));
+    float* bbox = c->h_scratch;                        // (pinned: a read-back into pageable memory goes through the runtime's staging)
+    MI_HIP(hipMemcpyAsync(bbox, d_bbox, 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     MI_HIP(hipStreamSynchronize(c->stream));
     NnGridView g{};
     grid_plan(bbox, m_local, c->tune.grid_points_per_cell, &g);
@@ -751,6 +875,7 @@ extern "C" int mi_icp_reset(mi_ctx* c)
     }
     MI_HIP(icp_schedule_reset(make_schedule(c), icp_row_count(c->n), c->stream));
     MI_HIP(hipStreamSynchronize(c->stream));
+    retire_buffers();
     return MI_OK;
 }
 
@@ -763,6 +888,18 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
     MI_TRY(icp_check_params(params));
     if (params->sum_mode == MI_SUM_CPU_SEQUENTIAL && c->distributed()) { set_error("mi_icp_load: MI_SUM_CPU_SEQUENTIAL needs a single-GPU context (the running sums follow one global point order)"); return MI_ERR_INVALID_ARG; }
     MI_HIP(hipSetDevice(c->device));
+    // mi_icp_load_times: host wall time per stage; with profiling on, the stream is drained at every mark
+    const double t_begin = wall_ms();
+    double t_mark = t_begin, a_mark = alloc_ms_counter();
+    for (double& v : c->load_ms) v = 0.0;
+    auto mark = [&](int stage) -> int {             // time since the last mark -> `stage`, its device allocations -> stage 0
+        if (c->profile) MI_HIP(hipStreamSynchronize(c->stream));
+        const double now = wall_ms(), a_now = alloc_ms_counter();
+        c->load_ms[0] += a_now - a_mark;
+        c->load_ms[stage] += (now - t_mark) - (a_now - a_mark);
+        t_mark = now; a_mark = a_now;
+        return MI_OK;
+    };
     c->icp_loaded = false;
     c->icp = *params;
     // what the ranks split (mi_slam.h MI_SHARD_*): decided from GLOBAL sizes, so every rank decides alike
@@ -777,6 +914,7 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
     // rank orders the WHOLE moving cloud along the Hilbert curve (1 ms) and keeps the 64-point chunks rank, rank + W, rank + 2W ...
     // of that order.  (Clouds too small for a few chunks per rank are cut into contiguous slices of the caller's order instead.)
     const int n_all = n_before;
+    c->n_global = n_all;
     const bool deal_chunks = c->source_sharded && n_all >= 4 * ICP_CHUNK_POINTS * c->world;
     if (c->source_sharded && !deal_chunks) {
         int slo = 0, shi = 0;
@@ -791,25 +929,32 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
     MI_TRY(c->bx.reserve(np)); MI_TRY(c->by.reserve(np)); MI_TRY(c->bz.reserve(np));
     MI_TRY(c->keys.reserve(np));
     MI_TRY(reserve_rows(c));
+    MI_TRY(mark(0));
     if (deal_chunks) {
         const int all_pad = round_up(n_all, NN_SRC_PAD);
         MI_TRY(c->cx.reserve((size_t)all_pad)); MI_TRY(c->cy.reserve((size_t)all_pad)); MI_TRY(c->cz.reserve((size_t)all_pad));
         MI_TRY(c->ax.reserve((size_t)all_pad)); MI_TRY(c->ay.reserve((size_t)all_pad)); MI_TRY(c->az.reserve((size_t)all_pad));
         MI_TRY(upload_soa(c, before_xyz, n_all, all_pad, c->cx.p, c->cy.p, c->cz.p, nullptr));
+        MI_TRY(mark(1));
         MI_TRY(sort_sources(c, c->cx.p, c->cy.p, c->cz.p, n_all, all_pad, c->ax.p, c->ay.p, c->az.p));
         MI_HIP(deal_chunks_soa(c->ax.p, c->ay.p, c->az.p, n_all, c->rank, c->world, c->n, c->n_pad, c->bx.p, c->by.p, c->bz.p, c->stream));
+        MI_TRY(mark(2));
     } else {
         MI_TRY(c->cx.reserve(np)); MI_TRY(c->cy.reserve(np)); MI_TRY(c->cz.reserve(np));
         // moving cloud: upload in the caller's order (cx.. as scratch), keep it Hilbert-sorted in bx..
         MI_TRY(upload_soa(c, before_xyz, n_before, c->n_pad, c->cx.p, c->cy.p, c->cz.p, nullptr));
+        MI_TRY(mark(1));
         MI_TRY(sort_sources(c, c->cx.p, c->cy.p, c->cz.p, n_before, c->n_pad, c->bx.p, c->by.p, c->bz.p));
+        MI_TRY(mark(2));
     }
     if (params->sum_mode == MI_SUM_CPU_SEQUENTIAL) {   // the sequential sums run in the CALLER's point order
         MI_TRY(c->sinv.reserve((size_t)n_before));
         MI_TRY(c->resid.reserve(np));
         MI_HIP(invert_order(c->sorder.p, n_before, c->sinv.p, c->stream));
     }
+    MI_TRY(mark(2));
     MI_TRY(upload_target_shard(c, after_xyz, n_after, c->source_sharded));
+    MI_TRY(mark(3));
     // The grid search carries the whole O(N) part of the iteration (nn_grid.hip) unless a stand-alone step has to come between
     // the search and the sums: the key all-reduce of a sharded fixed cloud, or cpu-slam's sequential running sums.
     const int m_local = c->shard_hi - c->shard_lo;
@@ -817,10 +962,22 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
     c->fused = mode == MI_NN_GRID && (!c->distributed() || c->source_sharded) && params->sum_mode == MI_SUM_EXACT;
     if (mode != MI_NN_BRUTEFORCE) {          // build the indexes now, not inside the first timed iteration
         MI_TRY(ensure_tree(c, m_local, c->shard_lo));
+        MI_TRY(mark(4));
         if (mode == MI_NN_GRID) MI_TRY(ensure_grid(c, m_local, c->shard_lo));
+        MI_TRY(mark(5));
     }
     c->icp_loaded = true;
-    return mi_icp_reset(c);
+    MI_TRY(mi_icp_reset(c));
+    MI_TRY(mark(6));
+    c->load_ms[7] = wall_ms() - t_begin;
+    return MI_OK;
+}
+
+extern "C" int mi_icp_load_times(mi_ctx* c, double out_ms[MI_LOAD_STAGES])
+{
+    if (!c || !out_ms) { set_error("mi_icp_load_times: null argument"); return MI_ERR_INVALID_ARG; }
+    for (int i = 0; i < MI_LOAD_STAGES; i++) out_ms[i] = c->load_ms[i];
+    return MI_OK;
 }
 
 static IcpRules icp_rules(const mi_ctx* c)
@@ -914,6 +1071,7 @@ static int icp_fetch_state(mi_ctx* c)
 {
     MI_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
     MI_HIP(hipStreamSynchronize(c->stream));
+    retire_buffers();
     return MI_OK;
 }
 
@@ -927,9 +1085,11 @@ extern "C" int mi_icp_run(mi_ctx* c, int max_new_iterations, int* iterations_don
     if (batch <= 0) {
         // auto: a long iteration dwarfs a host round trip (check after each one); short ones are launch-bound (batch them).
         // Estimated from the measured rates: every-pair ~7e12 pairs/s, indexed searches ~5e-11 s per moving point + launches.
-        const int m_local = c->shard_hi - c->shard_lo;
-        const bool brute = resolve_nn_mode(c, c->icp.nn_mode, m_local) == MI_NN_BRUTEFORCE;
-        const double est_s = brute ? (double)c->n * (double)m_local / 7e12 : 2e-5 + 5e-11 * (double)c->n;
+        // From GLOBAL sizes only: every batch ends in a collective, so all ranks must pick the same batch (a rank's own share
+        // of the dealt moving cloud differs from its neighbours' by up to 64 points).
+        const bool brute = resolve_nn_mode(c, c->icp.nn_mode, c->source_sharded ? c->m_total : c->m_total / c->world) == MI_NN_BRUTEFORCE;
+        const double n_rank = (double)c->n_global / c->world, m_rank = (double)c->m_total / c->world;
+        const double est_s = brute ? (c->source_sharded ? n_rank * (double)c->m_total : (double)c->n_global * m_rank) / 7e12 : 2e-5 + 5e-11 * n_rank;
         batch = est_s >= 5e-3 ? 1 : (est_s >= 2e-4 ? 4 : (est_s >= 1e-4 ? 8 : 16));
     }
     if (c->icp.verbose) batch = 1;       // one "loop_nr" line per iteration, like basicicp.cpp:50 / icpcuda.cu:39

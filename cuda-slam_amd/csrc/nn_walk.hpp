@@ -119,21 +119,6 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
             if (j < jb) bslot = s;
         }
     };
-#ifdef MISLAM_DEV_OLD_LEAF
-    auto scan_leaf = [&](int leaf) {                            // leaf is wave-uniform: its points arrive through scalar loads
-        if (STATS) n_leaves += 1;
-        const int slot0 = leaf * TREE_LEAF;
-        const float4* __restrict__ lp = leaf_soa + (size_t)leaf * (3 * TREE_LEAF / 4);
-#pragma unroll
-        for (int c4 = 0; c4 < TREE_LEAF / 4; c4++) {
-            const float4 X = lp[c4], Y = lp[TREE_LEAF / 4 + c4], Z = lp[2 * (TREE_LEAF / 4) + c4];
-            offer(sq3<FMA>(X.x - p[0], Y.x - p[1], Z.x - p[2]), slot0 + 4 * c4);
-            offer(sq3<FMA>(X.y - p[0], Y.y - p[1], Z.y - p[2]), slot0 + 4 * c4 + 1);
-            offer(sq3<FMA>(X.z - p[0], Y.z - p[1], Z.z - p[2]), slot0 + 4 * c4 + 2);
-            offer(sq3<FMA>(X.w - p[0], Y.w - p[1], Z.w - p[2]), slot0 + 4 * c4 + 3);
-        }
-    };
-#else
     // A leaf's distances first (packed fp32: the same IEEE operations, two per issue slot), then ONE question to the wave: does any
     // lane see a point at or below its best?  Mostly not -- a walk that starts from real candidates is mainly there to prove that
     // nothing closer exists -- and then the leaf is done; otherwise the sequential offers, which settle ties by global index.
@@ -166,7 +151,6 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
             offer(d[k].y, slot0 + 2 * k + 1);
         }
     };
-#endif
     {
         const float root_lb = box6_bound<FMA>(boxes6, p);
         if (__builtin_amdgcn_ballot_w64(root_lb <= best && root_lb < inf) == 0ull) return;

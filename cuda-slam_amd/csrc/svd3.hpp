@@ -124,19 +124,25 @@ __host__ __device__ inline Svd3 svd3(const Mat3& A)
         if (d < 0.f)
             for (int r = 0; r < 3; r++) out.U.a[r][i] = -out.U.a[r][i];
     }
-    // selection sort, descending, swapping the matching columns of U and V
-    for (int i = 0; i < 2; i++) {
-        int pos = i;
-        for (int k = i + 1; k < 3; k++)
-            if (out.S[k] > out.S[pos]) pos = k;
-        if (out.S[pos] == 0.f) break;
-        if (pos != i) {
-            float tmp = out.S[i]; out.S[i] = out.S[pos]; out.S[pos] = tmp;
-            for (int r = 0; r < 3; r++) {
-                tmp = out.U.a[r][i]; out.U.a[r][i] = out.U.a[r][pos]; out.U.a[r][pos] = tmp;
-                tmp = out.V.a[r][i]; out.V.a[r][i] = out.V.a[r][pos]; out.V.a[r][pos] = tmp;
-            }
+    // Eigen's selection sort, descending, swapping the matching columns of U and V -- for i = 0, 1: the FIRST maximum of S[i..2]
+    // goes to i (a maximum of 0 ends the sort, which changes nothing: then the tail is all zeros and the first maximum is i itself).
+    // Written with fixed indices and selects: a position computed at run time would put U, V and S into scratch memory (it did:
+    // 26 scratch stores and their reloads on the solve kernel's one-lane critical path).
+    auto swap_cols = [&](int i, int j, bool doit) {
+        const float si = out.S[i], sj = out.S[j];
+        out.S[i] = doit ? sj : si; out.S[j] = doit ? si : sj;
+        for (int r = 0; r < 3; r++) {
+            const float ui = out.U.a[r][i], uj = out.U.a[r][j], vi = out.V.a[r][i], vj = out.V.a[r][j];
+            out.U.a[r][i] = doit ? uj : ui; out.U.a[r][j] = doit ? ui : uj;
+            out.V.a[r][i] = doit ? vj : vi; out.V.a[r][j] = doit ? vi : vj;
         }
+    };
+    {
+        const bool p1 = out.S[1] > out.S[0];
+        const bool p2 = out.S[2] > (p1 ? out.S[1] : out.S[0]);
+        swap_cols(0, 1, p1 && !p2);
+        swap_cols(0, 2, p2);
+        swap_cols(1, 2, out.S[2] > out.S[1]);
     }
     return out;
 }

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MI_SLAM_ABI_VERSION 2   /* 2: mi_cpd_params gained sigma2_mode; mi_dist_info, mi_source_share, mi_cpd_sigma_squared_mode, mi_profile_search_stats, mi_selftest_sort_pairs */
+#define MI_SLAM_ABI_VERSION 3   /* 3: mi_icp_load_times; 2: mi_cpd_params gained sigma2_mode; mi_dist_info, mi_source_share, mi_cpd_sigma_squared_mode, mi_profile_search_stats, mi_selftest_sort_pairs */
 
 enum {
     MI_OK = 0,
@@ -402,6 +402,16 @@ int mi_profile_select(mi_ctx* ctx, unsigned int kernel_mask);
 int mi_profile_reset(mi_ctx* ctx);
 /* total_ms = sum of event-timed durations of that kernel since the last reset; launches = how many. */
 int mi_profile_get(mi_ctx* ctx, int kernel, double* total_ms, long long* launches);
+/* Where the last mi_icp_load (or the load inside mi_icp_register) spent its host wall time, in ms -- what the reference's own
+ * timing of a whole SlamFunc call includes besides the iterations (testrunner.cpp:54-56, doc/documentation.tex:397):
+ *   out[0] workspace (device allocations)          out[1] moving cloud: upload + AoS -> SoA
+ *   out[2] moving cloud: Hilbert order + permute    out[3] fixed cloud: upload + AoS -> SoA
+ *   out[4] box hierarchy over the fixed cloud       out[5] cell grid over the fixed cloud
+ *   out[6] state reset                              out[7] the whole load
+ * While profiling is enabled (mi_profile_enable) the stream is drained after every stage, so the parts are attributable (and no
+ * longer overlap); otherwise only out[7] is meaningful. */
+#define MI_LOAD_STAGES 8
+int mi_icp_load_times(mi_ctx* ctx, double out_ms[MI_LOAD_STAGES]);
 /* Work counters of the cell-grid search (MI_NN_GRID), summed over its launches while enabled: out[0] candidates tested in the
  * grid, out[1] cell rows scanned, out[2] moving points that went on to the box hierarchy, out[3] moving points searched, out[4]
  * hierarchy nodes and out[5] leaves visited by out[6] walking waves, out[7] nodes + leaves of the longest single walk (a
