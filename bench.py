@@ -14,8 +14,10 @@ libmislam.so over xGMI; torch.distributed (gloo) is only the bootstrap / barrier
 
 Rank 0 prints one JSON line.
   roofline        the search kernel of the timed steps: algorithmic bytes (20*N + 12*M_local) over its HIP-event-timed
-                  average launch; `issue` beside it is what actually bounds that kernel (vector-instruction issue), from the
-                  committed counter profile of this command
+                  average launch; `issue` beside it is the vector pipe's share of that kernel, from the committed counter profile of
+                  this command, CALIBRATED by the same counters read off a kernel of known instruction count (tools/valu_probe)
+  whole_call      one registration as the reference times it (host buffers in, allocation / upload / index builds / 50 iterations /
+                  result included: testrunner.cpp:54-56) at 1e5 and 1e6 points, with the load split into its stages
   sizes           the same measurement at N = M = 1e4, 1e5, 1e7 (BASELINE.json: "N = 10^4 ... 10^7"), a few steps each
   bruteforce_nn   the every-pair kernel on the same clouds with `valu`, its launch against the fp32 vector-issue rate
   target_sharded  N > 1 only: cfg 3's split -- fixed cloud sharded, every-pair search, ncclAllReduce(u64, min) of the keys
@@ -26,6 +28,7 @@ Rank 0 prints one JSON line.
 """
 import argparse
 import glob
+import hashlib
 import json
 import os
 import sys
@@ -54,18 +57,43 @@ def synth_cloud(np, n, seed=666):
     return before, after
 
 
+def search_source_hash():
+    """Hash of the search kernel's sources: a committed counter profile speaks for THIS code only if it carries the same one."""
+    h = hashlib.sha256()
+    for f in ("nn_grid.hip", "nn_grid.h", "nn_walk.hpp", "icp_rows.hpp"):
+        h.update(open(os.path.join(ROOT, "cuda-slam_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def committed_profile(workload, kernel, steps, warmup):
     """The committed rocprofv3 --pmc summary (profiles/*_counters.json) for this workload and kernel, and whether it was taken
-    with THIS run's --steps / --warmup (the search's cost depends on which iterations are timed).  bench.py cannot run counter
-    passes itself: they need their own rocprofv3 runs (tools/gpu_suite_and_profiles.sh)."""
+    with THIS run's --steps / --warmup (the search's cost depends on which iterations are timed) on THIS code (source hash of
+    the search kernel).  bench.py cannot run counter passes itself: they need their own rocprofv3 runs (tools/gpu_profiles_r03.sh)."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
             continue
         if d.get("workload") == workload and d.get("kernel") == kernel:
-            return d, os.path.relpath(path, ROOT), (d.get("steps") == steps and d.get("warmup") == warmup)
+            same = d.get("steps") == steps and d.get("warmup") == warmup
+            if "source_hash" in d and kernel == "nn_grid_kernel":
+                same = same and d["source_hash"] == search_source_hash()
+            return d, os.path.relpath(path, ROOT), same
     return None, None, False
+
+
+def valu_calibration():
+    """profiles/*_valu_calibration.json: the SQ counters of tools/valu_probe (v_fma_f32 only, 8 waves per SIMD) -- the practical vector
+    issue rate of this chip and what the busy counters read when the pipe is saturated."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_calibration.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            k = d["kernels"]["valu_probe<0>"]
+            if k.get("wave_instructions_per_s") and k.get("valu_busy_quadcycles_per_gui_cycle"):
+                return d, os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline(np, before, after, target_seconds=15.0):
@@ -137,6 +165,15 @@ def cpd_bunny(np, capi, ctx, world):
     before, after = z["before"], z["after"]
     pairs = float(len(before)) * len(after)
     out = {"workload": "cpd_bunny_14904", "n_gpus": world}
+    if world == 1:
+        # the initial sigma^2 on its own, both ways (the legs below start from cpu-slam's value handed in, so neither is inside them)
+        for label, mode in (("sigma2_exact", capi.SIGMA2_EXACT), ("sigma2_cpu_sequential", capi.SIGMA2_CPU_SEQUENTIAL)):
+            ctx.cpd_sigma_squared(before, after, mode)
+            t0 = time.perf_counter()
+            val = ctx.cpd_sigma_squared(before, after, mode)
+            out[label] = {"value": float(val), "ms": (time.perf_counter() - t0) * 1e3}
+        out["sigma2_cpu_sequential"]["note"] = ("cpu-slam's saturating sequential fp32 sum over all %.3g pairs, bit for bit (coherentpointdrift.cpp:126-139); "
+                                                "what a registration with sigma2_mode = MI_SIGMA2_CPU_SEQUENTIAL pays once, before its first E-step" % pairs)
     modes = [("exact", capi.CPD_APPROX_NONE)] + ([("hybrid", capi.CPD_APPROX_HYBRID)] if world == 1 else [])
     for label, approx in modes:
         p = capi.cpd_params(max_iterations=50, sigma2_init=g["sigma2_init"], approximation=approx)
@@ -158,18 +195,23 @@ def cpd_bunny(np, capi, ctx, world):
             den, con = prof["cpd_denom"], prof["cpd_contract"]
             if den[1] > 0:
                 leg["estep_pairs_per_s"] = pairs / world / (den[0] / den[1] * 1e-3)   # K7a: this rank's share of the N*M affinities
-            # roofline of the E-step (K7a + K7b: the affinity is evaluated twice, P is never stored): fp32 vector issue.  Lane
-            # operations per pair are MEASURED (SQ_INSTS_VALU of the committed counter profile / pairs), not estimated.
+            # roofline of the E-step (K7a + K7b: the affinity is evaluated twice, P is never stored): vector-pipe busy time of the two
+            # kernels from the committed counter profile, over what the same counters read on a saturated pipe (tools/valu_probe)
             prof_c, src, _ = committed_profile("cpd_bunny_14904", "cpd_estep", None, None)
-            if prof_c is not None and den[1] > 0 and con[1] > 0 and world == 1:
-                ops = prof_c["valu_lane_ops_per_pair_both_passes"]
-                t_estep = (den[0] / den[1] + con[0] / con[1]) * 1e-3
-                achieved = pairs * ops / t_estep                         # lane-operations/s
-                leg["roofline"] = {"bound": "fp32-valu-issue", "achieved": achieved, "peak": VALU_LANE_OPS_PEAK, "unit": "lane-ops/s",
-                                   "frac": achieved / VALU_LANE_OPS_PEAK, "ops_per_pair": ops, "ops_per_pair_source": src,
-                                   "kernels": "cpd_denominator_kernel + cpd_contract_mfma_kernel",
-                                   "note": "vector lane-operations per (x, y_k) pair over both passes, MEASURED (SQ_INSTS_VALU x 64 / pairs); "
-                                           "the 4 FMAs per pair of the contraction run on the matrix pipe (MFMA 4x4x1) and are not in it"}
+            cal, cal_src = valu_calibration()
+            if prof_c is not None and cal is not None and "kernels" in prof_c and world == 1:
+                sat = cal["kernels"]["valu_probe<0>"]["valu_busy_quadcycles_per_gui_cycle"]
+                ks = {k: v for k, v in prof_c["kernels"].items() if v.get("valu_busy_quadcycles_per_gui_cycle") and v.get("launch_ms")}
+                if ks:
+                    t_all = sum(v["launch_ms"] for v in ks.values())
+                    busy = sum(v["valu_busy_quadcycles_per_gui_cycle"] * v["launch_ms"] for v in ks.values()) / t_all
+                    leg["roofline"] = {"bound": "fp32-valu-issue", "achieved": busy, "peak": sat, "unit": "vector-pipe busy quad-cycles per GPU cycle",
+                                       "frac": busy / sat, "calibration_source": cal_src, "source": src,
+                                       "kernels": {k: {"launch_ms": v["launch_ms"], "frac": v["valu_busy_quadcycles_per_gui_cycle"] / sat,
+                                                       "valu_instructions_per_pair": v["SQ_INSTS_VALU"] * 64.0 / pairs if v.get("SQ_INSTS_VALU") else None}
+                                                   for k, v in ks.items()},
+                                       "note": "time-weighted over the two E-step kernels; packed instructions count by the time they hold the pipe, not as one; "
+                                               "the contraction's 4 FMAs per pair run on the matrix pipe (MFMA 4x4x1) when that form is selected"}
         out[label] = leg
     return out
 
@@ -185,6 +227,7 @@ def main():
     ap.add_argument("--dist-mode", type=int, default=0, help="0 = cpu-slam rounding (parity default), 1 = fma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sizes", action="store_true", help="skip the N = 1e4 / 1e5 / 1e7 legs")
+    ap.add_argument("--no-whole-call", action="store_true", help="skip the whole-registration legs (host buffers in, 50 iterations)")
     ap.add_argument("--shard", choices=["auto", "target", "source"], default="auto",
                     help="what N > 1 GPUs split: auto = moving cloud for the indexed searches, fixed cloud for the every-pair search")
     ap.add_argument("--brute-ref-steps", type=int, default=2,
@@ -303,7 +346,9 @@ def main():
     n, m = len(before), len(after)
     pl = plan(n, m, args.nn, args.shard)
     # eps = 0: the device-side stop rule is evaluated every step and never fires -> every step is a full iteration
-    params = capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=nn_mode, shard_mode=shard_mode)
+    # sync_every = steps: the host looks at the state once, after the timed steps (the stop rule itself runs on the device every
+    # step) -- the headline does not depend on the library's batch heuristic
+    params = capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=nn_mode, shard_mode=shard_mode, sync_every=max(args.steps, 1))
     elapsed, nn_prof = timed_run(before, after, params, args.warmup, args.steps)
     R, t, iters, err, why = ctx.icp_result()
     # per-kernel breakdown of a step: a few more (untimed) iterations with events around every kernel
@@ -385,6 +430,11 @@ def main():
     if world == 1 or os.environ.get("MISLAM_BENCH_CPD") == "1":
         cpd = cpd_bunny(np, capi, ctx, world)
 
+    # Outside the timed region too: whole registrations on host buffers, as the reference times a SlamFunc
+    whole = None
+    if world == 1 and not args.no_whole_call:
+        whole = {str(wn): whole_call(np, capi, ctx, wn) for wn in (100000, 1000000)}
+
     if rank == 0:
         workload = "icp_synthetic_uniform_n%d" % n
         roof = nn_figures(pl, nn_prof[0], nn_prof[1])
@@ -401,12 +451,22 @@ def main():
                 roof[key] = prof_c.get("traffic_bytes_per_launch")
                 roof["traffic_source"] = src + (" (rocprofv3 --pmc passes of this same command, means per launch; not measured by this run)"
                                                 if same_cmd else " (taken with --steps %s --warmup %s)" % (prof_c.get("steps"), prof_c.get("warmup")))
-                if "valu_wave_instructions_per_launch" in prof_c:
+                cal, cal_src = valu_calibration()
+                if cal is not None and prof_c.get("valu_busy_quadcycles_per_gui_cycle"):
+                    # ONE number: the vector pipe's busy time in this kernel over what the same counters read on a kernel that only
+                    # issues vector instructions at 8 waves per SIMD (packed instructions weigh by the time they hold the pipe)
+                    probe = cal["kernels"]["valu_probe<0>"]
+                    sat = probe["valu_busy_quadcycles_per_gui_cycle"]
                     rate = prof_c["valu_wave_instructions_per_launch"] / (prof_c["avg_launch_ms"] * 1e-3)
-                    roof["issue"] = {"bound": "valu-issue", "achieved": rate, "peak": VALU_WAVE_INSTR_PEAK, "unit": "wave-instructions/s",
-                                     "frac": rate / VALU_WAVE_INSTR_PEAK, "lanes_active_of_64": prof_c.get("lanes_active_of_64"),
+                    roof["issue"] = {"bound": "valu-issue", "achieved": prof_c["valu_busy_quadcycles_per_gui_cycle"], "peak": sat,
+                                     "unit": "vector-pipe busy quad-cycles per GPU cycle", "frac": prof_c["valu_busy_quadcycles_per_gui_cycle"] / sat,
+                                     "calibration_source": cal_src, "same_code_as_profile": same_cmd,
+                                     "wave_instructions_per_s": rate, "probe_wave_instructions_per_s": probe["wave_instructions_per_s"],
+                                     "instruction_rate_over_probe": rate / probe["wave_instructions_per_s"],
+                                     "valu_instructions_per_wave": prof_c.get("valu_instructions_per_wave"),
+                                     "lanes_active_of_64": prof_c.get("lanes_active_of_64"),
                                      "l1_line_accesses_per_launch": prof_c.get("tcp_total_cache_accesses_per_launch"),
-                                     "source": src + ": SQ_INSTS_VALU per launch over that profile's own average launch time"}
+                                     "source": src}
         out = {
             "metric": "icp_iterations_per_s", "value": args.steps / elapsed, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -426,6 +486,8 @@ def main():
         }
         if use_dist and rehearsal_transport == "gloo":
             out["rehearsal"] = "ranks share device %d over the gloo exchange context: flow check only, not a measurement" % local_rank
+        if whole is not None:
+            out["whole_call"] = whole
         if sizes is not None:
             out["sizes"] = sizes
         if brute_fig is not None:

@@ -49,6 +49,7 @@ struct CpdWorkspace {
     DevBuf<float> den_part, pt1, p1_part, px_part, p1, px;
     DevBuf<float4> xw4;
     DevBuf<double> part_x, part_k, part_init;
+    DevBuf<unsigned char> sig_scratch;   // cpd_sigma2_sequential
     CpdState* d_state = nullptr;
     CpdState* h_state = nullptr;
     int m = 0, n = 0, m_pad = 0, n_pad = 0;   // n = this rank's share of the fixed cloud
@@ -211,7 +212,8 @@ static int cpd_init(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const CpdRules
     const int seq = sigma2_mode == MI_SIGMA2_CPU_SEQUENTIAL && !(sigma2_override > 0.f);
     if (seq) {
         if (c->distributed()) { set_error("CPD: MI_SIGMA2_CPU_SEQUENTIAL needs a single-GPU context (one running sum over all pairs)"); return MI_ERR_INVALID_ARG; }
-        MI_HIP(cpd_sigma2_sequential(v, c->stream));
+        MI_TRY(w->sig_scratch.reserve(cpd_sigma2_scratch_bytes()));
+        MI_HIP(cpd_sigma2_sequential(v, c->stream, w->sig_scratch.p, (int*)c->h_scratch));
     }
     if (!c->distributed()) {
         MI_HIP(cpd_init_state(w->d_state, w->part_init.p, nb, rules, sigma2_override, seq, c->stream));

@@ -69,8 +69,10 @@ hipError_t cpd_init_sums(const CpdView& v, double* partials, int nblocks, hipStr
 hipError_t cpd_init_state(CpdState* state, const double* partials, int nblocks, const CpdRules& rules, float sigma2_override,
                           int sigma2_from_state, hipStream_t s);
 // cpu-slam's own sigma^2_0 bit for bit (coherentpointdrift.cpp:126-139): ONE sequential fp32 running sum over all m*n squared
-// distances, before-major -- into state->sigma2_init.  One wave; ~8 cycles per term (0.7 s for the bunny clouds).
-hipError_t cpd_sigma2_sequential(const CpdView& v, hipStream_t s);
+// distances, before-major -- into state->sigma2_init.  Computed binade by binade as integer prefix sums (cpd_kernels.hip); drains
+// the stream a few dozen times.  scratch: cpd_sigma2_scratch_bytes() of device memory; host_pinned: pinned host memory for two ints.
+size_t cpd_sigma2_scratch_bytes();
+hipError_t cpd_sigma2_sequential(const CpdView& v, hipStream_t s, void* scratch, int* host_pinned);
 hipError_t cpd_denominators(const CpdView& v, hipStream_t s);                                  // K7a
 // (xpartials / kpartials != null: the post kernels also leave the M-step's x-sums / k-sums, as cpd_xsums / cpd_ksums would, in nblocks rows)
 hipError_t cpd_post_denominators(const CpdView& v, hipStream_t s, double* xpartials = nullptr, int nblocks = 0);                             //   den, w, Pt1, xw4

@@ -79,26 +79,109 @@ __global__ __launch_bounds__(256) void cpd_init_sums_kernel(CpdView v, double* _
 
 // CalculateSigmaSquared of cpu-slam (coherentpointdrift.cpp:126-139): `sum += (before[i] - after[j]).LengthSquared()` over i, then
 // j, in ONE fp32 running sum that saturates once it dwarfs its terms (3.604 instead of 12.943 on the bunny clouds) -- and cpu-slam's
-// whole EM trajectory starts from that number.  A sequential fp32 sum cannot be re-associated, so it is retraced: one wave, 64
-// terms per step evaluated by the lanes, added one by one through v_readlane (a missing term adds +0.0f: no effect on a sum >= 0).
-__global__ __launch_bounds__(64) void cpd_sigma2_seq_kernel(CpdView v)
+// whole EM trajectory starts from that number.  A sequential fp32 sum cannot be re-associated; round 2 retraced it on one wave
+// (64 terms per step evaluated by the lanes, added one by one through v_readlane: 0.75 s for the bunny clouds' 2.2e8 terms).
+//
+// Round 3: the same sum, the same bits, in parallel.  While the running sum S stays inside one binade [2^e, 2^(e+1)) it is an
+// integer multiple s of U = ulp(S) = 2^(e-23), and adding a term t >= 0 gives fl(S + t) = (s + rne(t / U)) * U: t / U is exact (a
+// power-of-two scaling), the sum S + t is exact before rounding, and rounding to nearest-even at spacing U depends on t / U alone
+// -- except in an exact tie (t / U = k + 1/2), where the parity of s decides.  So within a binade the running sum is an INTEGER
+// prefix sum of q = rne(t / U), which any number of workgroups can compute in any order.  The terms are cut into blocks of
+// SIG_BLOCK; a window kernel leaves every block's sum of q and a tie flag; a scan finds the first block where the sum would leave
+// the binade (or that holds a tie) and the exact S in front of it; that one block is added the old way, term by term; then the
+// next window starts in the new binade.  A sum over 2.2e8 terms crosses ~30 binades: ~60 small launches instead of 0.75 s.
+constexpr int SIG_BLOCK = 4096;                 // terms per block: what is retraced one by one at a binade crossing or a tie
+constexpr int SIG_WINDOW_BLOCKS = 4096;         // blocks per window launch (16.8 M terms)
+
+__device__ __forceinline__ float sigma_term(const CpdView& v, long long g)
+{
+    const int i = (int)(g / v.n), j = (int)(g - (long long)i * v.n);
+    const float dx = v.bx[i] - v.ax[j], dy = v.by[i] - v.ay[j], dz = v.bz[i] - v.az[j];   // Point operator-, then x*x + y*y + z*z (point.h:49-51)
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+// terms [g0, g1) added to *acc one by one, in order (one wave)
+__global__ __launch_bounds__(64) void cpd_sigma2_seq_range_kernel(CpdView v, long long g0, long long g1, float* __restrict__ acc_io)
 {
     const int lane = threadIdx.x;
-    float acc = 0.f;
-    for (int i = 0; i < v.m; i++) {
-        const float bx = v.bx[i], by = v.by[i], bz = v.bz[i];
-        for (int j0 = 0; j0 < v.n; j0 += 64) {
-            const int j = j0 + lane;
-            float term = 0.f;
-            if (j < v.n) {
-                const float dx = bx - v.ax[j], dy = by - v.ay[j], dz = bz - v.az[j];   // Point operator-, then x*x + y*y + z*z (point.h:49-51)
-                term = (dx * dx + dy * dy) + dz * dz;
-            }
-            acc = seq_add64(acc, term);
+    float acc = *acc_io;
+    for (long long base = g0; base < g1; base += 64) {
+        const long long g = base + lane;
+        const float term = g < g1 ? sigma_term(v, g) : 0.f;      // a missing term adds +0.0f: no effect on a sum >= 0
+        acc = seq_add64(acc, term);
+    }
+    if (lane == 0) *acc_io = acc;
+}
+
+// per block of SIG_BLOCK terms from g0 on: sum of rne(t / ulp(S)) and "some t / ulp(S) is an exact tie"
+__global__ __launch_bounds__(256) void cpd_sigma2_window_kernel(CpdView v, long long g0, long long g1, const float* __restrict__ acc, double* __restrict__ blk_sum,
+                                                               int* __restrict__ blk_tie)
+{
+    __shared__ double lds[256];
+    __shared__ int tie_any;
+    const unsigned int sbits = __float_as_uint(*acc);
+    const int efield = (int)((sbits >> 23) & 0xffu);
+    // a sum that is zero, subnormal, not finite or negative has no binade to work in: every block is flagged and goes term by term
+    const bool no_binade = efield < 24 || efield > 250 || (sbits >> 31) != 0u;
+    const float inv_u = __uint_as_float((unsigned int)(no_binade ? 127 : 127 + 23 + 127 - efield) << 23);      // 2^(23 - e)
+    if (threadIdx.x == 0) tie_any = no_binade ? 1 : 0;
+    __syncthreads();
+    const long long b0 = g0 + (long long)blockIdx.x * SIG_BLOCK;
+    double q = 0.0;
+    bool tie = false;
+    for (int k = threadIdx.x; k < SIG_BLOCK; k += 256) {
+        const long long g = b0 + k;
+        if (g < g1) {
+            const float x = sigma_term(v, g) * inv_u;            // exact: a power-of-two scaling
+            const float r = rintf(x);                            // v_rndne_f32
+            tie = tie || fabsf(x - truncf(x)) == 0.5f;
+            q += (double)r;
         }
     }
+    if (tie) tie_any = 1;
+    lds[threadIdx.x] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {                          // sums of integers below 2^53: exact in any order
+        if ((int)threadIdx.x < w) lds[threadIdx.x] += lds[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { blk_sum[blockIdx.x] = lds[0]; blk_tie[blockIdx.x] = tie_any; }
+}
+
+// first block whose end would leave the binade of *acc, or that holds a tie -> out[0]; *acc advanced to the start of that block
+// (or past the whole window: out[0] = nblocks)
+__global__ __launch_bounds__(1024) void cpd_sigma2_scan_kernel(const double* __restrict__ blk_sum, const int* __restrict__ blk_tie, int nblocks,
+                                                               float* __restrict__ acc, int* __restrict__ out)
+{
+    __shared__ double pre[SIG_WINDOW_BLOCKS];
+    __shared__ int first_event;
+    const unsigned int sbits = __float_as_uint(*acc);
+    const int e = (int)((sbits >> 23) & 0xffu) - 127;
+    const double u = ldexp(1.0, e - 23), s0 = (double)*acc / u, limit = 16777216.0;        // s0 in [2^23, 2^24)
+    if (threadIdx.x == 0) first_event = nblocks;
+    for (int b = threadIdx.x; b < SIG_WINDOW_BLOCKS; b += 1024) pre[b] = b < nblocks ? blk_sum[b] : 0.0;
+    __syncthreads();
+    for (int off = 1; off < SIG_WINDOW_BLOCKS; off <<= 1) {      // inclusive prefix sums (exact: integers below 2^53)
+        double add[SIG_WINDOW_BLOCKS / 1024];
+        for (int k = 0; k < SIG_WINDOW_BLOCKS / 1024; k++) { const int b = threadIdx.x + 1024 * k; add[k] = b >= off ? pre[b - off] : 0.0; }
+        __syncthreads();
+        for (int k = 0; k < SIG_WINDOW_BLOCKS / 1024; k++) pre[threadIdx.x + 1024 * k] += add[k];
+        __syncthreads();
+    }
+    for (int b = threadIdx.x; b < nblocks; b += 1024)
+        if (blk_tie[b] != 0 || s0 + pre[b] >= limit) atomicMin(&first_event, b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int ev = first_event;
+        if (ev > 0) *acc = (float)((s0 + pre[ev - 1]) * u);      // s0 + prefix < 2^24: representable.  (ev == 0: the sum stands as it is)
+        out[0] = ev;
+    }
+}
+
+__global__ void cpd_sigma2_finish_kernel(CpdView v, const float* __restrict__ acc)
+{
     // sum /= (float)(DIMENSION * cloudBefore.size() * cloudAfter.size())   (:137: a size_t product, converted once)
-    if (lane == 0) v.state->sigma2_init = acc / (float)((size_t)3 * (size_t)v.m * (size_t)v.n);
+    if (threadIdx.x == 0) v.state->sigma2_init = *acc / (float)((size_t)3 * (size_t)v.m * (size_t)v.n);
 }
 
 __global__ __launch_bounds__(256) void cpd_init_state_kernel(CpdState* __restrict__ st, const double* __restrict__ partials, int nblocks,
@@ -495,9 +578,38 @@ hipError_t cpd_init_state(CpdState* state, const double* partials, int nblocks, 
     return hipGetLastError();
 }
 
-hipError_t cpd_sigma2_sequential(const CpdView& v, hipStream_t s)
+size_t cpd_sigma2_scratch_bytes() { return 64 + (size_t)SIG_WINDOW_BLOCKS * (sizeof(double) + sizeof(int)); }
+
+// scratch: cpd_sigma2_scratch_bytes() of device memory; host_pinned: two ints of pinned host memory
+hipError_t cpd_sigma2_sequential(const CpdView& v, hipStream_t s, void* scratch, int* host_pinned)
 {
-    hipLaunchKernelGGL(cpd_sigma2_seq_kernel, dim3(1), dim3(64), 0, s, v);
+    float* acc = (float*)scratch;                                // [0] the running sum
+    int* ev = (int*)scratch + 4;
+    double* blk_sum = (double*)((char*)scratch + 64);
+    int* blk_tie = (int*)(blk_sum + SIG_WINDOW_BLOCKS);
+    const long long total = (long long)v.m * (long long)v.n;
+    hipError_t e = hipMemsetAsync(scratch, 0, 64, s);
+    if (e != hipSuccess) return e;
+    long long pos = std::min<long long>(total, SIG_BLOCK);
+    hipLaunchKernelGGL(cpd_sigma2_seq_range_kernel, dim3(1), dim3(64), 0, s, v, 0ll, pos, acc);      // off zero, term by term
+    while (pos < total) {
+        const long long window = std::min<long long>(total - pos, (long long)SIG_WINDOW_BLOCKS * SIG_BLOCK);
+        const int nblocks = (int)((window + SIG_BLOCK - 1) / SIG_BLOCK);
+        // (a sum that is still zero, or not finite, has no binade: the window's flags then send every block through the sequential
+        //  kernel one after the other -- slow, correct, and only for degenerate inputs)
+        hipLaunchKernelGGL(cpd_sigma2_window_kernel, dim3(nblocks), dim3(256), 0, s, v, pos, pos + window, acc, blk_sum, blk_tie);
+        hipLaunchKernelGGL(cpd_sigma2_scan_kernel, dim3(1), dim3(1024), 0, s, blk_sum, blk_tie, nblocks, acc, ev);
+        if ((e = hipMemcpyAsync(host_pinned, ev, sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        const int first = host_pinned[0];
+        pos += std::min<long long>(window, (long long)first * SIG_BLOCK);
+        if (first < nblocks) {                                   // this block crosses into the next binade (or holds a tie): one by one
+            const long long end = std::min<long long>(total, pos + SIG_BLOCK);
+            hipLaunchKernelGGL(cpd_sigma2_seq_range_kernel, dim3(1), dim3(64), 0, s, v, pos, end, acc);
+            pos = end;
+        }
+    }
+    hipLaunchKernelGGL(cpd_sigma2_finish_kernel, dim3(1), dim3(64), 0, s, v, acc);
     return hipGetLastError();
 }
 

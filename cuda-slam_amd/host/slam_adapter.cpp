@@ -91,12 +91,12 @@ std::pair<Mat3, Vec3> GetCudaCpdTransformationMatrix(const std::vector<Point_f>&
     p.tolerance = tolerance;
     p.verbose = 1;   // cpdcuda.cu:357
     // the initial sigma^2 as cpu-slam (the parity target) computes it -- a saturating sequential fp32 sum,
-    // coherentpointdrift.cpp:126-139 -- up to the size at which retracing it costs about two seconds; MI355X_CPD_SIGMA=exact / =cpu
-    // forces either (same policy as integration/mi355x_adapters.cpp)
+    // coherentpointdrift.cpp:126-139 -- which the device computes in ~15 us per million pairs; MI355X_CPD_SIGMA=exact selects what
+    // cpdcuda.cu computes (same policy as integration/mi355x_adapters.cpp)
     {
         const char* mode = getenv("MI355X_CPD_SIGMA");
         const double pairs = (double)cloudBefore.size() * (double)cloudAfter.size();
-        p.sigma2_mode = (mode ? mode[0] == 'c' : pairs <= 6e8) ? MI_SIGMA2_CPU_SEQUENTIAL : MI_SIGMA2_EXACT;
+        p.sigma2_mode = (mode ? mode[0] == 'c' : pairs <= 4e9) ? MI_SIGMA2_CPU_SEQUENTIAL : MI_SIGMA2_EXACT;
     }
     float T[16];
     check(mi_cpd_register(context(), reinterpret_cast<const float*>(cloudBefore.data()), (int)cloudBefore.size(),

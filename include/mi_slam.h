@@ -260,8 +260,10 @@ typedef struct {
  *   CPU_SEQUENTIAL: cpu-slam's own arithmetic bit for bit -- ONE sequential fp32 running sum over all M*N squared distances, which
  *                   saturates once it dwarfs its terms (3.604 instead of 12.943 on the bunny clouds).  cpu-slam's whole EM
  *                   trajectory starts from that number, so this is the mode in which mi_cpd_register retraces cpu-slam without
- *                   being handed a constant.  A sequential sum cannot be re-associated: one wave, ~3.4 ns per pair (0.75 s for
- *                   the bunny clouds, once per registration); single-GPU contexts only. */
+ *                   being handed a constant.  A sequential sum cannot be re-associated, but inside one binade of the running sum
+ *                   it IS an integer prefix sum of rne(term / ulp): computed binade by binade over the whole GPU, the blocks
+ *                   at binade crossings and exact rounding ties term by term (cpd_kernels.hip) -- 3 ms for the bunny clouds'
+ *                   2.2e8 pairs (round 2's one-wave retrace: 750 ms), once per registration; single-GPU contexts only. */
 enum { MI_SIGMA2_EXACT = 0, MI_SIGMA2_CPU_SEQUENTIAL = 1 };
 
 /* "approximation-type" of the reference (common/enumerators.h:18-23, coherentpointdrift.cpp:141-167):

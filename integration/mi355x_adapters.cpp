@@ -56,12 +56,12 @@ std::pair<glm::mat3, glm::vec3> GetCudaCpdTransformationMatrix(
     p.fgt_order_of_truncation = (int)orderOfTruncation;
     // The initial sigma^2.  cpu-slam's is a sequential fp32 running sum that saturates (3.604 instead of 12.943 on bunny,
     // coherentpointdrift.cpp:126-139) and its whole trajectory starts there; cuda-slam's thrust reduction (cpdcuda.cu:65-78) gives
-    // roughly the exact value.  The parity target of this build is cpu-slam, so that is the default here, up to the size at which
-    // retracing the sequential sum costs about two seconds; MI355X_CPD_SIGMA=exact / =cpu forces either.
+    // roughly the exact value.  The parity target of this build is cpu-slam, so that is the default here (the device computes that
+    // very sum in ~3 ms for bunny-sized clouds, ~15 us per million pairs); MI355X_CPD_SIGMA=exact selects what cpdcuda.cu computes.
     {
         const char* mode = getenv("MI355X_CPD_SIGMA");
         const double pairs = (double)cloudBefore.size() * (double)cloudAfter.size();
-        const bool cpu = mode ? (mode[0] == 'c') : pairs <= 6e8;
+        const bool cpu = mode ? (mode[0] == 'c') : pairs <= 4e9;
         p.sigma2_mode = cpu ? MI_SIGMA2_CPU_SEQUENTIAL : MI_SIGMA2_EXACT;
     }
     glm::mat4 sRt;

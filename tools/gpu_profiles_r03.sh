@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-3 profiles of the driver's default bench command (python bench.py --steps 20 --warmup 5): rocprofv3 kernel-trace stats + the
+# rows of the TIMED dispatches, the --pmc passes (one per counter set, never mixed with tracing) for the search kernel, the every-pair
+# kernel and the CPD E-step kernels of the same run, and the same SQ counters on tools/valu_probe (kernels of a known instruction
+# count at 8 waves per SIMD) -- what bench.py's `issue` rooflines are calibrated by.
+#   gpurun -- 'bash tools/gpu_profiles_r03.sh'   ->   gpurun_out/r03_*  (copy the summaries into profiles/)
+mkdir -p gpurun_out; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+S=${STEPS:-20}; W=${WARMUP:-5}
+B="python3 bench.py --steps $S --warmup $W --no-cpu-baseline --no-sizes --no-whole-call"
+run() { d=gpurun_out/r03_$1; shift; rm -rf $d; timeout -k 10 500 rocprofv3 "$@" -d $d --output-format csv -- $B > $d.log 2>&1 || { tail -5 $d.log; exit 1; }; echo "pass $d done"; }
+probe() { d=gpurun_out/r03_$1; shift; rm -rf $d; timeout -k 10 200 rocprofv3 "$@" -d $d --output-format csv -- tools/valu_probe > $d.log 2>&1 || { tail -5 $d.log; exit 1; }; }
+SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU"
+SQ2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE"
+run stats --kernel-trace --stats
+run fetch --pmc FETCH_SIZE
+run write --pmc WRITE_SIZE
+run sq1 --pmc $SQ1
+run sq2 --pmc $SQ2
+run tcp --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum
+probe probe_trace --kernel-trace
+probe probe_sq1 --pmc $SQ1
+probe probe_sq2 --pmc $SQ2
+python3 tools/profiles_r03_reduce.py $S $W || exit 1
+find gpurun_out/r03_stats gpurun_out/r03_fetch gpurun_out/r03_write gpurun_out/r03_sq1 gpurun_out/r03_sq2 gpurun_out/r03_tcp gpurun_out/r03_probe_trace gpurun_out/r03_probe_sq1 gpurun_out/r03_probe_sq2 -type f -delete 2>/dev/null
+exit 0

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Reduces the rocprofv3 outputs of tools/gpu_profiles_r03.sh (gpurun_out/r03_<pass>/) to the summaries bench.py reads from profiles/:
+    r03_bench_n1e6_kernel_stats.csv             rocprofv3 --stats per-kernel summary of the whole command
+    r03_bench_n1e6_nn_grid_timed_dispatches.csv the kernel-trace rows of the TIMED launches of the search kernel (avg_launch_ms recomputable)
+    r03_bench_n1e6_nn_grid_counters.json        per-launch means of the counters over those launches + what produced them (git head, source hash)
+    r03_valu_calibration.json                   the same SQ counters on tools/valu_probe and on the every-pair kernel of the same run
+    r03_cpd_estep_counters.json                 the CPD E-step kernels of the same run
+"""
+import csv
+import glob
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+S, W = int(sys.argv[1]), int(sys.argv[2])
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def rows(d, pat):
+    out = []
+    for f in glob.glob(os.path.join(OUT, "r03_%s" % d, "**", "*%s" % pat), recursive=True):
+        out += list(csv.DictReader(open(f)))
+    return out
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for f in ("nn_grid.hip", "nn_grid.h", "nn_walk.hpp", "icp_rows.hpp"):
+        h.update(open(os.path.join(ROOT, "cuda-slam_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def counter_series(d, counter, kernel):
+    rs = [r for r in rows(d, "counter_collection.csv") if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    rs.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return [float(r["Counter_Value"]) for r in rs]
+
+
+def mean(v):
+    return sum(v) / len(v) if v else None
+
+
+SQ1 = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAVES", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"]
+SQ2 = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_SCA", "GRBM_GUI_ACTIVE"]
+SETS = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq1", SQ1), ("sq2", SQ2),
+        ("tcp", ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"]))
+
+# ---- kernel trace: per-kernel stats + the timed launches of the search kernel
+for f in glob.glob(os.path.join(OUT, "r03_stats", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(OUT, "r03_bench_n1e6_kernel_stats.csv"))
+tr = [r for r in rows("stats", "kernel_trace.csv") if "nn_grid_kernel" in r["Kernel_Name"]]
+tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+timed_rows = tr[W:W + S]
+with open(os.path.join(OUT, "r03_bench_n1e6_nn_grid_timed_dispatches.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["launch_of_this_kernel", "Dispatch_Id", "Kernel_Name", "Start_Timestamp", "End_Timestamp", "duration_ns"])
+    for k, r in enumerate(timed_rows):
+        w.writerow([W + k, r.get("Dispatch_Id", ""), r["Kernel_Name"][:60], r["Start_Timestamp"], r["End_Timestamp"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
+timed = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in timed_rows]
+
+
+def timed_mean(d, counter):
+    return mean(counter_series(d, counter, "nn_grid_kernel")[W:W + S])
+
+
+c = {k: timed_mean(d, k) for d, ks in SETS for k in ks}
+try:
+    head = subprocess.check_output(["git", "rev-parse", "HEAD"], cwd=ROOT, stderr=subprocess.DEVNULL).decode().strip()
+except Exception:
+    head = None
+doc = {
+    "workload": "icp_synthetic_uniform_n1000000", "kernel": "nn_grid_kernel", "steps": S, "warmup": W,
+    "git_head": head, "source_hash": source_hash(),
+    "command": "rocprofv3 --pmc <one pass per counter set> -- python3 bench.py --steps %d --warmup %d --no-cpu-baseline --no-sizes --no-whole-call; "
+               "means over the %d TIMED launches of the search kernel (launches %d..%d of it)" % (S, W, S, W, W + S - 1),
+    "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE / WRITE_SIZE are in KB; gfx950 FETCH_SIZE counts 64 B per 128 B request, so x2 on the read side",
+    "avg_launch_ms": mean(timed), "avg_launch_ms_source": "r03_bench_n1e6_nn_grid_timed_dispatches.csv (rocprofv3 --kernel-trace of the same command, same launches)",
+    "traffic_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
+    "algorithmic_bytes_per_launch": 32000000,
+    "valu_wave_instructions_per_launch": c["SQ_INSTS_VALU"],
+    "valu_instructions_per_wave": c["SQ_INSTS_VALU"] / c["SQ_WAVES"],
+    "valu_busy_quadcycles_per_gui_cycle": c["SQ_ACTIVE_INST_VALU"] / c["GRBM_GUI_ACTIVE"],
+    "lanes_active_of_64": c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"],
+    "tcp_total_cache_accesses_per_launch": c["TCP_TOTAL_CACHE_ACCESSES_sum"],
+    "wait_any_over_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+    "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
+    "per_launch_mean": c,
+}
+json.dump(doc, open(os.path.join(OUT, "r03_bench_n1e6_nn_grid_counters.json"), "w"), indent=1)
+print(json.dumps({k: doc[k] for k in ("avg_launch_ms", "traffic_bytes_per_launch", "valu_wave_instructions_per_launch", "valu_instructions_per_wave",
+                                      "lanes_active_of_64", "wait_any_over_wave_cycles", "l2_hit_rate")}))
+
+# ---- calibration: the probe kernels (known instruction count, 8 waves per SIMD) and the every-pair kernel under the same counters
+cal = {"command": "rocprofv3 --pmc <SQ sets> -- tools/valu_probe (and the nn_bruteforce_kernel launches of the bench command above)",
+       "note": "SQ_ACTIVE_INST_VALU counts quad-cycles in which a wave has a vector instruction executing, summed over waves; GRBM_GUI_ACTIVE is "
+               "summed over the 8 XCDs.  Their ratio on a kernel that only issues vector instructions at 8 waves per SIMD is what `saturated` "
+               "means for that ratio; a kernel's `issue.frac` is its own ratio over that one.", "kernels": {}}
+ptr = rows("probe_trace", "kernel_trace.csv")
+for name, key in (("valu_probe<0>", "valu_probeILi0"), ("valu_probe<1>", "valu_probeILi1")):
+    dur = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ptr if key in r["Kernel_Name"] or name in r["Kernel_Name"])
+    e = {"what": "v_fma_f32 x 8 chains" if name.endswith("<0>") else "v_pk_fma_f32 x 8 chains", "launch_ms": dur[-1] * 1e-6 if dur else None}
+    for d, ks in (("probe_sq1", SQ1), ("probe_sq2", SQ2)):
+        for k in ks:
+            v = counter_series(d, k, "valu_probe") if False else [float(r["Counter_Value"]) for r in rows(d, "counter_collection.csv")
+                                                                   if (key in r["Kernel_Name"] or name in r["Kernel_Name"]) and r["Counter_Name"] == k]
+            e[k] = max(v) if v else None                      # the long launch of the two (the short one is the warm-up)
+    if e.get("SQ_INSTS_VALU") and e["launch_ms"]:
+        e["wave_instructions_per_s"] = e["SQ_INSTS_VALU"] / (e["launch_ms"] * 1e-3)
+        e["valu_busy_quadcycles_per_gui_cycle"] = e["SQ_ACTIVE_INST_VALU"] / e["GRBM_GUI_ACTIVE"]
+    cal["kernels"][name] = e
+bf = {k: mean(counter_series(d, k, "nn_bruteforce_kernel")) for d, ks in (("sq1", SQ1), ("sq2", SQ2)) for k in ks}
+bft = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows("stats", "kernel_trace.csv") if "nn_bruteforce_kernel" in r["Kernel_Name"]]
+if bf.get("SQ_INSTS_VALU") and bft:
+    bf["launch_ms"] = mean(bft) * 1e-6
+    bf["wave_instructions_per_s"] = bf["SQ_INSTS_VALU"] / (bf["launch_ms"] * 1e-3)
+    bf["valu_busy_quadcycles_per_gui_cycle"] = bf["SQ_ACTIVE_INST_VALU"] / bf["GRBM_GUI_ACTIVE"]
+cal["kernels"]["nn_bruteforce_kernel"] = bf
+json.dump(cal, open(os.path.join(OUT, "r03_valu_calibration.json"), "w"), indent=1)
+print(json.dumps({k: {kk: v.get(kk) for kk in ("wave_instructions_per_s", "valu_busy_quadcycles_per_gui_cycle")} for k, v in cal["kernels"].items()}))
+
+# ---- CPD E-step kernels of the same run
+pairs = 14904.0 * 14904.0
+cpd = {"workload": "cpd_bunny_14904", "kernel": "cpd_estep", "steps": None, "warmup": None, "git_head": head,
+       "command": doc["command"].split(";")[0] + " (its cpd_bunny leg: exact P)", "pairs_per_launch": pairs, "kernels": {}}
+names = sorted({r["Kernel_Name"] for r in rows("sq1", "counter_collection.csv") if "cpd_denominator_kernel" in r["Kernel_Name"] or "cpd_contract" in r["Kernel_Name"]})
+for kn in names:
+    e = {k: mean(counter_series(d, k, kn)) for d, ks in (("sq1", SQ1), ("sq2", SQ2)) for k in ks}
+    t = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows("stats", "kernel_trace.csv") if r["Kernel_Name"] == kn]
+    e["launches"] = len(t)
+    e["launch_ms"] = mean(t) * 1e-6 if t else None
+    if e.get("SQ_ACTIVE_INST_VALU") and e.get("GRBM_GUI_ACTIVE"):
+        e["valu_busy_quadcycles_per_gui_cycle"] = e["SQ_ACTIVE_INST_VALU"] / e["GRBM_GUI_ACTIVE"]
+    cpd["kernels"][kn.split("(")[0][-60:]] = e
+json.dump(cpd, open(os.path.join(OUT, "r03_cpd_estep_counters.json"), "w"), indent=1)
+print(json.dumps({k: v.get("valu_busy_quadcycles_per_gui_cycle") for k, v in cpd["kernels"].items()}))
