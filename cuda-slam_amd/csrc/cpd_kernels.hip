@@ -370,9 +370,36 @@ __global__ __launch_bounds__(256) void cpd_contract_mfma_kernel(CpdView v)
     const int x_begin = chunk * v.x_chunk_len;
     const int x_end = min(x_begin + v.x_chunk_len, v.n);
     const float* __restrict__ wrec = reinterpret_cast<const float*>(v.xw4);
-    // R moving points per lane share each fixed point's scalar loads and its operand load
-    // (the compiler already pipelines this loop; hand-blocking it by CPD_T with the operand loads hoisted measured 5 % slower)
-    for (int x = x_begin; x < x_end; x++) {
+    // R moving points per lane share each fixed point's scalar loads and its operand load.  Blocks of CPD_T fixed points: their
+    // coordinates arrive as batched scalar loads, their CPD_T operand words are requested together, and the R * CPD_T matrix
+    // instructions of a block go into R independent accumulators -- the affinity arithmetic of point r + 1 runs while the matrix
+    // pipe applies point r's update.
+    // (the NEXT block's coordinates and operand words are requested before the current block is worked on: a block's loads then
+    //  have a whole block of arithmetic to arrive in, instead of being waited for where they are issued)
+    int x = x_begin;
+    float cax[CPD_T], cay[CPD_T], caz[CPD_T], cb[CPD_T];
+    const int n_blocks = (x_end - x_begin) / CPD_T;
+    if (n_blocks > 0) {
+#pragma unroll
+        for (int u = 0; u < CPD_T; u++) { cax[u] = v.ax[x + u]; cay[u] = v.ay[x + u]; caz[u] = v.az[x + u]; cb[u] = wrec[4 * (size_t)(x + u) + (lane & 3)]; }
+    }
+    for (int blk = 0; blk < n_blocks; blk++, x += CPD_T) {
+        float nax[CPD_T], nay[CPD_T], naz[CPD_T], nb[CPD_T];
+        const int xn = blk + 1 < n_blocks ? x + CPD_T : x;           // (the last block requests itself again: no branch in the loop)
+#pragma unroll
+        for (int u = 0; u < CPD_T; u++) { nax[u] = v.ax[xn + u]; nay[u] = v.ay[xn + u]; naz[u] = v.az[xn + u]; nb[u] = wrec[4 * (size_t)(xn + u) + (lane & 3)]; }
+#pragma unroll
+        for (int u = 0; u < CPD_T; u++) {
+            float p[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) p[r] = affinity<TRUNC>(mult * sq_dist(cax[u], cay[u], caz[u], yx[r], yy[r], yz[r]), v.trunc_log);
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(p[r], cb[u], acc[r], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < CPD_T; u++) { cax[u] = nax[u]; cay[u] = nay[u]; caz[u] = naz[u]; cb[u] = nb[u]; }
+    }
+    for (; x < x_end; x++) {
         const float ax = v.ax[x], ay = v.ay[x], az = v.az[x];
         const float b = wrec[4 * (size_t)x + (lane & 3)];
 #pragma unroll
@@ -562,7 +589,13 @@ __global__ __launch_bounds__(256) void cpd_transform_kernel(CpdView v, int m_pad
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int CPD_RA = 4;   // fixed points per lane in K7a (measured on the bunny clouds: 0.073 ms against 0.081 with 2)
-constexpr int CPD_RM = 1;   // moving points per lane in the MFMA form of K7b (2: 0.136 against 0.105 ms on the bunny clouds)
+// moving points per lane in the MFMA form of K7b.  Measured on the bunny clouds / 60 000^2 (profiles/r03_cpd_bench.log; ms per launch,
+// each form on its own context -- the switch is read once, at context creation): 1: 0.112 / 1.68, 2: 0.122 / 1.78, 4: 0.134 / 1.96;
+// the VALU form 0.124 / 1.93
+#ifndef MISLAM_CPD_RM
+#define MISLAM_CPD_RM 1
+#endif
+constexpr int CPD_RM = MISLAM_CPD_RM;
 constexpr int CPD_RB = 2;   // moving points per lane in the VALU form of K7b (4: 0.124 against 0.116 ms)
 
 hipError_t cpd_init_sums(const CpdView& v, double* partials, int nblocks, hipStream_t s)

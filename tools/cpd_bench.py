@@ -24,10 +24,13 @@ def main():
         b = rng.uniform(-5, 5, (60000, 3)).astype(np.float32)
         a = (b[rng.permutation(60000)] + 0.3).astype(np.float32)
         cases.append(("synthetic_60000", b, a, 0.0))
-    ctx = capi.Context(0)
+    ctx = None
     for name, before, after, s2 in cases:
         for mfma in ("1", "0"):
-            os.environ["MISLAM_CPD_MFMA"] = mfma
+            os.environ["MISLAM_CPD_MFMA"] = mfma               # (read once, at context creation)
+            if ctx is not None:
+                ctx.close()
+            ctx = capi.Context(0)
             p = capi.cpd_params(max_iterations=50, const_scale=0, sigma2_init=s2)
             ctx.cpd_register(before, after, p)          # warm-up (allocations, code load)
             ctx.profile_enable(True)
@@ -48,7 +51,9 @@ def main():
                               "K7a_pairs_per_s": pairs / (den_ms * 1e-3), "K7b_pairs_per_s": pairs / (con_ms * 1e-3),
                               "t": [float(x) for x in t], "sigma2": err}), flush=True)
         # the reference's approximate modes (K9: FGT E-step on the device), same clouds
-        os.environ["MISLAM_CPD_MFMA"] = "1"
+        os.environ.pop("MISLAM_CPD_MFMA", None)
+        ctx.close()
+        ctx = capi.Context(0)
         for approx, label in ((capi.CPD_APPROX_HYBRID, "hybrid"), (capi.CPD_APPROX_FULL, "full")):
             p = capi.cpd_params(max_iterations=50 if label == "hybrid" else 17, const_scale=0, sigma2_init=s2, approximation=approx)
             ctx.cpd_register(before, after, p)
