@@ -33,7 +33,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int) 
 EXPORTS = [
     "mi_abi_version", "mi_last_error", "mi_device_count", "mi_ctx_create", "mi_dist_unique_id", "mi_ctx_create_dist",
     "mi_ctx_create_exchange", "mi_ctx_preload", "mi_ctx_rank", "mi_dist_info", "mi_shard_range", "mi_source_share", "mi_pack_key", "mi_unpack_key", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_icp_params_default", "mi_icp_params_cuda_slam",
-    "mi_icp_register", "mi_icp_load", "mi_icp_reset", "mi_icp_run", "mi_icp_result", "mi_nn_search", "mi_nn_search_ex", "mi_kabsch",
+    "mi_icp_register", "mi_icp_load", "mi_icp_reset", "mi_icp_run", "mi_icp_auto_batch", "mi_icp_result", "mi_nn_search", "mi_nn_search_ex", "mi_cross_moments", "mi_kabsch",
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_sigma_squared_mode", "mi_cpd_estep",
     "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
     "mi_prepare_params_default", "mi_prepare_cloud",
@@ -164,6 +164,13 @@ def shard_range(m_total, rank, world):
     lo, hi = C.c_int(0), C.c_int(0)
     _check(lib().mi_shard_range(m_total, rank, world, C.byref(lo), C.byref(hi)))
     return lo.value, hi.value
+
+
+def icp_auto_batch(n_moving_total, m_fixed_total, world, source_sharded, every_pair_search):
+    """Iterations mi_icp_run enqueues between host checks with sync_every = 0: a function of global sizes only."""
+    f = lib().mi_icp_auto_batch
+    f.argtypes = [C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_int]
+    return int(f(n_moving_total, m_fixed_total, world, 1 if source_sharded else 0, 1 if every_pair_search else 0))
 
 
 def source_share(n_total, rank, world):
@@ -306,6 +313,18 @@ class Context:
         _check(lib().mi_kabsch(self._h, _fp(src), src.shape[0], _fp(tgt), tgt.shape[0], idx.ctypes.data_as(_i), kp, R9, t3,
                                C.byref(used)))
         return np.array(R9, np.float32).reshape(3, 3).T.copy(), np.array(t3, np.float32), used.value
+
+    def cross_moments(self, src, tgt, idx, keep=None):
+        """{pairs, sum src, sum tgt, sum tgt_r src_c} over the kept pairs (src[i], tgt[idx[i]]), fp64."""
+        src, tgt = _cloud(src), _cloud(tgt)
+        idx = np.ascontiguousarray(idx, np.int32)
+        kp = None
+        if keep is not None:
+            keep = np.ascontiguousarray(keep, np.uint8)
+            kp = keep.ctypes.data_as(_u8)
+        out = (C.c_double * 16)()
+        _check(lib().mi_cross_moments(self._h, _fp(src), src.shape[0], _fp(tgt), tgt.shape[0], idx.ctypes.data_as(_i), kp, out))
+        return np.array(out, np.float64)
 
     def transform_mse(self, src, R, t, tgt=None, idx=None, keep=None, divide_by_pairs=True, want_cloud=True):
         src = _cloud(src)

@@ -130,7 +130,7 @@ struct mi_ctx {
     mislam::DevBuf<double> part_mom, part_err;           // per-workgroup partial sums of the NICP / CPD drivers
     mislam::DevBuf<int> sched_order, sched_counters;     // work order of the fused search (IcpSchedule)
     mislam::DevBuf<unsigned char> sched_far;
-    mislam::DevBuf<double> rows, rows_reduced;           // ICP: one row of 18 sums per 128 moving points (icp_rows.hpp), and <= 64 reduced rows
+    mislam::DevBuf<double> rows, rows_reduced;           // ICP: one row of 18 sums per 64 moving points (icp_rows.hpp), and <= 64 reduced rows
     mislam::DevBuf<int> idx_tmp;
     mislam::DevBuf<unsigned char> keep_tmp;
     mislam::IcpState* d_state = nullptr;

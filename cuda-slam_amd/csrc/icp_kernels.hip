@@ -17,7 +17,7 @@
 //
 // Since round 2 the default (cell-grid) search carries K2 and K4+K5 itself (nn_grid.hip: the fused iteration); the stand-alone
 // kernels below serve the every-pair search, the multi-GPU split of the fixed cloud, MI_SUM_CPU_SEQUENTIAL and the test-grade
-// primitives.  Either way an iteration's sums are "rows" (icp_rows.hpp): one row of 18 partial sums per 128 moving points, added
+// primitives.  Either way an iteration's sums are "rows" (icp_rows.hpp): one row of 18 partial sums per 64 moving points, added
 // in one fixed tree -- so every strategy yields the same bits -- then icp_rows_reduce (<= 64 workgroups) and the solve kernel
 // sum the rows in index order.  No float atomics: results are bitwise reproducible run to run.
 // The stop rule of iteration i is evaluated at the START of the solve kernel of iteration i+1 (its error sums ride in the same

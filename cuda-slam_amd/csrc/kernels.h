@@ -102,7 +102,7 @@ hipError_t unpack_keys(const unsigned long long* keys, const int* order, int n, 
 hipError_t pack_keys(const int* idx, const unsigned char* keep, int n, unsigned long long* keys, hipStream_t s);
 
 int icp_reduce_blocks(int n);
-// An iteration's sums are "rows" (icp_rows.hpp): one row of 18 partial sums -- 16 moments, 2 error sums -- per 128 moving points,
+// An iteration's sums are "rows" (icp_rows.hpp): one row of 18 partial sums -- 16 moments, 2 error sums -- per 64 moving points,
 // whichever kernel produced them (the fused search of nn_grid.hip, or the two stand-alone kernels below).
 int icp_row_count(int n);                  // rows of a cloud of n points
 int icp_reduced_count(int nrows);          // rows left after icp_rows_reduce (<= 64)

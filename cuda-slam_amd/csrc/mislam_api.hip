@@ -1075,6 +1075,15 @@ static int icp_fetch_state(mi_ctx* c)
     return MI_OK;
 }
 
+extern "C" int mi_icp_auto_batch(long long n_moving_total, long long m_fixed_total, int world, int source_sharded, int every_pair_search)
+{
+    if (world < 1) world = 1;
+    const double n_rank = (double)n_moving_total / world, m_rank = (double)m_fixed_total / world;
+    const double est_s = every_pair_search ? (source_sharded ? n_rank * (double)m_fixed_total : (double)n_moving_total * m_rank) / 7e12
+                                           : 2e-5 + 5e-11 * (source_sharded ? n_rank : (double)n_moving_total);
+    return est_s >= 5e-3 ? 1 : (est_s >= 2e-4 ? 4 : (est_s >= 1e-4 ? 8 : 16));
+}
+
 extern "C" int mi_icp_run(mi_ctx* c, int max_new_iterations, int* iterations_done)
 {
     if (!c || !c->icp_loaded) { set_error("mi_icp_run: no problem loaded"); return MI_ERR_STATE; }
@@ -1088,9 +1097,7 @@ extern "C" int mi_icp_run(mi_ctx* c, int max_new_iterations, int* iterations_don
         // From GLOBAL sizes only: every batch ends in a collective, so all ranks must pick the same batch (a rank's own share
         // of the dealt moving cloud differs from its neighbours' by up to 64 points).
         const bool brute = resolve_nn_mode(c, c->icp.nn_mode, c->source_sharded ? c->m_total : c->m_total / c->world) == MI_NN_BRUTEFORCE;
-        const double n_rank = (double)c->n_global / c->world, m_rank = (double)c->m_total / c->world;
-        const double est_s = brute ? (c->source_sharded ? n_rank * (double)c->m_total : (double)c->n_global * m_rank) / 7e12 : 2e-5 + 5e-11 * n_rank;
-        batch = est_s >= 5e-3 ? 1 : (est_s >= 2e-4 ? 4 : (est_s >= 1e-4 ? 8 : 16));
+        batch = mi_icp_auto_batch(c->n_global, c->m_total, c->world, c->source_sharded ? 1 : 0, brute ? 1 : 0);
     }
     if (c->icp.verbose) batch = 1;       // one "loop_nr" line per iteration, like basicicp.cpp:50 / icpcuda.cu:39
     int enqueued = 0;
@@ -1237,6 +1244,22 @@ extern "C" int mi_kabsch(mi_ctx* c, const float* src_xyz, int n, const float* tg
     if (c->h_state->pairs <= 0) { set_error("mi_kabsch: no pair kept"); return MI_ERR_INVALID_ARG; }
     memcpy(out_R9, c->h_state->Ri, sizeof(float) * 9);
     memcpy(out_t3, c->h_state->ti, sizeof(float) * 3);
+    return MI_OK;
+}
+
+extern "C" int mi_cross_moments(mi_ctx* c, const float* src_xyz, int n, const float* tgt_xyz, int m, const int* idx,
+                                const unsigned char* keep, double out16[16])
+{
+    if (!c || !src_xyz || !tgt_xyz || !idx || n <= 0 || m <= 0 || !out16) { set_error("mi_cross_moments: bad arguments"); return MI_ERR_INVALID_ARG; }
+    MI_TRY(load_pairs(c, src_xyz, n, tgt_xyz, m, idx, keep));
+    MI_HIP(hipMemcpyAsync(c->d_state, c->h_state, sizeof(IcpState), hipMemcpyHostToDevice, c->stream));
+    const IcpView v = make_view(c);
+    const int nrows = icp_row_count(n);
+    { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_moments_rows(v, c->rows.p, c->stream)); }
+    MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream));
+    MI_HIP(icp_rows_to_state(c->d_state, c->rows_reduced.p, icp_reduced_count(nrows), 1, c->stream));
+    MI_TRY(icp_fetch_state(c));
+    for (int i = 0; i < ICP_MOMENTS; i++) out16[i] = c->h_state->mom[i];
     return MI_OK;
 }
 

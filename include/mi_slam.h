@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MI_SLAM_ABI_VERSION 3   /* 3: mi_icp_load_times; 2: mi_cpd_params gained sigma2_mode; mi_dist_info, mi_source_share, mi_cpd_sigma_squared_mode, mi_profile_search_stats, mi_selftest_sort_pairs */
+#define MI_SLAM_ABI_VERSION 3   /* 3: mi_icp_load_times, mi_cross_moments, mi_icp_auto_batch; 2: mi_cpd_params gained sigma2_mode; mi_dist_info, mi_source_share, mi_cpd_sigma_squared_mode, mi_profile_search_stats, mi_selftest_sort_pairs */
 
 enum {
     MI_OK = 0,
@@ -202,6 +202,10 @@ int mi_icp_load(mi_ctx* ctx, const float* before_xyz, int n_before, const float*
                 const mi_icp_params* params);
 int mi_icp_reset(mi_ctx* ctx);
 int mi_icp_run(mi_ctx* ctx, int max_new_iterations, int* iterations_done);
+/* The iterations mi_icp_run enqueues between two host checks when sync_every = 0 -- a pure function of GLOBAL sizes (moving and
+ * fixed points over all ranks, rank count, what is sharded, which search runs): every batch ends in a collective, so every rank
+ * of a multi-GPU registration must pick the same number. */
+int mi_icp_auto_batch(long long n_moving_total, long long m_fixed_total, int world, int source_sharded, int every_pair_search);
 int mi_icp_result(mi_ctx* ctx, float out_T[16], int* iterations, float* error, int* stop_reason);
 
 /* ----------------------------------------------------------------------------------------------------------------
@@ -216,6 +220,13 @@ int mi_nn_search(mi_ctx* ctx, const float* src_xyz, int n, const float* tgt_xyz,
 /* Same, with an explicit MI_NN_* strategy (mi_nn_search uses MI_NN_AUTO). */
 int mi_nn_search_ex(mi_ctx* ctx, const float* src_xyz, int n, const float* tgt_xyz, int m, int dist_mode, int nn_mode,
                     int* idx, float* d2);
+
+/* The sums LeastSquaresSVD is built from (the cross-covariance product of cudacommon.cu:196-201 -- CuBlasMultiply -- and the two
+ * centroid sums), over the kept pairs (src[i], tgt[idx[i]]):  out16 = { pairs, sum src (3), sum tgt (3), sum tgt_r * src_c (9, row-major
+ * in r) }, fp64.  What the reference's own MultiplicationTest checks on its GEMM (cudacommon.cu:319-343: ones(3x100) * ones(100x3) is
+ * 100 everywhere) is checked on these. */
+int mi_cross_moments(mi_ctx* ctx, const float* src_xyz, int n, const float* tgt_xyz, int m, const int* idx,
+                     const unsigned char* keep, double out16[16]);
 
 /* CUDACommon::LeastSquaresSVD (cudacommon.cu:168-253) / Common::LeastSquaresSVD (common.cpp:517-552) on the pairs
  * (src[i], tgt[idx[i]]), i = 0..n-1, keeping pair i only if keep == NULL or keep[i] != 0.

@@ -70,20 +70,46 @@ def main():
     assert abs(te[0].item() - (dfull ** 2).sum()) < 1e-9 * max(1.0, (dfull ** 2).sum())
     assert te[1].item() == kept.sum()
 
-    # MI_SHARD_SOURCE: rank r owns moving points [N*r/W, N*(r+1)/W) and the whole fixed cloud; nothing per-point is exchanged,
-    # the moments / error sums of the slices add up to the unsharded ones
-    slo, shi = capi.shard_range(n, rank, world)
-    sidx, sd2 = O.nn_search(src[slo:shi], tgt, threads=1)
-    assert np.array_equal(sidx, ridx[slo:shi]) and np.array_equal(sd2.view(np.uint32), rd2[slo:shi].view(np.uint32))
-    skept = sd2 < np.float32(30.0)
-    ts = torch.from_numpy(moments(src[slo:shi], tgt, sidx, skept).copy())
-    dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-    assert ts[0].item() == full[0]
-    assert np.allclose(ts.numpy(), full, rtol=1e-12, atol=1e-9)
-    sdiff = tgt[sidx[skept]].astype(np.float64) - cur[slo:shi][skept]
-    tse = torch.tensor([float((sdiff ** 2).sum()), float(skept.sum())], dtype=torch.float64)
-    dist.all_reduce(tse, op=dist.ReduceOp.SUM)
-    assert abs(tse[0].item() - (dfull ** 2).sum()) < 1e-9 * max(1.0, (dfull ** 2).sum()) and tse[1].item() == kept.sum()
+    # MI_SHARD_SOURCE as the product splits it (mislam_api.hip mi_icp_load / deal_chunks_kernel): every rank orders the WHOLE moving
+    # cloud the same way (the product: along the Hilbert curve, on the device; here any order all ranks agree on) and keeps the
+    # 64-point chunks rank, rank + W, rank + 2W ... of that order -- the last chunk may be ragged -- or, below 4 * 64 * W points, a
+    # contiguous slice of the caller's order.  Nothing per-point is exchanged; the shares partition the cloud (mi_source_share
+    # says how many points each rank holds) and the moments / error sums of the shares add up to the unsharded ones.
+    def source_share(points, r):
+        count = capi.source_share(points, r, world)
+        if points < 4 * 64 * world:
+            slo, shi = capi.shard_range(points, r, world)
+            assert shi - slo == count
+            return np.arange(slo, shi)
+        il = np.arange(count)
+        g = ((il // 64) * world + r) * 64 + il % 64                       # deal_chunks_kernel's index map
+        assert g.max() < points
+        return g
+
+    for n2 in (n, 2500, 64 * 4 * world, 64 * 4 * world + 1):               # slices or dealt chunks by world; ragged; the threshold itself
+        src2 = src if n2 == n else rng.uniform(-5, 5, (n2, 3)).astype(np.float32)
+        order = np.lexsort((src2[:, 2], src2[:, 1], src2[:, 0]))            # stand-in for the Hilbert order
+        shares = [source_share(n2, r) for r in range(world)]
+        allpts = np.sort(np.concatenate(shares))
+        assert np.array_equal(allpts, np.arange(n2)), "the shares do not partition the moving cloud"
+        dealt = n2 >= 4 * 64 * world
+        mine_idx = order[shares[rank]] if dealt else shares[rank]
+        ridx2, rd22 = O.nn_search(src2, tgt, threads=1)
+        sidx, sd2 = O.nn_search(src2[mine_idx], tgt, threads=1)
+        assert np.array_equal(sidx, ridx2[mine_idx]) and np.array_equal(sd2.view(np.uint32), rd22[mine_idx].view(np.uint32))
+        skept, kept2 = sd2 < np.float32(30.0), rd22 < np.float32(30.0)
+        full2 = moments(src2, tgt, ridx2, kept2)
+        ts = torch.from_numpy(moments(src2[mine_idx], tgt, sidx, skept).copy())
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        assert ts[0].item() == full2[0]
+        assert np.allclose(ts.numpy(), full2, rtol=1e-12, atol=1e-9)
+        cur2 = O.transform_cloud(src2, R, np.array([0.1, 0.2, 0.3], np.float32))
+        sdiff = tgt[sidx[skept]].astype(np.float64) - cur2[mine_idx][skept]
+        # ONE all-reduce per iteration in the product: the 16 moments and the 2 error sums travel together (IcpState mom | err)
+        tse = torch.from_numpy(np.concatenate([moments(src2[mine_idx], tgt, sidx, skept), [float((sdiff ** 2).sum()), float(skept.sum())]]))
+        dist.all_reduce(tse, op=dist.ReduceOp.SUM)
+        dfull2 = tgt[ridx2[kept2]].astype(np.float64) - cur2[kept2]
+        assert abs(tse[16].item() - (dfull2 ** 2).sum()) < 1e-9 * max(1.0, (dfull2 ** 2).sum()) and tse[17].item() == kept2.sum()
 
     # C2 -- rigid CPD with the FIXED cloud sharded (mi_cpd_register on a multi-GPU context): rank r owns fixed points
     # [N*r/W, N*(r+1)/W) and the whole moving cloud.  The denominators and Pt1 of its fixed points are local; its P1/PX hold only

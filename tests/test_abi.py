@@ -89,3 +89,20 @@ def test_no_cpu_fallback_without_a_device(capi):
             capi.Context(0)
         return
     assert n >= 1          # on the GPU box the same call simply succeeds
+
+
+def test_auto_batch_is_a_function_of_global_sizes_only(capi):
+    # Every batch of a multi-GPU registration ends in a collective, so all ranks must pick the same batch.  A rank's own share of a
+    # dealt moving cloud differs from its neighbours' by up to 64 points -- the batch therefore comes from the GLOBAL sizes
+    # (mi_icp_auto_batch has no rank argument); the thresholds are crossed at the same total size on every rank count's shares.
+    for world in (1, 2, 3, 8):
+        for n_rank_at_threshold in (1.6e6, 3.6e6, 9.96e7):                  # 5e-11 s per point: 1e-4 s, 2e-4 s, 5e-3 s
+            totals = [int(n_rank_at_threshold * world) + d for d in range(-200, 201, 40)]
+            for n in totals:
+                shares = [capi.source_share(n, r, world) for r in range(world)]
+                assert max(shares) - min(shares) <= 64
+                b = capi.icp_auto_batch(n, n, world, True, False)
+                assert b in (1, 4, 8, 16)
+            assert capi.icp_auto_batch(totals[0], totals[0], world, True, False) >= capi.icp_auto_batch(totals[-1], totals[-1], world, True, False)
+    assert capi.icp_auto_batch(10 ** 6, 10 ** 6, 1, False, False) == 16 and capi.icp_auto_batch(10 ** 4, 10 ** 4, 1, False, True) == 16
+    assert capi.icp_auto_batch(10 ** 6, 10 ** 6, 8, False, True) == 1            # every-pair search of 1e6 x 125 000 per rank: 18 ms

@@ -1,4 +1,4 @@
-"""CPU suite: the multi-GPU exchange protocol, world_size 2 and 3, over gloo (see tests/_dist_worker.py)."""
+"""CPU suite: the multi-GPU exchange protocol, world_size 2, 3 and 8, over gloo (see tests/_dist_worker.py)."""
 import os
 import socket
 import subprocess
@@ -17,7 +17,7 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_search_protocol_over_gloo(world):
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,

@@ -347,3 +347,25 @@ def test_world1_rccl_context_matches_plain_context(capi, bunny):
         ra, rb = dctx.icp_result(), sctx.icp_result()
         assert ra[2] == rb[2] == 39 and ra[3] == rb[3] and ra[4] == rb[4] == capi.STOP_CONVERGED
         assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+
+
+def test_multiplication_known_answer(ctx, capi):
+    # MultiplicationTest, source/cuda-slam/cudacommon.cu:319-343: ones(3 x 100) * ones(100 x 3) through the reference's GEMM wrapper must
+    # be 100 everywhere (+- 1e-5).  Here the product alignedAfter * alignedBefore^T of LeastSquaresSVD (cudacommon.cu:196-201) is the
+    # nine cross sums of the moment rows: 100 pairs of (1, 1, 1) against (1, 1, 1).
+    ones = np.ones((100, 3), np.float32)
+    mom = ctx.cross_moments(ones, ones, np.arange(100, dtype=np.int32))
+    assert mom[0] == 100
+    assert np.all(np.abs(mom[7:16] - 100.0) <= 1e-5) and np.all(np.abs(mom[1:7] - 100.0) <= 1e-5)
+    # the same product on values that are not all alike, against numpy in fp64; and with dropped pairs
+    rng = np.random.default_rng(5)
+    src = rng.uniform(-5, 5, (1003, 3)).astype(np.float32)
+    tgt = rng.uniform(-5, 5, (777, 3)).astype(np.float32)
+    idx = rng.integers(0, 777, 1003).astype(np.int32)
+    keep = (rng.uniform(0, 1, 1003) < 0.8).astype(np.uint8)
+    for kp in (None, keep):
+        mom = ctx.cross_moments(src, tgt, idx, kp)
+        sel = np.ones(1003, bool) if kp is None else kp.astype(bool)
+        b, a = src[sel].astype(np.float64), tgt[idx[sel]].astype(np.float64)
+        want = np.concatenate([[sel.sum()], b.sum(0), a.sum(0), (a[:, :, None] * b[:, None, :]).sum(0).reshape(9)])
+        assert np.allclose(mom, want, rtol=1e-12, atol=1e-9)

@@ -8,7 +8,8 @@ out=$root/cuda-slam_amd/variants
 obj=/tmp/mislam_variant_$name
 mkdir -p "$out" "$obj"
 cd "$root/cuda-slam_amd/csrc"
-for f in nn_kernel nn_tree nn_grid radix_sort icp_kernels cpd_kernels cpd_fgt mislam_api cpd_api nicp_api prepare_api; do
+srcs=$(sed -n 's/^SRCS *= *//p' Makefile)              # the product build's own list: a new translation unit cannot drop out
+for f in ${srcs//.hip/}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -I/opt/rocm/include "$@" -c $f.hip -o $obj/$f.o &
 done
 wait

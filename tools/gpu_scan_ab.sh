@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: parity of the current grid scan, A/B against variants (args), per-iteration probe and wave timeline of the product build
+# parity of the grid scan (NN + ICP + soak tests), A/B of the product build against variant builds (args), per-iteration probe and wave timeline
 mkdir -p gpurun_out; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 tag=${TAG:-s}
 timeout -k 10 900 python -m pytest tests/test_gpu_nn.py tests/test_gpu_icp.py tests/test_gpu_nn_soak.py -x -q -m gpu > gpurun_out/r03_${tag}_tests.log 2>&1 || { tail -30 gpurun_out/r03_${tag}_tests.log; exit 1; }
