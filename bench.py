@@ -351,12 +351,19 @@ def main():
     params = capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=nn_mode, shard_mode=shard_mode, sync_every=max(args.steps, 1))
     elapsed, nn_prof = timed_run(before, after, params, args.warmup, args.steps)
     R, t, iters, err, why = ctx.icp_result()
+    headline_allreduce = None
     # per-kernel breakdown of a step: a few more (untimed) iterations with events around every kernel
     ctx.profile_enable(True)
     ctx.profile_select(None)
     ctx.profile_reset()
     extra = ctx.icp_run(min(args.steps, 5))
     breakdown = {capi.KERNEL_NAMES[k]: ctx.profile_get(k) for k in range(len(capi.KERNEL_NAMES))}
+    if use_dist:
+        ar = breakdown.get("allreduce", (0.0, 0))
+        if ar[1] > 0:        # the headline path's own collective: one 18-double sum per iteration (+ a 2-double one per host batch), event-timed
+            headline_allreduce = {"launches": ar[1], "ms_per_launch": ar[0] / ar[1], "payload_bytes": 8 * 18,
+                                  "collective": "ncclAllReduce(ncclDouble, ncclSum) of IcpState mom|err on the context's stream (mislam_api.hip allreduce_sum_f64)"
+                                                if rehearsal_transport != "gloo" else "caller's transport (gloo rehearsal)"}
     breakdown = {k: v[0] / v[1] for k, v in breakdown.items() if v[1] > 0 and extra > 0}
 
     # Outside the timed region: the same steps with the every-pair search (K1), for the brute-force roofline figures the
@@ -492,6 +499,8 @@ def main():
             out["sizes"] = sizes
         if brute_fig is not None:
             out["bruteforce_nn"] = brute_fig
+        if headline_allreduce is not None:
+            out["allreduce_f64_sum"] = headline_allreduce
         if target_leg is not None:
             out["target_sharded"] = target_leg
             out["rccl"] = rccl

@@ -114,12 +114,14 @@ struct mi_ctx {
     // ---- workspace shared by the drivers
     mislam::DevBuf<float> staging;                       // AoS upload/download staging
     // pinned host staging of the cloud uploads (host_to_device): the runtime's own pageable-copy path stalls for 20-50 ms every
-    // few dozen calls on this machine (tools/alloc_probe.cpp: median 0.36 ms, max 27 ms for 12 MB); 1 MB pieces copied here and sent
-    // on while the next piece is being copied take 0.30 ms, every time
+    // few dozen calls on this machine (tools/alloc_probe.cpp: median 0.36 ms, max 27 ms for 12 MB).  A ring of PIN_SLOTS pieces of
+    // 1 MB, pinned once per context: a piece is copied in while the pieces before it are on their way -- 0.30 ms for 12 MB, every time
+    static constexpr int PIN_SLOTS = 16;
+    static constexpr size_t PIN_PIECE = 1u << 20;
     char* pin = nullptr;
-    size_t pin_cap = 0, pin_used = 0;
-    hipEvent_t pin_event = nullptr;                      // recorded behind the last transfer out of `pin`
-    bool pin_busy = false;
+    hipEvent_t pin_event[PIN_SLOTS] = {nullptr};         // recorded behind the last transfer out of slot k
+    unsigned int pin_busy = 0;                           // bit k: pin_event[k] has been recorded and not waited for since
+    unsigned int pin_next = 0;
     float* h_scratch = nullptr;                          // 64 pinned floats for small read-backs
     mislam::DevBuf<float> bx, by, bz;                    // original moving cloud, SoA
     mislam::DevBuf<float> cx, cy, cz;                    // current (transformed) moving cloud, SoA

@@ -170,12 +170,11 @@ static int ctx_create_common(int device, mi_ctx** out)
         c->tune.fgt_resume = env_i("MISLAM_FGT_RESUME", 1);
         if (const char* ppc = getenv("MISLAM_GRID_PPC")) { const float f = (float)atof(ppc); if (f >= 0.25f && f <= 64.f) c->tune.grid_points_per_cell = f; }
         if (env_i("MISLAM_PRELOAD", 0) == 1) MI_TRY(mi_ctx_preload(c));       // =1: mi_ctx_preload as part of every context creation
-        // pinned upload staging: pinning host memory costs ~0.25 ms per MB on this machine, so the first 32 MB (both clouds of a
-        // 1.3-million-point registration) are pinned here, once per context, not inside some registration call; it grows on demand
-        const int pin_mb = env_i("MISLAM_PIN_MB", 32);
-        if (pin_mb > 0) {
-            MI_HIP(hipHostMalloc((void**)&c->pin, (size_t)pin_mb << 20, hipHostMallocDefault));
-            c->pin_cap = (size_t)pin_mb << 20;
+        // pinned upload staging: a ring of 16 pieces of 1 MB, pinned here, once per context (pinning costs ~0.25 ms per MB on this
+        // machine); MISLAM_PIN=0 uses the runtime's pageable-copy path instead
+        if (env_i("MISLAM_PIN", 1) != 0) {
+            MI_HIP(hipHostMalloc((void**)&c->pin, mi_ctx::PIN_PIECE * mi_ctx::PIN_SLOTS, hipHostMallocDefault));
+            for (hipEvent_t& e : c->pin_event) MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
         MI_HIP(hipHostMalloc((void**)&c->h_scratch, 64 * sizeof(float), hipHostMallocDefault));
         return MI_OK;
@@ -344,9 +343,9 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     retire_buffers();
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->exchange_host) (void)hipHostFree(c->exchange_host);
+    for (hipEvent_t e : c->pin_event) if (e) (void)hipEventDestroy(e);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
-    if (c->pin_event) (void)hipEventDestroy(c->pin_event);
     cpd_workspace_destroy(c);
     c->staging.release();
     c->bx.release(); c->by.release(); c->bz.release();
@@ -545,34 +544,21 @@ NnPlan plan_nn(const mi_ctx* ctx, int n, int m_local)
 
 int host_to_device(mi_ctx* c, void* dst_dev, const void* src_host, size_t bytes)
 {
-    constexpr size_t PIECE = 1u << 20;
-    if (bytes < PIECE / 4) {                          // small: the runtime's path is fine (and synchronous for pageable memory)
+    constexpr size_t PIECE = mi_ctx::PIN_PIECE;
+    if (bytes < PIECE / 4 || c->pin == nullptr) {     // small: the runtime's path is fine (and synchronous for pageable memory)
         MI_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
         return MI_OK;
     }
-    if (c->pin_used + bytes > c->pin_cap) {           // no room left: start over at the front once the transfers in flight are done
-        if (c->pin_busy) { MI_HIP(hipEventSynchronize(c->pin_event)); c->pin_busy = false; }
-        c->pin_used = 0;
-        if (bytes > c->pin_cap) {
-            if (c->pin) (void)hipHostFree(c->pin);
-    if (c->h_scratch) (void)hipHostFree(c->h_scratch);
-            c->pin = nullptr;
-            const size_t want = std::max(2 * bytes, c->pin_cap + c->pin_cap / 2);      // room for both clouds of a registration
-            c->pin_cap = 0;
-            MI_HIP(hipHostMalloc((void**)&c->pin, want, hipHostMallocDefault));
-            c->pin_cap = want;
-        }
-    }
-    if (!c->pin_event) MI_HIP(hipEventCreateWithFlags(&c->pin_event, hipEventDisableTiming));
-    char* base = c->pin + c->pin_used;
-    for (size_t o = 0; o < bytes; o += PIECE) {       // the copy of piece k overlaps the transfer of piece k - 1
+    for (size_t o = 0; o < bytes; o += PIECE) {       // the copy of piece k overlaps the transfers of the pieces before it
         const size_t nb = std::min(PIECE, bytes - o);
-        memcpy(base + o, (const char*)src_host + o, nb);
-        MI_HIP(hipMemcpyAsync((char*)dst_dev + o, base + o, nb, hipMemcpyHostToDevice, c->stream));
+        const unsigned int k = c->pin_next++ % mi_ctx::PIN_SLOTS;
+        if (c->pin_busy & (1u << k)) { MI_HIP(hipEventSynchronize(c->pin_event[k])); c->pin_busy &= ~(1u << k); }   // (sixteen pieces ago: long done)
+        char* slot = c->pin + (size_t)k * PIECE;
+        memcpy(slot, (const char*)src_host + o, nb);
+        MI_HIP(hipMemcpyAsync((char*)dst_dev + o, slot, nb, hipMemcpyHostToDevice, c->stream));
+        MI_HIP(hipEventRecord(c->pin_event[k], c->stream));
+        c->pin_busy |= 1u << k;
     }
-    c->pin_used += (bytes + 255) / 256 * 256;
-    MI_HIP(hipEventRecord(c->pin_event, c->stream));
-    c->pin_busy = true;
     return MI_OK;
 }
 
@@ -1044,18 +1030,23 @@ static int icp_enqueue_iteration(mi_ctx* c)
         if (seq) { ProfScope ps(c, MI_KERNEL_MOMENTS); MI_HIP(icp_seq_centroids(v, c->stream)); }
     }
     {   // K3 (+ K6 of the previous iteration)
-        ProfScope ps(c, MI_KERNEL_SOLVE);
         const IcpSchedule sched = make_schedule(c);
-        MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream, c->fused ? &sched : nullptr));
         int* cursors = c->fused ? sched.counters : nullptr;
         if (c->distributed()) {
             // ONE all-reduce per iteration: this iteration's 16 moments and the previous iteration's 2 error sums (contiguous in
             // the state block)
             static_assert(offsetof(IcpState, err) == offsetof(IcpState, mom) + sizeof(double) * ICP_MOMENTS, "mom and err must be contiguous");
-            MI_HIP(icp_rows_to_state(c->d_state, c->rows_reduced.p, reduced, 3, c->stream));
-            MI_TRY(allreduce_doubles(c, c->d_state->mom, ICP_MOMENTS + ICP_ERRSUMS));
+            {
+                ProfScope ps(c, MI_KERNEL_SOLVE);
+                MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream, c->fused ? &sched : nullptr));
+                MI_HIP(icp_rows_to_state(c->d_state, c->rows_reduced.p, reduced, 3, c->stream));
+            }
+            { ProfScope ps(c, MI_KERNEL_ALLREDUCE); MI_TRY(allreduce_doubles(c, c->d_state->mom, ICP_MOMENTS + ICP_ERRSUMS)); }
+            ProfScope ps(c, MI_KERNEL_SOLVE);
             MI_HIP(icp_solve_deferred(c->d_state, nullptr, 0, c->icp.compose_mode, rules, 1, c->stream, cursors));
         } else {
+            ProfScope ps(c, MI_KERNEL_SOLVE);
+            MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream, c->fused ? &sched : nullptr));
             MI_HIP(icp_solve_deferred(c->d_state, c->rows_reduced.p, reduced, c->icp.compose_mode, rules, 1, c->stream, cursors));
         }
     }
