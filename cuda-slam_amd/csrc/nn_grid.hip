@@ -448,35 +448,35 @@ __device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, uns
         C[j] = s.alive ? C[j] : 0;
         s.budget -= C[j];
     }
-    // the batch's runs as ONE flat sequence of candidates, four per trip.  (Two streams of runs with eight gathers in flight per
-    // lane were measured too -- profiles/r03_scan_forms.log: the lanes whose streams had run out still fetched and tested, and the
-    // bytes returned to the registers, 16 per lane and gather whatever the addresses, are one of the things a launch waits for.)
-    static_assert(GRID_BATCH == 4, "the run queue below holds four runs");
-    unsigned int p = S[0], s1 = S[1], s2 = S[2], s3 = S[3];
-    int left = C[0], c1 = C[1], c2 = C[2], c3 = C[3];
+    // The batch's runs as ONE flat sequence of candidates, four per trip.  What a launch waits for is the wave's INSTRUCTION count, not
+    // its gathers (profiles/r03_scan_forms.log: with every gather of the scan replaced by register moves the launch takes the same
+    // time), so the loop is built for few instructions: each run is rounded up to whole trips (what follows a run in pts are real
+    // points, and testing any real point is harmless), the runs are laid end to end on ONE position counter t, and the run a trip
+    // belongs to falls out of three compares -- no queue to shift, no lane masked off: a lane that has run out keeps re-testing
+    // its last four candidates.
+    static_assert(GRID_BATCH == 4, "four runs laid end to end");
+    const unsigned int e1 = (unsigned int)(C[0] + 3) & ~3u, e2 = e1 + ((unsigned int)(C[1] + 3) & ~3u), e3 = e2 + ((unsigned int)(C[2] + 3) & ~3u),
+                       e4 = e3 + ((unsigned int)(C[3] + 3) & ~3u);
+    const unsigned int b0 = S[0], b1 = S[1] - e1, b2 = S[2] - e2, b3 = S[3] - e3;      // slot of position t inside run r: b_r + t
+    const unsigned int t_last = e4 >= 4u ? e4 - 4u : 0u;
     unsigned long long kbest = s.kbest;
     unsigned int bslot = s.bslot;
-    while (__builtin_amdgcn_ballot_w64((left > 0) | ((c1 | c2 | c3) > 0)) != 0ull) {
+    for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < e4) != 0ull; t += 4) {
 #ifdef MISLAM_DEV_WAVE_TIMELINE
         if (NARROW) s.trips_block += 1; else s.trips_rest += 1;
 #endif
+        const unsigned int tt = min(t, t_last);
+        const unsigned int p = (tt >= e2 ? (tt >= e3 ? b3 : b2) : (tt >= e1 ? b1 : b0)) + tt;
+        const float4* __restrict__ pp = pts + p;               // one address, three immediate offsets
+        const float4 cs[4] = {pp[0], pp[1], pp[2], pp[3]};
 #pragma unroll
-        for (int hop = 0; hop < 2; hop++)                      // next non-empty run (an empty one costs the lane a hop, rarely a trip)
-            if (left <= 0) { p = s1; left = c1; s1 = s2; c1 = c2; s2 = s3; c2 = c3; c3 = 0; }
-        if (left > 0) {
-            const float4* __restrict__ pp = pts + p;           // one address, three immediate offsets
-            const float4 cs[4] = {pp[0], pp[1], pp[2], pp[3]};
-#pragma unroll
-            for (int j4 = 0; j4 < 4; j4++) {
-                const float d = sq3<FMA>(cs[j4].x - s.q[0], cs[j4].y - s.q[1], cs[j4].z - s.q[2]);
-                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(cs[j4].w);
-                const bool better = key < kbest;               // d >= +0: closer, or as close with a lower index
-                kbest = better ? key : kbest;
-                bslot = better ? p + (unsigned int)j4 : bslot;
-            }
+        for (int j4 = 0; j4 < 4; j4++) {
+            const float d = sq3<FMA>(cs[j4].x - s.q[0], cs[j4].y - s.q[1], cs[j4].z - s.q[2]);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(cs[j4].w);
+            const bool better = key < kbest;                   // d >= +0: closer, or as close with a lower index
+            kbest = better ? key : kbest;
+            bslot = better ? p + (unsigned int)j4 : bslot;
         }
-        p += 4;
-        left -= 4;
     }
     s.kbest = kbest;
     s.bslot = bslot;
@@ -544,6 +544,99 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
         const bool covered = x0 >= xa0 && x1 <= xa1;           // the block's rows need no second look
         mask = s.alive ? grid_rows_mask(y0 - s.cy + GRID_ROWS_R, y1 - s.cy + GRID_ROWS_R, z0 - s.cz + GRID_ROWS_R, z1 - s.cz + GRID_ROWS_R) & ~(covered ? block : 0u) : 0u;
     }
+#ifndef MISLAM_GRID_ITEM_ROWS
+#define MISLAM_GRID_ITEM_ROWS 12
+#endif
+#ifndef MISLAM_GRID_NO_ITEMS
+    // ---- the leftover rows, dealt out over the whole wave.  About one lane in five has any (its neighbour lies beyond the block, or
+    // the radius still pokes out of it), one to four rows each -- scanned by their owners they cost the wave more trips than the block
+    // did, with a dozen lanes working.  So the leftover rows of the lanes that have at most GRID_ITEM_ROWS of them become ITEMS, the
+    // first 64 of the wave: lane L takes item L -- some owner's row -- scans it against the owner's query and hands the result back
+    // through an LDS minimum; what is not dealt out stays in `mask` for its owner.  Which lane does a row changes nothing (a lexicographic minimum over the same candidates).
+    {
+        constexpr int GRID_ITEM_ROWS = MISLAM_GRID_ITEM_ROWS;
+        __shared__ unsigned int item_desc[64];                  // (owner lane << 8) | row bit
+        __shared__ float4 item_q[64];                           // per OWNER: query, radius
+        __shared__ uint4 item_m[64];                            // per OWNER: cell range, key
+        __shared__ unsigned long long item_key[64];             // per OWNER: running minimum of the keys its items found
+        __shared__ unsigned int item_slot[64], item_flag[64];
+        const int lane = (int)threadIdx.x & 63;
+        const int n_all = __builtin_popcount(mask);
+        const int n_items = n_all <= GRID_ITEM_ROWS ? n_all : 0;       // (a lane with more rows than that -- at the cloud's edge -- keeps them all)
+        if (__builtin_amdgcn_ballot_w64(n_items > 0) != 0ull) {
+            // exclusive prefix sum of the counts (four bits) over the lanes, bit by bit: ballots and mbcnt, no exchange
+            static_assert(GRID_ITEM_ROWS < 16, "the prefix sum below adds four bits");
+            const unsigned long long b0 = __builtin_amdgcn_ballot_w64((n_items & 1) != 0), b1 = __builtin_amdgcn_ballot_w64((n_items & 2) != 0),
+                                     b2 = __builtin_amdgcn_ballot_w64((n_items & 4) != 0), b3 = __builtin_amdgcn_ballot_w64((n_items & 8) != 0);
+            auto below = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u)); };
+            const int first = below(b0) + 2 * below(b1) + 4 * below(b2) + 8 * below(b3);
+            const int total = __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1) + 4 * __builtin_popcountll(b2) + 8 * __builtin_popcountll(b3);
+            {
+                const int x0 = (int)fmaxf(fx0, 0.f), x1 = (int)fminf(fx1, (float)(g.nx - 1));
+                item_q[lane] = make_float4(s.q[0], s.q[1], s.q[2], r2);
+                item_m[lane] = make_uint4((unsigned int)x0, (unsigned int)x1, (unsigned int)(s.kbest >> 32), (unsigned int)s.kbest);
+                item_key[lane] = s.kbest;
+                item_flag[lane] = 0u;
+                {
+                    unsigned int mm = mask;
+#pragma unroll
+                    for (int k = 0; k < GRID_ITEM_ROWS; k++) {  // owners publish their items -- the first 64 of the wave; the others stay in `mask`
+                        const int b = mm != 0u ? __builtin_ctz(mm) : 0;
+                        if (k < n_items && first + k < 64) { item_desc[first + k] = ((unsigned int)lane << 8) | (unsigned int)b; mask &= ~(1u << b); }
+                        mm &= mm - 1u;
+                    }
+                    __syncthreads();                            // (one wave per workgroup: orders the LDS traffic)
+                    const bool have = lane < total;
+                    const unsigned int desc = have ? item_desc[lane] : 0u;
+                    const int owner = (int)(desc >> 8), b = (int)(desc & 0xffu);
+                    const float4 oq = item_q[owner];
+                    const uint4 om = item_m[owner];
+                    const float ou1 = cell_u(oq.y, g.oy, g.inv_h), ou2 = cell_u(oq.z, g.oz, g.inv_h);
+                    const int oz = (b * ((256 + GRID_ROWS_W - 1) / GRID_ROWS_W)) >> 8, oy = b - GRID_ROWS_W * oz;
+                    const int iy = cell_index(ou1, g.ny) + oy - GRID_ROWS_R, iz = cell_index(ou2, g.nz) + oz - GRID_ROWS_R;
+                    const float gy = gap_cells(ou1, iy) * g.h_lo, gz = gap_cells(ou2, iz) * g.h_lo;
+                    const bool ok = have && (int)om.y >= (int)om.x && gy * gy + gz * gz <= oq.w;
+                    const unsigned int rb = ((unsigned int)iz * (unsigned int)g.ny + (unsigned int)iy) * (unsigned int)g.nx;
+                    const unsigned int p0 = g.cell_start[ok ? rb + om.x : 0u];
+                    int cnt = (int)(g.cell_start[ok ? rb + om.y + 1u : 0u] - p0);
+                    if (STATS && ok) { s.n_rows += 1u; }
+                    if (cnt > GRID_CAND_BUDGET / GRID_ITEM_ROWS) { item_flag[owner] = 1u; cnt = 0; }       // crowded: its owner gives up
+                    const unsigned int c4 = (unsigned int)(cnt + 3) & ~3u, t_last = c4 >= 4u ? c4 - 4u : 0u;
+                    unsigned long long kb = ((unsigned long long)om.z << 32) | om.w;
+                    const unsigned long long kb0 = kb;
+                    unsigned int slot = 0u;
+                    for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < c4) != 0ull; t += 4) {
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+                        s.trips_rest += 1;
+#endif
+                        const unsigned int p = p0 + min(t, t_last);
+                        const float4* __restrict__ pp = g.pts + p;
+                        const float4 cs[4] = {pp[0], pp[1], pp[2], pp[3]};
+#pragma unroll
+                        for (int j4 = 0; j4 < 4; j4++) {
+                            const float d = sq3<FMA>(cs[j4].x - oq.x, cs[j4].y - oq.y, cs[j4].z - oq.z);
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(cs[j4].w);
+                            const bool better = key < kb;
+                            kb = better ? key : kb;
+                            slot = better ? p + (unsigned int)j4 : slot;
+                        }
+                    }
+                    // back to the owners: the minimum of the keys, then the slot of whoever holds it (keys of distinct points differ)
+                    if (kb < kb0) atomicMin(&item_key[owner], kb);
+                    __syncthreads();
+                    if (kb < kb0 && item_key[owner] == kb) item_slot[owner] = slot;
+                    __syncthreads();
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+                    s.batches_rest += 256;                      // (item passes count in the high byte)
+#endif
+                }
+                const unsigned long long kfin = item_key[lane];
+                if (kfin < s.kbest) { s.kbest = kfin; s.bslot = item_slot[lane]; }
+                if (item_flag[lane] != 0u) s.alive = false;
+            }
+        }
+    }
+#endif
     while (__builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) {
         // the cells of a row from the radius as it stands now: one range for the whole batch (a superset of what each row's own
         // gap would leave of it)

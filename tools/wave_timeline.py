@@ -43,8 +43,9 @@ with capi.Context(0) as ctx:
         m = ~walked
         t_in, t_blk = (tl[:, 4] - t0) * 0.01, (tl[:, 5] - t0) * 0.01
         trips_b, trips_r, batches_r = tl[:, 6] & 0xffff, (tl[:, 6] >> 16) & 0xffff, (tl[:, 6] >> 32) & 0xffff
-        print("  scan-only waves, us: prologue %.1f | first batch %.1f (%.1f trips) | rest %.1f (%.1f batches, %.1f trips) | epilogue %.1f"
-              % ((t_in - start)[m].mean(), (t_blk - t_in)[m].mean(), trips_b[m].mean(), (scan - t_blk)[m].mean(), batches_r[m].mean(), trips_r[m].mean(), (end - scan)[m].mean()))
+        item_passes, batches_r = batches_r >> 8, batches_r & 0xff
+        print("  scan-only waves, us: prologue %.1f | first batch %.1f (%.1f trips) | rest %.1f (%.2f item passes, %.1f lockstep batches, %.1f trips) | epilogue %.1f"
+              % ((t_in - start)[m].mean(), (t_blk - t_in)[m].mean(), trips_b[m].mean(), (scan - t_blk)[m].mean(), item_passes[m].mean(), batches_r[m].mean(), trips_r[m].mean(), (end - scan)[m].mean()))
         p1, p2, p3 = (tl[:, 8] - t0) * 0.01, (tl[:, 9] - t0) * 0.01, (tl[:, 10] - t0) * 0.01
         print("  scan-only waves, prologue us: work order -> %.1f | state + moving point -> %.1f | key, slot, previous match -> %.1f | near flag -> %.1f"
               % ((p1 - start)[m].mean(), (p2 - p1)[m].mean(), (p3 - p2)[m].mean(), (t_in - p3)[m].mean()))
