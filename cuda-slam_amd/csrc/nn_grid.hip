@@ -461,7 +461,11 @@ __device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, uns
     const unsigned int t_last = e4 >= 4u ? e4 - 4u : 0u;
     unsigned long long kbest = s.kbest;
     unsigned int bslot = s.bslot;
+#ifdef MISLAM_DEV_BLOCK_CAP             // timing experiment (counting build only): wrong answers
+    for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < e4 && !(STATS && NARROW && t >= MISLAM_DEV_BLOCK_CAP)) != 0ull; t += 4) {
+#else
     for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < e4) != 0ull; t += 4) {
+#endif
 #ifdef MISLAM_DEV_WAVE_TIMELINE
         if (NARROW) s.trips_block += 1; else s.trips_rest += 1;
 #endif
