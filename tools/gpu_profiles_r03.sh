@@ -9,6 +9,7 @@ S=${STEPS:-20}; W=${WARMUP:-5}
 B="python3 bench.py --steps $S --warmup $W --no-cpu-baseline --no-sizes --no-whole-call"
 run() { d=gpurun_out/r03_$1; shift; rm -rf $d; timeout -k 10 500 rocprofv3 "$@" -d $d --output-format csv -- $B > $d.log 2>&1 || { tail -5 $d.log; exit 1; }; echo "pass $d done"; }
 probe() { d=gpurun_out/r03_$1; shift; rm -rf $d; timeout -k 10 200 rocprofv3 "$@" -d $d --output-format csv -- tools/valu_probe > $d.log 2>&1 || { tail -5 $d.log; exit 1; }; }
+[ -x tools/valu_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -w tools/valu_probe.hip -o tools/valu_probe || exit 1
 SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU"
 SQ2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE"
 run stats --kernel-trace --stats

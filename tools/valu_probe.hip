@@ -2,7 +2,8 @@
 // 8 waves per SIMD on every CU -- run under `rocprofv3 --pmc` with the counter sets the search kernel is profiled with, their
 // SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU and GRBM_GUI_ACTIVE say what those counters read at a (near) saturated vector pipe, and their
 // event-timed rate is the practical peak the search kernel's instruction rate is divided by.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/valu_probe.hip -o tools/valu_probe;  tools/valu_probe
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize tools/valu_probe.hip -o tools/valu_probe;  tools/valu_probe
+// (-fno-slp-vectorize: left to itself the compiler fuses the eight v_fma_f32 chains of probe 0 into four v_pk_fma_f32)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
