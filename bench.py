@@ -44,6 +44,35 @@ OPS_PER_PAIR = {0: 8.5, 1: 6.5}            # 3 sub + 3 mul + 2 add (or 1 mul + 2
 SWEEP_SIZES = (10000, 100000, 10000000)
 
 
+def host_cpu_budget():
+    """CPUs this process may actually use: the container's CFS quota (cgroup v2 cpu.max / v1 cfs_quota_us) when there is one, else
+    the cores it sees.  The GPU boxes show 256 cores and grant 16."""
+    cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return max(1, min(cores, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0:
+            return max(1, min(cores, int(round(quota / period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def quiet_host_pools():
+    """Before numpy is imported: one BLAS / OpenMP thread.  numpy's BLAS pool starts a spinning thread per VISIBLE core (256 on the
+    GPU boxes) for the 3x3 product in synth_cloud; under the container's 16-CPU quota that exhausts the quota of the 100 ms period
+    and the kernel freezes every thread of the process until the next one -- measured as 20-60 ms 'stalls' of whichever call came
+    next (hipStreamSynchronize, a copy, a launch; `MISLAM_DEV_STALL_MS` shows them as involuntary context switches)."""
+    for var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(var, "1")
+
+
 def synth_cloud(np, n, seed=666):
     """SURVEY 8d / BASELINE.md section 3: uniform [-5,5]^3 (spread 10), after = R(0.2 rad about (1,2,3)/sqrt14) * before
     + 10*(1,1,1)/sqrt3, target independently permuted."""
@@ -101,7 +130,7 @@ def cpu_baseline(np, before, after, target_seconds=15.0):
     short probe measures this host's pair rate, then the sample is sized for ~15 s of CPU work."""
     from oracle import refbind, oraclebind
     n, m = len(before), len(after)
-    cores = os.cpu_count() or 1
+    cores = os.cpu_count() or 1            # what the reference starts: std::thread::hardware_concurrency() threads (common.cpp:443)
     if refbind.available():
         kind = "reference"
         search = lambda rows: refbind.corresponding_points(before[:rows], after, 1000.0, True)
@@ -117,7 +146,7 @@ def cpu_baseline(np, before, after, target_seconds=15.0):
     search(rows)
     dt = time.perf_counter() - t0
     full_iter_s = dt * (n / rows)
-    return {"value": 1.0 / full_iter_s, "unit": "iterations/s", "cores": cores, "kind": kind,
+    return {"value": 1.0 / full_iter_s, "unit": "iterations/s", "cores": cores, "host_cpu_quota": host_cpu_budget(), "kind": kind,
             "sample": "GetCorrespondingPoints (common.cpp:441-507, %d threads) on %d of %d source rows x all %d targets: "
                       "%.2f s, scaled x%.1f to one iteration (the search is >99%% of a cpu-slam iteration)"
                       % (cores, rows, n, m, dt, n / rows),
@@ -247,6 +276,7 @@ def main():
     # MISLAM_BENCH_FORCE_DIST=1 takes the multi-process path (gloo bootstrap, RCCL communicator) even with one rank:
     # the rehearsal a single-GPU box allows
     use_dist = world > 1 or os.environ.get("MISLAM_BENCH_FORCE_DIST") == "1"
+    quiet_host_pools()           # (before numpy / torch are imported)
     dist = None
     if use_dist:
         # torch first: its bundled HIP/RCCL runtime must be the one in the process before libmislam.so is loaded

@@ -4,6 +4,7 @@
 // whole iteration -- search, (all-reduce), moments, solve, transform, error, stop rule -- is enqueued on one HIP stream
 // without a single host round trip; the host only reads the 256-byte state block back every `sync_every` iterations.
 #include <hip/hip_runtime.h>
+#include <sys/resource.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -109,6 +110,24 @@ void retire_buffers()
 }
 }  // namespace mislam
 
+// developer switch MISLAM_DEV_STALL_MS=<ms>: report any host-side section that takes longer, with the calling thread's context switches
+// over it -- an INVOLUNTARY one with no voluntary ones means the thread was taken off its core (a CPU quota of the container
+// running out: numpy's BLAS pool spinning on every host core did exactly that to the round-2 sweeps), not that the GPU or the
+// runtime made it wait.
+static double g_stall_ms = -1.0;
+struct StallProbe {
+    const char* label; double t0; struct rusage ru0;
+    explicit StallProbe(const char* l) : label(l), t0(0.0) { if (g_stall_ms > 0) { t0 = mislam::wall_ms(); getrusage(RUSAGE_THREAD, &ru0); } }
+    ~StallProbe()
+    {
+        if (g_stall_ms <= 0) return;
+        const double d = mislam::wall_ms() - t0;
+        if (d <= g_stall_ms) return;
+        struct rusage ru1; getrusage(RUSAGE_THREAD, &ru1);
+        fprintf(stderr, "mislam stall: %s %.2f ms (context switches: %ld voluntary, %ld involuntary)\n", label, d, ru1.ru_nvcsw - ru0.ru_nvcsw, ru1.ru_nivcsw - ru0.ru_nivcsw);
+    }
+};
+
 extern "C" const char* mi_last_error(void) { return g_error; }
 extern "C" int mi_abi_version(void) { return MI_SLAM_ABI_VERSION; }
 
@@ -162,6 +181,7 @@ static int ctx_create_common(int device, mi_ctx** out)
         memset(c->h_state, 0, sizeof(IcpState));
         // developer switches: read here, once -- nothing on the per-iteration path looks at the environment
         auto env_i = [](const char* name, int dflt) { const char* v = getenv(name); return (v && *v) ? atoi(v) : dflt; };
+        if (const char* sm = getenv("MISLAM_DEV_STALL_MS")) g_stall_ms = atof(sm);
         c->tune.nn_force_mode = env_i("MISLAM_NN_MODE", 0);
         c->tune.nn_R = env_i("MISLAM_NN_R", 2);
         c->tune.nn_wgs = env_i("MISLAM_NN_WGS", 0);
@@ -626,7 +646,8 @@ static int ensure_grid(mi_ctx* c, int m_local, int index_base)
     MI_HIP(cloud_bbox(c->tx.p, c->ty.p, c->tz.p, m_local, c->tbbox.p, d_bbox, c->stream));
     float* bbox = c->h_scratch;                        // (pinned: a read-back into pageable memory goes through the runtime's staging)
     MI_HIP(hipMemcpyAsync(bbox, d_bbox, 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    MI_HIP(hipStreamSynchronize(c->stream));
+    { StallProbe sp("grid: bounding-box synchronize"); MI_HIP(hipStreamSynchronize(c->stream)); }
+    StallProbe sp_rest("grid: reserve + enqueue build");
     NnGridView g{};
     grid_plan(bbox, m_local, c->tune.grid_points_per_cell, &g);
     const size_t n_cells = (size_t)g.nx * g.ny * g.nz;
@@ -1060,9 +1081,9 @@ static int icp_enqueue_iteration(mi_ctx* c)
 
 static int icp_fetch_state(mi_ctx* c)
 {
-    MI_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
-    MI_HIP(hipStreamSynchronize(c->stream));
-    retire_buffers();
+    { StallProbe sp("fetch_state: enqueue copy"); MI_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream)); }
+    { StallProbe sp("fetch_state: stream synchronize"); MI_HIP(hipStreamSynchronize(c->stream)); }
+    { StallProbe sp("fetch_state: retire buffers"); retire_buffers(); }
     return MI_OK;
 }
 
@@ -1095,11 +1116,20 @@ extern "C" int mi_icp_run(mi_ctx* c, int max_new_iterations, int* iterations_don
     while (!c->h_state->done && (max_new_iterations < 0 || enqueued < max_new_iterations)) {
         int todo = batch;
         if (max_new_iterations >= 0) todo = std::min(todo, max_new_iterations - enqueued);
-        for (int b = 0; b < todo; b++) MI_TRY(icp_enqueue_iteration(c));
-        MI_TRY(icp_flush_pending(c));
+        hipEvent_t dev_e0 = nullptr, dev_e1 = nullptr;
+        if (g_stall_ms > 0) { (void)hipEventCreate(&dev_e0); (void)hipEventCreate(&dev_e1); (void)hipEventRecord(dev_e0, c->stream); }
+        { StallProbe sp("run: enqueue batch"); for (int b = 0; b < todo; b++) MI_TRY(icp_enqueue_iteration(c)); }
+        { StallProbe sp("run: enqueue flush"); MI_TRY(icp_flush_pending(c)); }
+        if (dev_e1) (void)hipEventRecord(dev_e1, c->stream);
         enqueued += todo;
         const int shown = c->h_state->passes;
         MI_TRY(icp_fetch_state(c));
+        if (dev_e1) {
+            float dev_ms = 0.f;
+            (void)hipEventElapsedTime(&dev_ms, dev_e0, dev_e1);
+            if (dev_ms > g_stall_ms) fprintf(stderr, "mislam stall: the batch's %d iterations took %.2f ms ON THE DEVICE (events)\n", todo, dev_ms);
+            (void)hipEventDestroy(dev_e0); (void)hipEventDestroy(dev_e1);
+        }
         if (c->icp.verbose && c->rank == 0 && c->h_state->passes > shown)
             printf("loop_nr %d, error: %f, correspondencesSize: %d\n", c->h_state->passes - 1, c->h_state->error, c->h_state->pairs);
     }

@@ -3,6 +3,9 @@ import json
 import os
 import sys
 
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):   # one BLAS thread: a pool spinning on every visible core
+    os.environ.setdefault(_v, "1")                                          # exhausts the GPU box's 16-CPU quota (bench.quiet_host_pools)
+
 import numpy as np
 import pytest
 

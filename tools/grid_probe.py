@@ -6,6 +6,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):   # see bench.quiet_host_pools: BLAS pools vs the CPU quota
+    os.environ.setdefault(_v, "1")
 import numpy as np  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
 from bench import synth_cloud  # noqa: E402
