@@ -265,99 +265,7 @@ __device__ __forceinline__ float gap_cells(float u, int i)
     return fmaxf(fmaxf(lo - u, u - (lo + 1.f)) - 1e-3f, 0.f);
 }
 
-// k = 0, 1, 2, 3, 4 ... -> 0, -1, +1, -2, +2 ...: slabs in the order of their distance from the query's own
-__device__ __forceinline__ int centre_out(int k) { return (k & 1) ? -((k + 1) >> 1) : (k >> 1); }
-
-#ifdef MISLAM_GRID_SCAN_V1
-// Grid part of one lane's search.  Returns true if the lane gave up (it must then walk the hierarchy from (best, bidx)).
-//
-// The lane scans the cells within r2 = min(best, cap2) of the query, nearest slabs first, so that `best` -- and with it r2 --
-// shrinks at once and the outer rows are pruned with a realistic radius whatever the starting candidate was worth.  Every point
-// with d <= the FINAL r2 is met: r2 only shrinks, and each row's test and x-range use an r2 that is at least the final one.  So
-// if the final best is within cap2 the answer is exact; otherwise (nothing near: the query lies outside the fixed cloud, or has
-// no starting candidate and sits in an empty region) the lane gives up.  cap2 is the square of GRID_DU_MAX cells.
-// The row loops run in LOCKSTEP over the wave (k-th nearest slab of each lane's own position, a wave-uniform counter): a row
-// that no lane needs costs a ballot, not a trip, and a row's points are fetched four at a time.
-template <bool FMA, bool STATS>
-__device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3], float& best, unsigned int& bidx, unsigned int& bslot,
-                                            unsigned int& n_cand, unsigned int& n_rows)
-{
-    const float4* __restrict__ pts = g.pts;
-    const unsigned int* __restrict__ cell_start = g.cell_start;
-    const float u0 = cell_u(q[0], g.ox, g.inv_h), u1 = cell_u(q[1], g.oy, g.inv_h), u2 = cell_u(q[2], g.oz, g.inv_h);
-    const float cap = (GRID_DU_MAX - 2e-3f) * g.h_lo;          // every point within `cap` of the query lies within GRID_DU_MAX cells
-    const float cap2 = cap * cap * (1.f - 1e-5f);
-    // A starting candidate far beyond the grid's reach says the query lies well outside the fixed cloud (or its neighbourhood is
-    // empty): scanning (2 GRID_DU_MAX + 1)^2 mostly empty rows first would only delay the walk.  Speed only -- the walk is exact.
-    bool alive = !(best < __builtin_inff() && best > cap2 * (GRID_FAR_FACTOR * GRID_FAR_FACTOR));
-#ifdef MISLAM_DEV_SKIP_GRID           // timing experiments only (tools/build_variant.sh): wrong answers
-    if (alive) return false;
-#endif
-    // the query's own slabs, clamped into the grid (a query outside the grid starts from the nearest boundary slab)
-    const int cy = cell_index(u1, g.ny), cz = cell_index(u2, g.nz);
-    constexpr int SPAN = 2 * (int)GRID_DU_MAX + 3;             // slabs per axis that can lie within GRID_DU_MAX cells
-    int budget = GRID_CAND_BUDGET;
-    // Slabs come nearest first, alternating sides (0, -1, +1, -2, +2 ...), and a side's gaps only grow with the offset while the
-    // radius only shrinks: once no lane needs either slab of an offset, no lane needs any slab beyond it -- the loop ends there.
-    bool z_prev_none = false;
-    for (int kz = 0; kz < SPAN; kz++) {
-        const int iz = cz + centre_out(kz);
-        const float gz = gap_cells(u2, iz) * g.h_lo;
-        const bool zok = alive && iz >= 0 && iz < g.nz && gz * gz <= fminf(best, cap2);
-        const bool z_none = __builtin_amdgcn_ballot_w64(zok) == 0ull;
-        if (kz > 0 && (kz & 1) == 0 && z_none && z_prev_none) break;
-        z_prev_none = z_none;
-        if (z_none) continue;
-        bool y_prev_none = false;
-        for (int ky = 0; ky < SPAN; ky++) {
-            const int iy = cy + centre_out(ky);
-            const float gy = gap_cells(u1, iy) * g.h_lo;
-            const float g2 = gy * gy + gz * gz;
-            const float r2 = fminf(best, cap2);
-            // a row is skipped only if it is strictly farther than the search radius: then it cannot win or tie
-            const bool near = zok && alive && iy >= 0 && iy < g.ny && g2 <= r2;
-            const bool y_none = __builtin_amdgcn_ballot_w64(near) == 0ull;
-            if (ky > 0 && (ky & 1) == 0 && y_none && y_prev_none) break;
-            y_prev_none = y_none;
-            if (y_none) continue;                                         // (before the costlier x-range arithmetic)
-            const float rem = fmaxf(r2 * 1.000001f - g2, 0.f);
-            // raw v_sqrt_f32 (1 ulp, denormals flushed): both are covered by the slack that follows
-            const float dux = __builtin_amdgcn_sqrtf(rem) * g.inv_h * 1.00001f + 1e-3f;
-            const float flo = floorf(u0 - dux), fhi = floorf(u0 + dux);
-            const bool ok = near && fhi >= 0.f && flo <= (float)(g.nx - 1);
-            if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
-            unsigned int s = 0u, e = 0u;
-            if (ok) {
-                const int x0 = (int)fmaxf(flo, 0.f), x1 = (int)fminf(fhi, (float)(g.nx - 1));
-                const unsigned int rb = ((unsigned int)iz * (unsigned int)g.ny + (unsigned int)iy) * (unsigned int)g.nx;
-                s = cell_start[rb + x0];
-                e = cell_start[rb + x1 + 1];
-                if (e - s > (unsigned int)budget) { alive = false; e = s; }   // crowded: give up, the hierarchy takes over
-                budget -= (int)(e - s);
-                if (STATS) n_rows += 1;
-            }
-            for (unsigned int p = s; p < e; p += 4) {
-                // four points per trip; past the end the last point is fetched again (testing a candidate twice changes nothing)
-                const unsigned int last = e - 1;
-                const float4 cs[4] = {pts[p], pts[min(p + 1, last)], pts[min(p + 2, last)], pts[min(p + 3, last)]};
-#pragma unroll
-                for (int j4 = 0; j4 < 4; j4++) {
-                    const float d = sq3<FMA>(cs[j4].x - q[0], cs[j4].y - q[1], cs[j4].z - q[2]);
-                    const unsigned int j = __float_as_uint(cs[j4].w);
-                    const bool better = (d < best) | ((d == best) & (j < bidx));
-                    best = better ? d : best;
-                    bidx = better ? j : bidx;
-                    bslot = better ? min(p + (unsigned int)j4, last) : bslot;
-                }
-            }
-        }
-    }
-    if (STATS) n_cand += (unsigned int)(GRID_CAND_BUDGET - budget);
-    return !alive || !(best <= cap2);
-}
-
-#else
-// ---- round-3 form of the grid part -----------------------------------------------------------------------------------------
+// ---- the grid part (round 3; round 2's lockstep slab loops: git show 67995b1:cuda-slam_amd/csrc/nn_grid.hip) --------------------
 // What round 2's scan cost (profiles/r03_timeline.log, r03_pmc_*): a launch lasts as long as its waves hold their slots, and a scan
 // wave lived ~35 us through ~18 DEPENDENT memory round trips (every cell row: its two offsets, then its points, four at a time)
 // while two thirds of its vector instructions were the bookkeeping of the lockstep slab loops.  Now:
@@ -408,39 +316,67 @@ struct GridLane {
 #endif
 };
 
-struct __attribute__((packed, aligned(4))) GridOffsets4 { unsigned int v[4]; };
-
-// One batch: takes up to GRID_BATCH rows off `mask`, scans cells [x0, x1] of each that lies within r2.  NARROW: x1 - x0 <= 2, so a row's
-// two offsets come out of ONE 16-byte load (cell_start carries three words of padding).
-template <bool FMA, bool STATS, bool NARROW>
-__device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, unsigned int& mask, int x0, int x1, float r2)
+// One batch: takes up to GRID_BATCH rows off `mask`, scans cells [x0, x1] of each that lies within r2.  BLOCK: the rows are the (up to)
+// 2 x 2 rows [blk.y0, blk.y1] x [blk.z0, blk.z1] of the nearest block instead -- named directly, their two gaps per axis computed once.
+struct GridBlockRows { int y0, y1, z0, z1; };
+#ifndef MISLAM_GRID_TRIP
+#define MISLAM_GRID_TRIP 4
+#endif
+constexpr unsigned int GRID_TRIP = MISLAM_GRID_TRIP;          // candidates per trip (a power of two, <= GRID_PTS_PAD)
+static_assert(GRID_TRIP >= 1 && GRID_TRIP <= GRID_PTS_PAD && (GRID_TRIP & (GRID_TRIP - 1)) == 0, "trip width");
+__device__ __forceinline__ unsigned int grid_trip_round(int c) { return (unsigned int)(c + (int)GRID_TRIP - 1) & ~(GRID_TRIP - 1u); }
+// `reach` (BLOCK only): occupied_near of the query's cell, a byte that is still on its way from memory when the block's offsets are
+// requested -- it only decides whether their runs count, so the two round trips overlap.
+template <bool FMA, bool STATS, bool BLOCK>
+__device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, unsigned int& mask, int x0, int x1, float r2, const GridBlockRows& blk,
+                                           unsigned int reach_word = 1u)
 {
     const float4* __restrict__ pts = g.pts;
     const unsigned int* __restrict__ cell_start = g.cell_start;
     unsigned int S[GRID_BATCH];
     int C[GRID_BATCH];
+    float gy2b[2] = {0.f, 0.f}, gz2b[2] = {0.f, 0.f};
+    if (BLOCK) {
+        const float a = gap_cells(s.u1, blk.y0) * g.h_lo, b = gap_cells(s.u1, blk.y1) * g.h_lo, c = gap_cells(s.u2, blk.z0) * g.h_lo, d = gap_cells(s.u2, blk.z1) * g.h_lo;
+        gy2b[0] = a * a; gy2b[1] = b * b; gz2b[0] = c * c; gz2b[1] = d * d;
+    }
 #pragma unroll
     for (int j = 0; j < GRID_BATCH; j++) {
-        const bool have = mask != 0u;
-        const int b = have ? __builtin_ctz(mask) : 0;
-        mask &= mask - 1u;
-        const int oz = (b * ((256 + GRID_ROWS_W - 1) / GRID_ROWS_W)) >> 8, oy = b - GRID_ROWS_W * oz;       // b / W, b % W (b < 64)
-        const int iy = s.cy + oy - GRID_ROWS_R, iz = s.cz + oz - GRID_ROWS_R;
-        const float gy = gap_cells(s.u1, iy) * g.h_lo, gz = gap_cells(s.u2, iz) * g.h_lo;
-        // a row is skipped only if it is strictly farther than the search radius: then it cannot win or tie
-        const bool ok = have && s.alive && x1 >= x0 && gy * gy + gz * gz <= r2;
-        const unsigned int rb = ((unsigned int)iz * (unsigned int)g.ny + (unsigned int)iy) * (unsigned int)g.nx;
-        if (NARROW) {
-            GridOffsets4 o;
-            __builtin_memcpy(&o, cell_start + (ok ? rb + (unsigned int)x0 : 0u), sizeof o);
-            const unsigned int e = x1 - x0 == 0 ? o.v[1] : (x1 - x0 == 1 ? o.v[2] : o.v[3]);
-            S[j] = o.v[0];
-            C[j] = ok ? (int)(e - o.v[0]) : 0;
+        bool have;
+        int iy, iz;
+        float g2;                                              // the row's squared gap to the query, a lower bound (summed like a distance)
+        if (BLOCK) {
+            static_assert(GRID_BATCH == 4, "the block's 2 x 2 rows are one batch");
+            have = ((j & 1) == 0 || blk.y1 > blk.y0) && ((j & 2) == 0 || blk.z1 > blk.z0);
+            iy = (j & 1) ? blk.y1 : blk.y0; iz = (j & 2) ? blk.z1 : blk.z0;
+            g2 = gy2b[j & 1] + gz2b[(j >> 1) & 1];
         } else {
-            S[j] = cell_start[ok ? rb + (unsigned int)x0 : 0u];                        // (not ok: both offsets of entry 0, an empty run)
-            C[j] = (int)(cell_start[ok ? rb + (unsigned int)x1 + 1u : 0u] - S[j]);
+            have = mask != 0u;
+            const int b = have ? __builtin_ctz(mask) : 0;
+            mask &= mask - 1u;
+            const int oz = (b * ((256 + GRID_ROWS_W - 1) / GRID_ROWS_W)) >> 8, oy = b - GRID_ROWS_W * oz;   // b / W, b % W (b < 64)
+            iy = s.cy + oy - GRID_ROWS_R; iz = s.cz + oz - GRID_ROWS_R;
+            const float gy = gap_cells(s.u1, iy) * g.h_lo, gz = gap_cells(s.u2, iz) * g.h_lo;
+            g2 = gy * gy + gz * gz;
         }
+        // a row is skipped only if it is strictly farther than the search radius: then it cannot win or tie
+        const bool ok = have && s.alive && x1 >= x0 && g2 <= r2;
+        const unsigned int rb = ((unsigned int)iz * (unsigned int)g.ny + (unsigned int)iy) * (unsigned int)g.nx;
+        // (not ok: both offsets of entry 0, an empty run.  Two independent 4-byte loads per row, eight per batch, all in flight together:
+        // one 16-byte load per row of the block was tried -- the compiler narrows it to the words the cell range selects, behind a
+        // branch with a wait inside, four memory round trips in a row instead of one)
+        S[j] = cell_start[ok ? rb + (unsigned int)x0 : 0u];
+        C[j] = (int)(cell_start[ok ? rb + (unsigned int)x1 + 1u : 0u] - S[j]);
         if (STATS) s.n_rows += ok ? 1u : 0u;
+    }
+    if (BLOCK) {
+        // the byte is looked at only now, behind the offsets (loads return in order: it has arrived when they have) -- the compiler would
+        // otherwise test it the moment it is loaded and stall the wave a whole round trip before the offsets are even requested
+        asm("" : "+v"(reach_word) : "v"(C[0]), "v"(C[1]), "v"(C[2]), "v"(C[3]));      // (not volatile: see far_class)
+        const bool reach = reach_word != 0u;
+#pragma unroll
+        for (int j = 0; j < GRID_BATCH; j++) C[j] = reach ? C[j] : 0;
+        s.alive = s.alive && reach;
     }
 #pragma unroll
     for (int j = 0; j < GRID_BATCH; j++) {
@@ -455,26 +391,27 @@ __device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, uns
     // belongs to falls out of three compares -- no queue to shift, no lane masked off: a lane that has run out keeps re-testing
     // its last four candidates.
     static_assert(GRID_BATCH == 4, "four runs laid end to end");
-    const unsigned int e1 = (unsigned int)(C[0] + 3) & ~3u, e2 = e1 + ((unsigned int)(C[1] + 3) & ~3u), e3 = e2 + ((unsigned int)(C[2] + 3) & ~3u),
-                       e4 = e3 + ((unsigned int)(C[3] + 3) & ~3u);
+    const unsigned int e1 = grid_trip_round(C[0]), e2 = e1 + grid_trip_round(C[1]), e3 = e2 + grid_trip_round(C[2]), e4 = e3 + grid_trip_round(C[3]);
     const unsigned int b0 = S[0], b1 = S[1] - e1, b2 = S[2] - e2, b3 = S[3] - e3;      // slot of position t inside run r: b_r + t
-    const unsigned int t_last = e4 >= 4u ? e4 - 4u : 0u;
+    const unsigned int t_last = e4 >= GRID_TRIP ? e4 - GRID_TRIP : 0u;
     unsigned long long kbest = s.kbest;
     unsigned int bslot = s.bslot;
 #ifdef MISLAM_DEV_BLOCK_CAP             // timing experiment (counting build only): wrong answers
-    for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < e4 && !(STATS && NARROW && t >= MISLAM_DEV_BLOCK_CAP)) != 0ull; t += 4) {
+    for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < e4 && !(STATS && BLOCK && t >= MISLAM_DEV_BLOCK_CAP)) != 0ull; t += GRID_TRIP) {
 #else
-    for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < e4) != 0ull; t += 4) {
+    for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < e4) != 0ull; t += GRID_TRIP) {
 #endif
 #ifdef MISLAM_DEV_WAVE_TIMELINE
-        if (NARROW) s.trips_block += 1; else s.trips_rest += 1;
+        if (BLOCK) s.trips_block += 1; else s.trips_rest += 1;
 #endif
         const unsigned int tt = min(t, t_last);
         const unsigned int p = (tt >= e2 ? (tt >= e3 ? b3 : b2) : (tt >= e1 ? b1 : b0)) + tt;
         const float4* __restrict__ pp = pts + p;               // one address, three immediate offsets
-        const float4 cs[4] = {pp[0], pp[1], pp[2], pp[3]};
+        float4 cs[GRID_TRIP];
 #pragma unroll
-        for (int j4 = 0; j4 < 4; j4++) {
+        for (unsigned int j4 = 0; j4 < GRID_TRIP; j4++) cs[j4] = pp[j4];
+#pragma unroll
+        for (unsigned int j4 = 0; j4 < GRID_TRIP; j4++) {
             const float d = sq3<FMA>(cs[j4].x - s.q[0], cs[j4].y - s.q[1], cs[j4].z - s.q[2]);
             const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(cs[j4].w);
             const bool better = key < kbest;                   // d >= +0: closer, or as close with a lower index
@@ -492,9 +429,9 @@ __device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, uns
 // met, because r2 only shrinks and every row test and cell range uses an r2 that is at least the final one.  So if the final best
 // is within cap2 the answer is exact; otherwise (nothing near: the query lies outside the fixed cloud, or has no starting
 // candidate and sits in an empty region) the lane gives up.  cap2 is the square of (a hair less than) GRID_DU_MAX cells.
-// `in_reach` = occupied_near of the query's cell: false says no cell the scan could visit holds a point.
+// `reach_word` = occupied_near of the query's cell: 0 says no cell the scan could visit holds a point.  `lane_on`: the lane has a point.
 template <bool FMA, bool STATS>
-__device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3], bool in_reach, float& best, unsigned int& bidx,
+__device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3], bool lane_on, unsigned int reach_word, float& best, unsigned int& bidx,
                                             unsigned int& bslot, unsigned int& n_cand, unsigned int& n_rows
 #ifdef MISLAM_DEV_WAVE_TIMELINE
                                             , unsigned long long (&dev_tl)[3]
@@ -521,7 +458,8 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
     float r2 = fminf(best, cap2);
     float du = __builtin_amdgcn_sqrtf(r2 * 1.000001f) * g.inv_h * 1.00001f + 1e-3f;
     float fx0 = floorf(u0 - du), fx1 = floorf(u0 + du), fy0 = floorf(u1 - du), fy1 = floorf(u1 + du), fz0 = floorf(u2 - du), fz1 = floorf(u2 + du);
-    s.alive = in_reach && fx1 >= 0.f && fx0 <= (float)(g.nx - 1) && fy1 >= 0.f && fy0 <= (float)(g.ny - 1) && fz1 >= 0.f && fz0 <= (float)(g.nz - 1);
+    // (alive: geometry only so far; the reach byte joins in inside the first batch)
+    s.alive = lane_on && fx1 >= 0.f && fx0 <= (float)(g.nx - 1) && fy1 >= 0.f && fy0 <= (float)(g.ny - 1) && fz1 >= 0.f && fz0 <= (float)(g.nz - 1);
     // ---- the nearest 2 x 2 x 2 block (what of it the starting radius reaches)
     const int sx = u0 - (float)cx >= 0.5f ? 1 : -1, sy = u1 - (float)s.cy >= 0.5f ? 1 : -1, sz = u2 - (float)s.cz >= 0.5f ? 1 : -1;
     const int xa0 = max(max(min(cx, cx + sx), 0), (int)fmaxf(fx0, 0.f)), xa1 = min(min(max(cx, cx + sx), g.nx - 1), (int)fminf(fx1, (float)(g.nx - 1)));
@@ -533,7 +471,9 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
 #ifdef MISLAM_DEV_WAVE_TIMELINE
     s.t_in = wall_clock64(); s.trips_block = s.trips_rest = s.batches_rest = 0;
 #endif
-    if (__builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) grid_batch<FMA, STATS, true>(g, s, mask, xa0, xa1, r2);
+    const GridBlockRows blk{ya0, ya1, za0, za1};
+    if (__builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) grid_batch<FMA, STATS, true>(g, s, mask, xa0, xa1, r2, blk, reach_word);
+    s.alive = s.alive && reach_word != 0u;
 #ifdef MISLAM_DEV_WAVE_TIMELINE
     s.t_block = wall_clock64();
 #endif
@@ -583,8 +523,9 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
                 item_flag[lane] = 0u;
                 {
                     unsigned int mm = mask;
-#pragma unroll
-                    for (int k = 0; k < GRID_ITEM_ROWS; k++) {  // owners publish their items -- the first 64 of the wave; the others stay in `mask`
+                    // owners publish their items -- the first 64 of the wave; the others stay in `mask` (as many rounds as the lane with
+                    // the most items has)
+                    for (int k = 0; __builtin_amdgcn_ballot_w64(k < n_items && first + k < 64) != 0ull; k++) {
                         const int b = mm != 0u ? __builtin_ctz(mm) : 0;
                         if (k < n_items && first + k < 64) { item_desc[first + k] = ((unsigned int)lane << 8) | (unsigned int)b; mask &= ~(1u << b); }
                         mm &= mm - 1u;
@@ -605,19 +546,21 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
                     int cnt = (int)(g.cell_start[ok ? rb + om.y + 1u : 0u] - p0);
                     if (STATS && ok) { s.n_rows += 1u; }
                     if (cnt > GRID_CAND_BUDGET / GRID_ITEM_ROWS) { item_flag[owner] = 1u; cnt = 0; }       // crowded: its owner gives up
-                    const unsigned int c4 = (unsigned int)(cnt + 3) & ~3u, t_last = c4 >= 4u ? c4 - 4u : 0u;
+                    const unsigned int c4 = grid_trip_round(cnt), t_last = c4 >= GRID_TRIP ? c4 - GRID_TRIP : 0u;
                     unsigned long long kb = ((unsigned long long)om.z << 32) | om.w;
                     const unsigned long long kb0 = kb;
                     unsigned int slot = 0u;
-                    for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < c4) != 0ull; t += 4) {
+                    for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < c4) != 0ull; t += GRID_TRIP) {
 #ifdef MISLAM_DEV_WAVE_TIMELINE
                         s.trips_rest += 1;
 #endif
                         const unsigned int p = p0 + min(t, t_last);
                         const float4* __restrict__ pp = g.pts + p;
-                        const float4 cs[4] = {pp[0], pp[1], pp[2], pp[3]};
+                        float4 cs[GRID_TRIP];
 #pragma unroll
-                        for (int j4 = 0; j4 < 4; j4++) {
+                        for (unsigned int j4 = 0; j4 < GRID_TRIP; j4++) cs[j4] = pp[j4];
+#pragma unroll
+                        for (unsigned int j4 = 0; j4 < GRID_TRIP; j4++) {
                             const float d = sq3<FMA>(cs[j4].x - oq.x, cs[j4].y - oq.y, cs[j4].z - oq.z);
                             const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(cs[j4].w);
                             const bool better = key < kb;
@@ -650,7 +593,7 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
 #ifdef MISLAM_DEV_WAVE_TIMELINE
         s.batches_rest += 1;
 #endif
-        grid_batch<FMA, STATS, false>(g, s, mask, (int)fmaxf(flo, 0.f), (int)fminf(fhi, (float)(g.nx - 1)), r2);
+        grid_batch<FMA, STATS, false>(g, s, mask, (int)fmaxf(flo, 0.f), (int)fminf(fhi, (float)(g.nx - 1)), r2, blk);
     }
     best = __uint_as_float((unsigned int)(s.kbest >> 32));
     bidx = (unsigned int)s.kbest;
@@ -661,8 +604,6 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
 #endif
     return !s.alive || !(best <= cap2);
 }
-
-#endif
 
 // One wave per workgroup, one lane per moving point: a wave's 64 Morton neighbours share cells and cache lines, and nothing has
 // to be exchanged between waves -- the lanes that give up walk the hierarchy TOGETHER right where they are (tree_walk_wave takes
@@ -693,10 +634,19 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
     unsigned long long pre_cycles = 0, life_cycles = 0;
 #endif
     unsigned int chunk = xcd_chunk(blockIdx.x, gridDim.x, TREE_XCD_CHUNKS * (256 / GRID_BLOCK));
-    if (FUSED && a.order != nullptr) chunk = (unsigned int)a.order[chunk];   // walking chunks first (IcpSchedule): speed only
+    if (FUSED) chunk = (unsigned int)a.order[chunk];          // walking chunks first (IcpSchedule): speed only
     const int i = (int)(chunk * GRID_BLOCK) + tid;
     const bool valid = i < a.n;
     MI_TL_STAMP(tl_p1, i);
+    // the chunk's class from the last iteration (requested here, used below: its round trip overlaps the moving point's)
+    // (through a per-lane address as far as the compiler can tell: it would move a wave-uniform byte into a scalar register, and wait
+    // for it, before the next branch)
+    unsigned int far_class = 0u;
+    if (FUSED) {
+        unsigned int lane_zero = 0u;
+        asm("" : "+v"(lane_zero));                           // (not volatile: that would cost every later load its scalar form)
+        far_class = a.far[chunk + lane_zero];
+    }
 
     float q[3] = {0.f, 0.f, 0.f};
     float best = __builtin_inff();
@@ -737,25 +687,20 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
 
     MI_TL_STAMP(tl_p3, best);
     // occupied_near of the query's (clamped) cell: 0 = the scan could not meet a single point (requested here, ahead of the scan)
-    bool in_reach = false;
-    if (valid) in_reach = g.occupied_near[cell_of(g, q[0], q[1], q[2])] != 0;
+    // (every lane asks -- a lane without a point has q = 0, some cell of the grid: no branch, so nothing waits for the byte here)
+    const unsigned int near_word = g.occupied_near[cell_of(g, q[0], q[1], q[2])];
     bool hard = false;
     unsigned long long walk_cycles = 0;
     unsigned int n_cand = 0u, n_rows = 0u, n_nodes = 0u, n_leaves = 0u;
     // A chunk most of whose lanes ended beyond the grid's reach last time (they will again: the flags move slowly) skips the scan:
     // all its lanes walk, each from its own starting candidate -- the walk is exact by itself, the few lanes the scan would have
     // served add little to the union the wave visits anyway, and the wave's critical path loses the scan (speed only).
-    bool walk_only = false;
-    if (FUSED && a.far != nullptr) walk_only = a.far[chunk] >= 2;
+    const bool walk_only = FUSED && (unsigned int)__builtin_amdgcn_readfirstlane((int)far_class) >= 2u;
     if (walk_only) hard = valid;
-#ifdef MISLAM_GRID_SCAN_V1
-    else if (valid) hard = grid_search<FMA, STATS>(g, q, best, bidx, bslot, n_cand, n_rows);
-#else
 #ifdef MISLAM_DEV_WAVE_TIMELINE
-    else hard = grid_search<FMA, STATS>(g, q, valid && in_reach, best, bidx, bslot, n_cand, n_rows, dev_tl) && valid;
+    else hard = grid_search<FMA, STATS>(g, q, valid, near_word, best, bidx, bslot, n_cand, n_rows, dev_tl) && valid;
 #else
-    else hard = grid_search<FMA, STATS>(g, q, valid && in_reach, best, bidx, bslot, n_cand, n_rows) && valid;   // (all lanes: the loops run in step)
-#endif
+    else hard = grid_search<FMA, STATS>(g, q, valid, near_word, best, bidx, bslot, n_cand, n_rows) && valid;   // (all lanes: the loops run in step)
 #endif
     const bool walked = __builtin_amdgcn_ballot_w64(hard) != 0ull;
 #ifdef MISLAM_DEV_WAVE_TIMELINE
@@ -770,7 +715,11 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
 #ifdef MISLAM_DEV_WALK_PRIO
         __builtin_amdgcn_s_setprio(MISLAM_DEV_WALK_PRIO);
 #endif
+#ifdef MISLAM_DEV_WALK_CAP               // (only once the registration is past its cold iterations, whose long walks are the point of them)
+        tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves, FUSED && a.state->passes >= 8 ? MISLAM_DEV_WALK_CAP : 1 << 30);
+#else
         tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves);
+#endif
 #ifdef MISLAM_DEV_WALK_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -849,7 +798,7 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
         double* row = a.rows + (size_t)chunk * ICP_ROW;
         row_store_moments(mom, row, nullptr);
         row_store_error(e0, e1, row, nullptr);
-        if (a.far != nullptr) {
+        {
             // next iteration's class of this chunk: 0 = no lane walked, 1 = some did, 2 = most lanes lie beyond the grid's reach
             const float cap = (GRID_DU_MAX - 2e-3f) * g.h_lo;
             const float cap2 = cap * cap * (1.f - 1e-5f);
@@ -866,6 +815,7 @@ hipError_t nn_grid_query(const NnGridView& g, const NnTreeView& t, const GridSea
     if (a.n <= 0) return hipSuccess;
     const dim3 grid((a.n + GRID_BLOCK - 1) / GRID_BLOCK), block(GRID_BLOCK);
     const bool fused = a.state != nullptr;
+    if (fused && (a.order == nullptr || a.far == nullptr || a.rows == nullptr || a.match_slot == nullptr)) return hipErrorInvalidValue;   // (the fused kernel does not test for them)
 #define MI_GRID_LAUNCH(F, U, S) hipLaunchKernelGGL((nn_grid_kernel<F, U, S>), grid, block, 0, s, g, t, a)
     if (a.stats != nullptr) {          // counting build of the same kernel (mi_profile_search_stats)
         if (fused) { if (fma) MI_GRID_LAUNCH(true, true, true); else MI_GRID_LAUNCH(false, true, true); }
