@@ -316,15 +316,121 @@ struct GridLane {
 #endif
 };
 
-// One batch: takes up to GRID_BATCH rows off `mask`, scans cells [x0, x1] of each that lies within r2.  BLOCK: the rows are the (up to)
-// 2 x 2 rows [blk.y0, blk.y1] x [blk.z0, blk.z1] of the nearest block instead -- named directly, their two gaps per axis computed once.
-struct GridBlockRows { int y0, y1, z0, z1; };
 #ifndef MISLAM_GRID_TRIP
 #define MISLAM_GRID_TRIP 4
 #endif
 constexpr unsigned int GRID_TRIP = MISLAM_GRID_TRIP;          // candidates per trip (a power of two, <= GRID_PTS_PAD)
 static_assert(GRID_TRIP >= 1 && GRID_TRIP <= GRID_PTS_PAD && (GRID_TRIP & (GRID_TRIP - 1)) == 0, "trip width");
 __device__ __forceinline__ unsigned int grid_trip_round(int c) { return (unsigned int)(c + (int)GRID_TRIP - 1) & ~(GRID_TRIP - 1u); }
+
+// A batch's trips dealt out over the wave.  The lockstep trip loop below lasts as long as the lane with the MOST trips has any (8.9
+// for the block's four rows, where the mean lane has 4.6): every one of them is four gathers and ~65 vector instructions for the whole
+// wave.  Here each lane first says how many trips it has (n < 32), the wave lays them end to end (prefix sum by ballots), every lane
+// writes the slots of its trips into LDS, and then lane L takes trip L, L + 64, ... -- whoever it belongs to: it reads the owner's
+// query and running best from LDS, tests the four candidates, and folds the result back with an LDS minimum.  ceil(total / 64) passes
+// instead of max(n) trips; which lane tests a candidate changes nothing (a lexicographic minimum over the same candidates).
+#ifndef MISLAM_GRID_DEAL_MAX
+#define MISLAM_GRID_DEAL_MAX 384
+#endif
+#ifndef MISLAM_GRID_DEAL_GAIN
+#define MISLAM_GRID_DEAL_GAIN 1          // deal when the passes (plus this) are fewer than the longest lane's trips
+#endif
+constexpr unsigned int GRID_DEAL_MAX = MISLAM_GRID_DEAL_MAX;
+// The wave's LDS (one wave per workgroup), 3.6 KB: at 7 waves per SIMD a CU's 160 KB leave 5.8 KB per wave.  The dealt trips and the dealt
+// rows (grid_search) never overlap in time and share it.
+struct GridLds {
+    union {
+        struct { unsigned int p[GRID_DEAL_MAX]; unsigned char owner[GRID_DEAL_MAX]; } deal;     // trip -> first slot, owner lane
+        struct { unsigned int desc[64]; uint4 m[64]; unsigned int flag[64]; } item;              // row item -> (owner << 8) | row bit; per OWNER: cell range + key; gave up
+    };
+    float4 q[64];                                              // per OWNER: its query (w: its radius, rows only)
+    unsigned long long key[64];                                // per OWNER: running minimum of the keys found for it
+    unsigned int slot[64];                                     // per OWNER: where that minimum sits in pts
+};
+__device__ __forceinline__ GridLds& grid_lds()
+{
+    __shared__ GridLds lds;
+    return lds;
+}
+// Returns false (nothing done) if dealing does not pay or does not fit; true: kbest / bslot hold the lane's results.
+template <bool FMA>
+__device__ __forceinline__ bool grid_deal_scan(const float4* __restrict__ pts, const float q[3], unsigned int n_trips, unsigned int e1, unsigned int e2,
+                                               unsigned int e3, unsigned int b0, unsigned int b1, unsigned int b2, unsigned int b3,
+                                               unsigned long long& kbest, unsigned int& bslot, unsigned int& dev_passes)
+{
+    static_assert(GRID_TRIP == 4, "a dealt trip is four candidates");
+    GridLds& L = grid_lds();
+    unsigned int* const deal_p = L.deal.p;
+    unsigned char* const deal_owner = L.deal.owner;
+    float4* const deal_q = L.q;
+    unsigned long long* const deal_key = L.key;
+    unsigned int* const deal_slot = L.slot;
+    const int lane = (int)threadIdx.x & 63;
+    if (__builtin_amdgcn_ballot_w64(n_trips >= 32u) != 0ull) return false;
+    // counts -> exclusive prefix, total and maximum, bit by bit: ballots, mbcnt and scalar arithmetic, no exchange
+    const unsigned long long B0 = __builtin_amdgcn_ballot_w64((n_trips & 1u) != 0u), B1 = __builtin_amdgcn_ballot_w64((n_trips & 2u) != 0u),
+                             B2 = __builtin_amdgcn_ballot_w64((n_trips & 4u) != 0u), B3 = __builtin_amdgcn_ballot_w64((n_trips & 8u) != 0u),
+                             B4 = __builtin_amdgcn_ballot_w64((n_trips & 16u) != 0u);
+    const unsigned int total = (unsigned int)__builtin_popcountll(B0) + 2u * (unsigned int)__builtin_popcountll(B1) + 4u * (unsigned int)__builtin_popcountll(B2) +
+                               8u * (unsigned int)__builtin_popcountll(B3) + 16u * (unsigned int)__builtin_popcountll(B4);
+    unsigned int longest = 0u;
+    {
+        unsigned long long cand = ~0ull;                        // lanes that still can hold the maximum
+        const unsigned long long B[5] = {B0, B1, B2, B3, B4};
+#pragma unroll
+        for (int b = 4; b >= 0; b--) {
+            const unsigned long long m = B[b] & cand;
+            if (m != 0ull) { longest |= 1u << b; cand = m; }
+        }
+    }
+    const unsigned int passes = (total + 63u) >> 6;
+    if (total > GRID_DEAL_MAX || passes + MISLAM_GRID_DEAL_GAIN >= longest) return false;
+    auto below = [](unsigned long long m) { return (unsigned int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u)); };
+    const unsigned int first = below(B0) + 2u * below(B1) + 4u * below(B2) + 8u * below(B3) + 16u * below(B4);
+    deal_q[lane] = make_float4(q[0], q[1], q[2], 0.f);
+    deal_key[lane] = kbest;
+    for (unsigned int k = 0; k < longest; k++) {                // (wave-uniform bound: the lane with the most trips)
+        if (k < n_trips) {
+            const unsigned int t = k * GRID_TRIP;
+            deal_p[first + k] = (t >= e2 ? (t >= e3 ? b3 : b2) : (t >= e1 ? b1 : b0)) + t;
+            deal_owner[first + k] = (unsigned char)lane;
+        }
+    }
+    __syncthreads();                                            // (one wave per workgroup: orders the LDS traffic)
+    for (unsigned int base = 0; base < total; base += 64u) {
+        const unsigned int idx = base + (unsigned int)lane;
+        const bool have = idx < total;
+        const unsigned int p = have ? deal_p[idx] : 0u;
+        const unsigned int owner = have ? (unsigned int)deal_owner[idx] : (unsigned int)lane;
+        const float4 oq = deal_q[owner];
+        unsigned long long kb = deal_key[owner];
+        const unsigned long long kb0 = kb;
+        unsigned int slot = 0u;
+        const float4* __restrict__ pp = pts + p;
+        const float4 cs[4] = {pp[0], pp[1], pp[2], pp[3]};
+#pragma unroll
+        for (int j4 = 0; j4 < 4; j4++) {
+            const float d = sq3<FMA>(cs[j4].x - oq.x, cs[j4].y - oq.y, cs[j4].z - oq.z);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(cs[j4].w);
+            const bool better = key < kb;
+            kb = better ? key : kb;
+            slot = better ? p + (unsigned int)j4 : slot;
+        }
+        const bool won = have && kb < kb0;
+        if (won) atomicMin(&deal_key[owner], kb);
+        // LDS operations of one wave complete in program order: every lane now reads the minimum of the pass, and whoever holds it says where
+        if (won && deal_key[owner] == kb) deal_slot[owner] = slot;
+        dev_passes += 1u;
+    }
+    __syncthreads();
+    const unsigned long long kfin = deal_key[lane];
+    if (kfin < kbest) { kbest = kfin; bslot = deal_slot[lane]; }
+    return true;
+}
+
+// One batch: takes up to GRID_BATCH rows off `mask`, scans cells [x0, x1] of each that lies within r2.  BLOCK: the rows are the (up to)
+// 2 x 2 rows [blk.y0, blk.y1] x [blk.z0, blk.z1] of the nearest block instead -- named directly, their two gaps per axis computed once.
+struct GridBlockRows { int y0, y1, z0, z1; };
 // `reach` (BLOCK only): occupied_near of the query's cell, a byte that is still on its way from memory when the block's offsets are
 // requested -- it only decides whether their runs count, so the two round trips overlap.
 template <bool FMA, bool STATS, bool BLOCK>
@@ -396,6 +502,16 @@ __device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, uns
     const unsigned int t_last = e4 >= GRID_TRIP ? e4 - GRID_TRIP : 0u;
     unsigned long long kbest = s.kbest;
     unsigned int bslot = s.bslot;
+#ifndef MISLAM_GRID_NO_DEAL
+    {
+        unsigned int dev_passes = 0u;
+        const bool dealt = grid_deal_scan<FMA>(pts, s.q, e4 / GRID_TRIP, e1, e2, e3, b0, b1, b2, b3, kbest, bslot, dev_passes);
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+        if (BLOCK) s.trips_block += dev_passes; else s.trips_rest += dev_passes;
+#endif
+        if (dealt) { s.kbest = kbest; s.bslot = bslot; return; }
+    }
+#endif
 #ifdef MISLAM_DEV_BLOCK_CAP             // timing experiment (counting build only): wrong answers
     for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < e4 && !(STATS && BLOCK && t >= MISLAM_DEV_BLOCK_CAP)) != 0ull; t += GRID_TRIP) {
 #else
@@ -499,11 +615,13 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
     // through an LDS minimum; what is not dealt out stays in `mask` for its owner.  Which lane does a row changes nothing (a lexicographic minimum over the same candidates).
     {
         constexpr int GRID_ITEM_ROWS = MISLAM_GRID_ITEM_ROWS;
-        __shared__ unsigned int item_desc[64];                  // (owner lane << 8) | row bit
-        __shared__ float4 item_q[64];                           // per OWNER: query, radius
-        __shared__ uint4 item_m[64];                            // per OWNER: cell range, key
-        __shared__ unsigned long long item_key[64];             // per OWNER: running minimum of the keys its items found
-        __shared__ unsigned int item_slot[64], item_flag[64];
+        GridLds& L = grid_lds();
+        unsigned int* const item_desc = L.item.desc;            // (owner lane << 8) | row bit
+        float4* const item_q = L.q;                             // per OWNER: query, radius
+        uint4* const item_m = L.item.m;                         // per OWNER: cell range, key
+        unsigned long long* const item_key = L.key;             // per OWNER: running minimum of the keys its items found
+        unsigned int* const item_slot = L.slot;
+        unsigned int* const item_flag = L.item.flag;
         const int lane = (int)threadIdx.x & 63;
         const int n_all = __builtin_popcount(mask);
         const int n_items = n_all <= GRID_ITEM_ROWS ? n_all : 0;       // (a lane with more rows than that -- at the cloud's edge -- keeps them all)
