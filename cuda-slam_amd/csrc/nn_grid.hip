@@ -336,13 +336,14 @@ __device__ __forceinline__ unsigned int grid_trip_round(int c) { return (unsigne
 #define MISLAM_GRID_DEAL_GAIN 1          // deal when the passes (plus this) are fewer than the longest lane's trips
 #endif
 constexpr unsigned int GRID_DEAL_MAX = MISLAM_GRID_DEAL_MAX;
-// The wave's LDS (one wave per workgroup), 3.6 KB: at 7 waves per SIMD a CU's 160 KB leave 5.8 KB per wave.  The dealt trips and the dealt
+// The wave's LDS (one wave per workgroup), 3.9 KB: at 7 waves per SIMD a CU's 160 KB leave 5.8 KB per wave.  The dealt trips and the dealt
 // rows (grid_search) never overlap in time and share it.
 struct GridLds {
     union {
         struct { unsigned int p[GRID_DEAL_MAX]; unsigned char owner[GRID_DEAL_MAX]; } deal;     // trip -> first slot, owner lane
-        struct { unsigned int desc[64]; uint4 m[64]; unsigned int flag[64]; } item;              // row item -> (owner << 8) | row bit; per OWNER: cell range + key; gave up
+        struct { unsigned int desc[64]; uint4 m[64]; } item;                                     // row item -> (owner << 8) | row bit; per OWNER: cell range + key
     };
+    unsigned int flag[64];                                     // per OWNER: a dealt row was crowded, it gives up
     float4 q[64];                                              // per OWNER: its query (w: its radius, rows only)
     unsigned long long key[64];                                // per OWNER: running minimum of the keys found for it
     unsigned int slot[64];                                     // per OWNER: where that minimum sits in pts
@@ -389,11 +390,12 @@ __device__ __forceinline__ bool grid_deal_scan(const float4* __restrict__ pts, c
     const unsigned int first = below(B0) + 2u * below(B1) + 4u * below(B2) + 8u * below(B3) + 16u * below(B4);
     deal_q[lane] = make_float4(q[0], q[1], q[2], 0.f);
     deal_key[lane] = kbest;
+    const unsigned char mine = (unsigned char)lane;
     for (unsigned int k = 0; k < longest; k++) {                // (wave-uniform bound: the lane with the most trips)
         if (k < n_trips) {
             const unsigned int t = k * GRID_TRIP;
             deal_p[first + k] = (t >= e2 ? (t >= e3 ? b3 : b2) : (t >= e1 ? b1 : b0)) + t;
-            deal_owner[first + k] = (unsigned char)lane;
+            deal_owner[first + k] = mine;
         }
     }
     __syncthreads();                                            // (one wave per workgroup: orders the LDS traffic)
@@ -621,7 +623,7 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
         uint4* const item_m = L.item.m;                         // per OWNER: cell range, key
         unsigned long long* const item_key = L.key;             // per OWNER: running minimum of the keys its items found
         unsigned int* const item_slot = L.slot;
-        unsigned int* const item_flag = L.item.flag;
+        unsigned int* const item_flag = L.flag;
         const int lane = (int)threadIdx.x & 63;
         const int n_all = __builtin_popcount(mask);
         const int n_items = n_all <= GRID_ITEM_ROWS ? n_all : 0;       // (a lane with more rows than that -- at the cloud's edge -- keeps them all)
