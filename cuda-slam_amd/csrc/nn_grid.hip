@@ -336,23 +336,6 @@ __device__ __forceinline__ unsigned int grid_trip_round(int c) { return (unsigne
 #define MISLAM_GRID_DEAL_GAIN 1          // deal when the passes (plus this) are fewer than the longest lane's trips
 #endif
 constexpr unsigned int GRID_DEAL_MAX = MISLAM_GRID_DEAL_MAX;
-// The wave's LDS (one wave per workgroup), 3.9 KB: at 7 waves per SIMD a CU's 160 KB leave 5.8 KB per wave.  The dealt trips and the dealt
-// rows (grid_search) never overlap in time and share it.
-struct GridLds {
-    union {
-        struct { unsigned int p[GRID_DEAL_MAX]; unsigned char owner[GRID_DEAL_MAX]; } deal;     // trip -> first slot, owner lane
-        struct { unsigned int desc[64]; uint4 m[64]; } item;                                     // row item -> (owner << 8) | row bit; per OWNER: cell range + key
-    };
-    unsigned int flag[64];                                     // per OWNER: a dealt row was crowded, it gives up
-    float4 q[64];                                              // per OWNER: its query (w: its radius, rows only)
-    unsigned long long key[64];                                // per OWNER: running minimum of the keys found for it
-    unsigned int slot[64];                                     // per OWNER: where that minimum sits in pts
-};
-__device__ __forceinline__ GridLds& grid_lds()
-{
-    __shared__ GridLds lds;
-    return lds;
-}
 // Returns false (nothing done) if dealing does not pay or does not fit; true: kbest / bslot hold the lane's results.
 template <bool FMA>
 __device__ __forceinline__ bool grid_deal_scan(const float4* __restrict__ pts, const float q[3], unsigned int n_trips, unsigned int e1, unsigned int e2,
@@ -360,12 +343,12 @@ __device__ __forceinline__ bool grid_deal_scan(const float4* __restrict__ pts, c
                                                unsigned long long& kbest, unsigned int& bslot, unsigned int& dev_passes)
 {
     static_assert(GRID_TRIP == 4, "a dealt trip is four candidates");
-    GridLds& L = grid_lds();
-    unsigned int* const deal_p = L.deal.p;
-    unsigned char* const deal_owner = L.deal.owner;
-    float4* const deal_q = L.q;
-    unsigned long long* const deal_key = L.key;
-    unsigned int* const deal_slot = L.slot;
+    // (3.6 KB of LDS per wave -- one wave per workgroup; at 7 waves per SIMD a CU's 160 KB leave 5.8 KB each)
+    __shared__ unsigned int deal_p[GRID_DEAL_MAX];             // trip -> slot of its first candidate
+    __shared__ unsigned char deal_owner[GRID_DEAL_MAX];        // trip -> the lane it belongs to
+    __shared__ float4 deal_q[64];                              // per OWNER: its query
+    __shared__ unsigned long long deal_key[64];                // per OWNER: running minimum of the keys found for it
+    __shared__ unsigned int deal_slot[64];                     // per OWNER: where that minimum sits in pts
     const int lane = (int)threadIdx.x & 63;
     if (__builtin_amdgcn_ballot_w64(n_trips >= 32u) != 0ull) return false;
     // counts -> exclusive prefix, total and maximum, bit by bit: ballots, mbcnt and scalar arithmetic, no exchange
@@ -422,7 +405,9 @@ __device__ __forceinline__ bool grid_deal_scan(const float4* __restrict__ pts, c
         if (won) atomicMin(&deal_key[owner], kb);
         // LDS operations of one wave complete in program order: every lane now reads the minimum of the pass, and whoever holds it says where
         if (won && deal_key[owner] == kb) deal_slot[owner] = slot;
+#ifdef MISLAM_DEV_WAVE_TIMELINE
         dev_passes += 1u;
+#endif
     }
     __syncthreads();
     const unsigned long long kfin = deal_key[lane];
@@ -606,104 +591,10 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
         const bool covered = x0 >= xa0 && x1 <= xa1;           // the block's rows need no second look
         mask = s.alive ? grid_rows_mask(y0 - s.cy + GRID_ROWS_R, y1 - s.cy + GRID_ROWS_R, z0 - s.cz + GRID_ROWS_R, z1 - s.cz + GRID_ROWS_R) & ~(covered ? block : 0u) : 0u;
     }
-#ifndef MISLAM_GRID_ITEM_ROWS
-#define MISLAM_GRID_ITEM_ROWS 12
-#endif
-#ifndef MISLAM_GRID_NO_ITEMS
-    // ---- the leftover rows, dealt out over the whole wave.  About one lane in five has any (its neighbour lies beyond the block, or
-    // the radius still pokes out of it), one to four rows each -- scanned by their owners they cost the wave more trips than the block
-    // did, with a dozen lanes working.  So the leftover rows of the lanes that have at most GRID_ITEM_ROWS of them become ITEMS, the
-    // first 64 of the wave: lane L takes item L -- some owner's row -- scans it against the owner's query and hands the result back
-    // through an LDS minimum; what is not dealt out stays in `mask` for its owner.  Which lane does a row changes nothing (a lexicographic minimum over the same candidates).
-    {
-        constexpr int GRID_ITEM_ROWS = MISLAM_GRID_ITEM_ROWS;
-        GridLds& L = grid_lds();
-        unsigned int* const item_desc = L.item.desc;            // (owner lane << 8) | row bit
-        float4* const item_q = L.q;                             // per OWNER: query, radius
-        uint4* const item_m = L.item.m;                         // per OWNER: cell range, key
-        unsigned long long* const item_key = L.key;             // per OWNER: running minimum of the keys its items found
-        unsigned int* const item_slot = L.slot;
-        unsigned int* const item_flag = L.flag;
-        const int lane = (int)threadIdx.x & 63;
-        const int n_all = __builtin_popcount(mask);
-        const int n_items = n_all <= GRID_ITEM_ROWS ? n_all : 0;       // (a lane with more rows than that -- at the cloud's edge -- keeps them all)
-        if (__builtin_amdgcn_ballot_w64(n_items > 0) != 0ull) {
-            // exclusive prefix sum of the counts (four bits) over the lanes, bit by bit: ballots and mbcnt, no exchange
-            static_assert(GRID_ITEM_ROWS < 16, "the prefix sum below adds four bits");
-            const unsigned long long b0 = __builtin_amdgcn_ballot_w64((n_items & 1) != 0), b1 = __builtin_amdgcn_ballot_w64((n_items & 2) != 0),
-                                     b2 = __builtin_amdgcn_ballot_w64((n_items & 4) != 0), b3 = __builtin_amdgcn_ballot_w64((n_items & 8) != 0);
-            auto below = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u)); };
-            const int first = below(b0) + 2 * below(b1) + 4 * below(b2) + 8 * below(b3);
-            const int total = __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1) + 4 * __builtin_popcountll(b2) + 8 * __builtin_popcountll(b3);
-            {
-                const int x0 = (int)fmaxf(fx0, 0.f), x1 = (int)fminf(fx1, (float)(g.nx - 1));
-                item_q[lane] = make_float4(s.q[0], s.q[1], s.q[2], r2);
-                item_m[lane] = make_uint4((unsigned int)x0, (unsigned int)x1, (unsigned int)(s.kbest >> 32), (unsigned int)s.kbest);
-                item_key[lane] = s.kbest;
-                item_flag[lane] = 0u;
-                {
-                    unsigned int mm = mask;
-                    // owners publish their items -- the first 64 of the wave; the others stay in `mask` (as many rounds as the lane with
-                    // the most items has)
-                    for (int k = 0; __builtin_amdgcn_ballot_w64(k < n_items && first + k < 64) != 0ull; k++) {
-                        const int b = mm != 0u ? __builtin_ctz(mm) : 0;
-                        if (k < n_items && first + k < 64) { item_desc[first + k] = ((unsigned int)lane << 8) | (unsigned int)b; mask &= ~(1u << b); }
-                        mm &= mm - 1u;
-                    }
-                    __syncthreads();                            // (one wave per workgroup: orders the LDS traffic)
-                    const bool have = lane < total;
-                    const unsigned int desc = have ? item_desc[lane] : 0u;
-                    const int owner = (int)(desc >> 8), b = (int)(desc & 0xffu);
-                    const float4 oq = item_q[owner];
-                    const uint4 om = item_m[owner];
-                    const float ou1 = cell_u(oq.y, g.oy, g.inv_h), ou2 = cell_u(oq.z, g.oz, g.inv_h);
-                    const int oz = (b * ((256 + GRID_ROWS_W - 1) / GRID_ROWS_W)) >> 8, oy = b - GRID_ROWS_W * oz;
-                    const int iy = cell_index(ou1, g.ny) + oy - GRID_ROWS_R, iz = cell_index(ou2, g.nz) + oz - GRID_ROWS_R;
-                    const float gy = gap_cells(ou1, iy) * g.h_lo, gz = gap_cells(ou2, iz) * g.h_lo;
-                    const bool ok = have && (int)om.y >= (int)om.x && gy * gy + gz * gz <= oq.w;
-                    const unsigned int rb = ((unsigned int)iz * (unsigned int)g.ny + (unsigned int)iy) * (unsigned int)g.nx;
-                    const unsigned int p0 = g.cell_start[ok ? rb + om.x : 0u];
-                    int cnt = (int)(g.cell_start[ok ? rb + om.y + 1u : 0u] - p0);
-                    if (STATS && ok) { s.n_rows += 1u; }
-                    if (cnt > GRID_CAND_BUDGET / GRID_ITEM_ROWS) { item_flag[owner] = 1u; cnt = 0; }       // crowded: its owner gives up
-                    const unsigned int c4 = grid_trip_round(cnt), t_last = c4 >= GRID_TRIP ? c4 - GRID_TRIP : 0u;
-                    unsigned long long kb = ((unsigned long long)om.z << 32) | om.w;
-                    const unsigned long long kb0 = kb;
-                    unsigned int slot = 0u;
-                    for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < c4) != 0ull; t += GRID_TRIP) {
-#ifdef MISLAM_DEV_WAVE_TIMELINE
-                        s.trips_rest += 1;
-#endif
-                        const unsigned int p = p0 + min(t, t_last);
-                        const float4* __restrict__ pp = g.pts + p;
-                        float4 cs[GRID_TRIP];
-#pragma unroll
-                        for (unsigned int j4 = 0; j4 < GRID_TRIP; j4++) cs[j4] = pp[j4];
-#pragma unroll
-                        for (unsigned int j4 = 0; j4 < GRID_TRIP; j4++) {
-                            const float d = sq3<FMA>(cs[j4].x - oq.x, cs[j4].y - oq.y, cs[j4].z - oq.z);
-                            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(cs[j4].w);
-                            const bool better = key < kb;
-                            kb = better ? key : kb;
-                            slot = better ? p + (unsigned int)j4 : slot;
-                        }
-                    }
-                    // back to the owners: the minimum of the keys, then the slot of whoever holds it (keys of distinct points differ)
-                    if (kb < kb0) atomicMin(&item_key[owner], kb);
-                    __syncthreads();
-                    if (kb < kb0 && item_key[owner] == kb) item_slot[owner] = slot;
-                    __syncthreads();
-#ifdef MISLAM_DEV_WAVE_TIMELINE
-                    s.batches_rest += 256;                      // (item passes count in the high byte)
-#endif
-                }
-                const unsigned long long kfin = item_key[lane];
-                if (kfin < s.kbest) { s.kbest = kfin; s.bslot = item_slot[lane]; }
-                if (item_flag[lane] != 0u) s.alive = false;
-            }
-        }
-    }
-#endif
+    // ---- the leftover rows -- about one lane in five has any (its neighbour lies beyond the block, or the radius still pokes out of it),
+    // one to four each, more at the cloud's edge -- four per lane and round, their trips dealt out over the wave like the block's.  (Round 3
+    // first dealt the ROWS out, one per lane, before there was a way to deal trips: git show eefc579:cuda-slam_amd/csrc/nn_grid.hip; with the
+    // trips dealt the two are as fast, at 1e5, 1e6 and 1e7 points, and this is the shorter code.)
     while (__builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) {
         // the cells of a row from the radius as it stands now: one range for the whole batch (a superset of what each row's own
         // gap would leave of it)
@@ -850,7 +741,12 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
 #endif
     }
 #endif
-    if (valid && best < __builtin_inff()) a.keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
+    // the point's index again, from the chunk number (a scalar) as far as the compiler can tell a different one: kept from the prologue it
+    // would sit in two vector registers through the whole search, which is short of them
+    unsigned int chunk_again = chunk;
+    asm("" : "+s"(chunk_again));
+    const int io = (int)(chunk_again * GRID_BLOCK) + tid;
+    if (valid && best < __builtin_inff()) a.keys[io] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
     // measurement hook (mi_profile_search_stats).  Kept BEHIND the walk: a global atomic ahead of it would stop the compiler from
     // using scalar loads for the hierarchy (it can no longer prove those arrays unwritten)
     if (STATS) {
@@ -909,12 +805,12 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
             const bool mine = gidx >= a.shard_lo && gidx < a.shard_hi;
             const bool kept = a.filter_pairs ? (best < a.max_distance_squared) : true;
             if (hard) bslot = g.slot_of[gidx - g.index_base];   // a walk's winner: the hierarchy keeps its own order
-            a.match_slot[i] = bslot;
+            a.match_slot[io] = bslot;
             if (mine && kept) {
                 const float4 p = g.pts[bslot];
                 pair_moments(mom, q[0], q[1], q[2], p.x, p.y, p.z);
             }
-        } else if (valid) a.match_slot[i] = ~0u;
+        } else if (valid) a.match_slot[io] = ~0u;
         double* row = a.rows + (size_t)chunk * ICP_ROW;
         row_store_moments(mom, row, nullptr);
         row_store_error(e0, e1, row, nullptr);
