@@ -120,14 +120,16 @@ __global__ __launch_bounds__(ICP_ROW_POINTS) void icp_moments_rows_kernel(IcpVie
 // and the short grid-only chunks fill in behind them instead of the other way round (a wave that walks lives ~5x longer).  Scheduling
 // only: which workgroup handles which chunk never changes a result.
 constexpr int ROWS_REDUCE_THREADS = 1024;
+// The two jobs are independent, so with a schedule the launch is twice as wide: workgroups [0, n_sum) add their slices up, workgroups
+// [n_sum, 2 n_sum) deal the next search its order for theirs -- the launch lasts as long as the longer of the two, not as their sum.
 __global__ __launch_bounds__(ROWS_REDUCE_THREADS) void icp_rows_reduce_kernel(const double* __restrict__ rows, int nrows, int rows_per_block,
-                                                                             double* __restrict__ out, IcpSchedule sched)
+                                                                             double* __restrict__ out, IcpSchedule sched, int n_sum)
 {
     constexpr int STRIPS = ROWS_REDUCE_THREADS / ICP_ROW;      // 56 strips of rows, 18 columns each
     __shared__ double lds[STRIPS * ICP_ROW];
-    if (sched.order != nullptr) {
+    if ((int)blockIdx.x >= n_sum) {
         __shared__ int s_far, s_near, s_base_far, s_base_near;
-        const int lo = blockIdx.x * rows_per_block;
+        const int lo = ((int)blockIdx.x - n_sum) * rows_per_block;
         const int hi = lo + rows_per_block < nrows ? lo + rows_per_block : nrows;
         if (threadIdx.x == 0) { s_far = 0; s_near = 0; }
         __syncthreads();
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(ROWS_REDUCE_THREADS) void icp_rows_reduce_kernel(co
                 else sched.order[nrows - 1 - (s_base_near + atomicAdd(&s_near, 1))] = r;
             }
         }
-        __syncthreads();
+        return;
     }
     const int k = threadIdx.x % ICP_ROW, strip = threadIdx.x / ICP_ROW;
     const int lo = blockIdx.x * rows_per_block;
@@ -494,7 +496,7 @@ hipError_t icp_rows_reduce(const double* rows, int nrows, double* part, hipStrea
     const int per = (nrows + g - 1) / g;
     IcpSchedule sc{};
     if (sched != nullptr) sc = *sched;
-    hipLaunchKernelGGL(icp_rows_reduce_kernel, dim3(g), dim3(ROWS_REDUCE_THREADS), 0, s, rows, nrows, per, part, sc);
+    hipLaunchKernelGGL(icp_rows_reduce_kernel, dim3(sched != nullptr && sc.order != nullptr ? 2 * g : g), dim3(ROWS_REDUCE_THREADS), 0, s, rows, nrows, per, part, sc, g);
     return hipGetLastError();
 }
 

@@ -108,7 +108,7 @@ def test_result_independent_of_host_check_interval(ctx, capi, bunny, sync_every)
 @pytest.mark.parametrize("cuda_rules", [False, True])
 def test_search_strategy_does_not_change_the_registration(ctx, capi, bunny, cuda_rules):
     # every pair, the box hierarchy and the cell grid return the same keys, and every path -- the grid's fused iteration
-    # included -- adds an iteration's sums in the same per-128-point rows: the whole run is bitwise identical
+    # included -- adds an iteration's sums in the same per-64-point rows: the whole run is bitwise identical
     before, after = bunny
     runs = []
     for nn_mode in (capi.NN_BRUTEFORCE, capi.NN_TREE, capi.NN_GRID):
