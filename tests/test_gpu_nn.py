@@ -88,7 +88,7 @@ def test_tree_equals_bruteforce_on_clustered_and_degenerate_clouds(ctx, capi, mo
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), indexed
 
 
-@pytest.mark.parametrize("ppc", ["0.25", "1", "8", "64"])
+@pytest.mark.parametrize("ppc", ["0.25", "1", "2", "3", "8", "16", "64"])   # 2-3: around the most trips one deal takes; 16: lanes with 32 trips (lockstep)
 @pytest.mark.parametrize("mode", [0, 1])
 def test_grid_is_exact_at_every_cell_size(capi, oracle, monkeypatch, ppc, mode):
     # the grid's cell size is a speed knob (MISLAM_GRID_PPC = mean points per cell, read at context creation): from cells far
