@@ -622,7 +622,7 @@ static int ensure_tree(mi_ctx* c, int m_local, int index_base)
     MI_TRY(c->tboxes.reserve((size_t)4 * n_pad));
     MI_TRY(c->tleaf.reserve((size_t)n_leaves * (3 * TREE_LEAF / 4)));
     MI_TRY(c->tidx.reserve((size_t)n_leaves * TREE_LEAF));
-    MI_TRY(c->tboxes6.reserve((size_t)6 * (2 * (size_t)n_pad - 1 + 8)));
+    MI_TRY(c->tboxes6.reserve((size_t)12 * ((size_t)n_pad + 6)));        // pairs of nodes (nn_tree.h), incl. the padding a step may read
     TreeBuildArgs a{};
     MI_TRY(morton_args(c, c->tx.p, c->ty.p, c->tz.p, m_local, c->torder_out.p, &a.morton));
     a.index_base = index_base; a.n_leaves = n_leaves; a.n_pad = n_pad;

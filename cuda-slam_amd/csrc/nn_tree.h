@@ -19,13 +19,19 @@ constexpr int TREE_MAX_HEIGHT = 24;
 constexpr int TREE_XCD_CHUNKS = 32;
 constexpr int TREE_BLOCK_THREADS = 64;         // one wave per workgroup: a walk is wave-wide, nothing is shared between waves, no LDS
 
+// float offset of node i's lo.x in NnTreeView::boxes6 (its other components follow two floats apart): odd i is the first of its pair, even
+// i (and the root, alone in pair 0) the second
+__host__ __device__ inline size_t tree_box_offset(int i) { return (size_t)((i + 1) >> 1) * 12 + (size_t)((i & 1) ^ 1); }
+
 struct NnTreeView {
     int n_pad;                        // leaf count padded to a power of two (padding leaves carry empty boxes)
     int height;                       // log2(n_pad)
     int n_leaves;                     // real leaves: a node is empty iff the first leaf below it is >= n_leaves
-    const float* boxes6;              // node i: lo.xyz hi.xyz, 24 bytes; implicit heap, children of i are 2i+1 and 2i+2, leaves start at
-                                      // n_pad-1, so the 2^k descendants k levels below a node are contiguous (+ 48 floats of padding: a
-                                      // step always reads eight boxes)
+    const float* boxes6;              // node boxes, implicit heap (children of i are 2i+1 and 2i+2, leaves start at n_pad-1, so the 2^k
+                                      // descendants k levels below a node are contiguous), SIBLINGS INTERLEAVED: pair q = nodes 2q-1, 2q as
+                                      // lo.x lo.x' lo.y lo.y' lo.z lo.z' hi.x hi.x' hi.y hi.y' hi.z hi.z' (48 bytes; tree_box_offset) -- the
+                                      // walk bounds two boxes per packed instruction straight out of its scalar loads; a step reads four
+                                      // consecutive pairs (+ padding pairs at the end: a step always reads eight boxes)
     const float4* leaf_soa;           // leaf f: x[TREE_LEAF], y[TREE_LEAF], z[TREE_LEAF] (3*TREE_LEAF/4 float4; no index word)
     const int* leaf_idx;              // GLOBAL index of sorted slot s (read only for the winner and on exact ties)
 };
@@ -48,7 +54,7 @@ struct TreeBuildArgs {
     int n_leaves, n_pad;
     float4* pts;                      // scratch: n_leaves * TREE_LEAF sorted points (x, y, z, global-index bits)
     float4* boxes;                    // scratch: 2 * (2*n_pad - 1) float4 (lo, hi per node)
-    float* boxes6;                    // 6 * (2*n_pad - 1) + 48 floats
+    float* boxes6;                    // 12 floats per pair of nodes: 12 * (n_pad + 5) floats
     float4* leaf_soa;                 // n_leaves * 3 * TREE_LEAF / 4 float4
     int* leaf_idx;                    // n_leaves * TREE_LEAF
 };

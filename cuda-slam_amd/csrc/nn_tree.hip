@@ -199,16 +199,21 @@ __global__ __launch_bounds__(256) void tree_level_kernel(int first, int count, f
     boxes[2 * node + 1] = make_float4(fmaxf(c.x, d.x), fmaxf(c.y, d.y), fmaxf(c.z, d.z), 0.f);
 }
 
-// node boxes as 6 floats (the wide walk reads eight consecutive ones per step); the tail padding gets empty boxes
+// node boxes for the wide walk, SIBLINGS INTERLEAVED (NnTreeView::boxes6): pair q holds nodes 2q-1 and 2q component by component; the tail
+// padding (and the unused first half of pair 0) gets empty boxes
 __global__ __launch_bounds__(256) void tree_pack_boxes6_kernel(const float4* __restrict__ boxes, int n_nodes, int n_out, float* __restrict__ boxes6)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_out) return;
     float4 lo = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
     float4 hi = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), 0.f);
+    if (i == 0) {                                              // (the half of pair 0 that is nobody's)
+        float* e = boxes6;
+        e[0] = lo.x; e[2] = lo.y; e[4] = lo.z; e[6] = hi.x; e[8] = hi.y; e[10] = hi.z;
+    }
     if (i < n_nodes) { lo = boxes[2 * (size_t)i]; hi = boxes[2 * (size_t)i + 1]; }
-    float* o = boxes6 + 6 * (size_t)i;
-    o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = hi.x; o[4] = hi.y; o[5] = hi.z;
+    float* o = boxes6 + tree_box_offset(i);
+    o[0] = lo.x; o[2] = lo.y; o[4] = lo.z; o[6] = hi.x; o[8] = hi.y; o[10] = hi.z;
 }
 
 __global__ __launch_bounds__(256) void tree_pack_leaves_kernel(const float4* __restrict__ pts, int n_slots, float* __restrict__ soa,

@@ -75,25 +75,31 @@ __device__ __forceinline__ void unpack_start(unsigned long long k0, float& best,
 // prunes).  First the child that is nearest for most lanes, then the others in index order.  Exactness is the per-lane rule
 // unchanged: a lane's true neighbour lies in a child that lane needs at every step, needed children are never dropped, skipped
 // ones have a bound strictly above that lane's best.  Call with any subset of a wave's lanes active.
+// b: the node's lo.x in NnTreeView::boxes6 (siblings interleaved: its other components follow two floats apart)
 template <bool FMA>
 __device__ __forceinline__ float box6_bound(const float* __restrict__ b, const float s[3])
 {
-    const float ex = fmaxf(fmaxf(b[0] - s[0], s[0] - b[3]), 0.f);
-    const float ey = fmaxf(fmaxf(b[1] - s[1], s[1] - b[4]), 0.f);
-    const float ez = fmaxf(fmaxf(b[2] - s[2], s[2] - b[5]), 0.f);
+    const float ex = fmaxf(fmaxf(b[0] - s[0], s[0] - b[6]), 0.f);
+    const float ey = fmaxf(fmaxf(b[2] - s[1], s[1] - b[8]), 0.f);
+    const float ez = fmaxf(fmaxf(b[4] - s[2], s[2] - b[10]), 0.f);
     return sq3<FMA>(ex, ey, ez);
 }
 
-// the bounds of two boxes at once: the squares and sums as packed fp32 operations (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 -- the
-// same IEEE operations as the single ones, two results per issue slot)
+// the bounds of the two boxes of one PAIR (twelve floats: lo.x lo.x' lo.y lo.y' lo.z lo.z' hi.x hi.x' ...) at once: the gaps, the squares
+// and the sums as packed fp32 operations (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 -- the same IEEE operations as the single ones, two
+// results per issue slot), the pair's components coming straight out of the scalar loads as register pairs
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool FMA>
-__device__ __forceinline__ f32x2 box6_bound2(const float* __restrict__ b0, const float* __restrict__ b1, const float s[3])
+__device__ __forceinline__ f32x2 box6_bound2(const float* __restrict__ pr, const float s[3])
 {
+    const f32x2 sx = {s[0], s[0]}, sy = {s[1], s[1]}, sz = {s[2], s[2]};
+    const f32x2 ax = (f32x2){pr[0], pr[1]} - sx, bx = sx - (f32x2){pr[6], pr[7]};
+    const f32x2 ay = (f32x2){pr[2], pr[3]} - sy, by = sy - (f32x2){pr[8], pr[9]};
+    const f32x2 az = (f32x2){pr[4], pr[5]} - sz, bz = sz - (f32x2){pr[10], pr[11]};
     f32x2 ex, ey, ez;
-    ex.x = fmaxf(fmaxf(b0[0] - s[0], s[0] - b0[3]), 0.f); ex.y = fmaxf(fmaxf(b1[0] - s[0], s[0] - b1[3]), 0.f);
-    ey.x = fmaxf(fmaxf(b0[1] - s[1], s[1] - b0[4]), 0.f); ey.y = fmaxf(fmaxf(b1[1] - s[1], s[1] - b1[4]), 0.f);
-    ez.x = fmaxf(fmaxf(b0[2] - s[2], s[2] - b0[5]), 0.f); ez.y = fmaxf(fmaxf(b1[2] - s[2], s[2] - b1[5]), 0.f);
+    ex.x = fmaxf(fmaxf(ax.x, bx.x), 0.f); ex.y = fmaxf(fmaxf(ax.y, bx.y), 0.f);
+    ey.x = fmaxf(fmaxf(ay.x, by.x), 0.f); ey.y = fmaxf(fmaxf(ay.y, by.y), 0.f);
+    ez.x = fmaxf(fmaxf(az.x, bz.x), 0.f); ez.y = fmaxf(fmaxf(az.y, bz.y), 0.f);
     if constexpr (FMA) return __builtin_elementwise_fma(ez, ez, __builtin_elementwise_fma(ey, ey, ex * ex));
     else return (ex * ex + ey * ey) + ez * ez;
 }
@@ -156,7 +162,7 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
         }
     };
     {
-        const float root_lb = box6_bound<FMA>(boxes6, p);
+        const float root_lb = box6_bound<FMA>(boxes6 + tree_box_offset(0), p);
         if (__builtin_amdgcn_ballot_w64(root_lb <= best && root_lb < inf) == 0ull) return;
     }
     if (H == 0) {
@@ -176,13 +182,13 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
             const int base = ((un + 1) << k) - 1;                   // first of the 2^k descendants k levels down
             const int clevel = level + k;
             if (STATS) n_nodes += 1;
-            const float* __restrict__ bp = boxes6 + (size_t)base * 6;
+            const float* __restrict__ bp = boxes6 + (size_t)((base + 1) >> 1) * 12;   // base is odd: the first of a pair of siblings
             float lb[8];
             unsigned int mask = 0u;
             // (a root step of fewer than three levels reads boxes past its children: masked off below)
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
-                const f32x2 b2 = box6_bound2<FMA>(bp + 6 * j, bp + 6 * j + 6, p);
+                const f32x2 b2 = box6_bound2<FMA>(bp + 6 * j, p);
                 lb[j] = b2.x;
                 lb[j + 1] = b2.y;
                 if (__builtin_amdgcn_ballot_w64(lb[j] <= best) != 0ull) mask |= 1u << j;
