@@ -266,18 +266,18 @@ __device__ __forceinline__ float gap_cells(float u, int i)
 }
 
 // ---- the grid part (round 3; round 2's lockstep slab loops: git show 67995b1:cuda-slam_amd/csrc/nn_grid.hip) --------------------
-// What round 2's scan cost (profiles/r03_timeline.log, r03_pmc_*): a launch lasts as long as its waves hold their slots, and a scan
+// What round 2's scan cost (profiles/r03_wave_timeline.log, r03_scan_forms.log): a launch lasts as long as its waves hold their slots, and a scan
 // wave lived ~35 us through ~18 DEPENDENT memory round trips (every cell row: its two offsets, then its points, four at a time)
 // while two thirds of its vector instructions were the bookkeeping of the lockstep slab loops.  Now:
 //   * rows are named by a per-lane BIT MASK over the (2R+1)^2 rows around the query's own (R = GRID_REACH_CELLS): building it is
 //     arithmetic (two ranges, one multiply), and the wave steps through set bits only -- a row no lane needs costs nothing;
 //   * FIRST the 2 x 2 x 2 block of cells nearest to the query (its own cell and, on each axis, the neighbour on the side the query
-//     leans to): with ~2 points per cell the neighbour is in there nine times out of ten, so the radius is tight before anything
+//     leans to): with 1.5 points per cell the neighbour is in there nine times out of ten, so the radius is tight before anything
 //     else is looked at -- whatever the starting candidate was worth; THEN the rows the shrunken radius still reaches, minus what
 //     the block covered;
-//   * GRID_BATCH rows at a time: their offsets are requested together (one round trip) and their points are scanned as ONE flat
-//     sequence of runs, four candidates per trip, hopping from run to run -- the lanes stay busy until the lane with the most
-//     candidates is done, not until the fullest row of every slab is;
+//   * GRID_BATCH rows at a time: their offsets are requested together (one round trip) and their points are ONE flat sequence of
+//     runs, four candidates per trip -- and the trips are DEALT OUT over the wave (grid_deal_scan): ceil(total / 64) passes instead
+//     of as many trips as the busiest lane has; the lockstep trip loop remains for batches where dealing does not pay or fit;
 //   * a trip fetches pts[p .. p + 3] whatever is left of the run: what follows a run in pts are real points too (GRID_PTS_PAD copies
 //     of the last one at the very end), and testing ANY real point is harmless for a lexicographic minimum;
 //   * (distance, index) is ONE unsigned 64-bit key -- non-negative floats order like their bit patterns -- so "closer, or as
