@@ -87,10 +87,14 @@ def synth_cloud(np, n, seed=666):
 
 
 def search_source_hash():
-    """Hash of the search kernel's sources: a committed counter profile speaks for THIS code only if it carries the same one."""
+    """Hash of the search kernel's sources: a committed counter profile speaks for THIS code only if it carries the same one.
+    Of the CODE: `//` comments and white space do not count (a reworded comment is not another kernel)."""
+    import re
     h = hashlib.sha256()
-    for f in ("nn_grid.hip", "nn_grid.h", "nn_walk.hpp", "icp_rows.hpp"):
-        h.update(open(os.path.join(ROOT, "cuda-slam_amd", "csrc", f), "rb").read())
+    for f in ("nn_grid.hip", "nn_grid.h", "nn_walk.hpp", "icp_rows.hpp", "nn_tree.h"):
+        text = open(os.path.join(ROOT, "cuda-slam_amd", "csrc", f), "r").read()
+        text = re.sub(r"//[^\n]*", "", text)
+        h.update("".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 
