@@ -19,7 +19,7 @@ NN_AUTO, NN_BRUTEFORCE, NN_TREE, NN_GRID = 0, 1, 2, 3
 SHARD_AUTO, SHARD_TARGET, SHARD_SOURCE = 0, 1, 2
 SUM_EXACT, SUM_CPU_SEQUENTIAL = 0, 1
 SIGMA2_EXACT, SIGMA2_CPU_SEQUENTIAL = 0, 1
-NN_INDEX_MIN_POINTS = 12000         # MI_NN_AUTO switches to the cell grid at this many fixed points (mi_slam.h MI_NN_INDEX_MIN_POINTS)
+NN_INDEX_MIN_POINTS = 10000         # MI_NN_AUTO switches to the cell grid at this many fixed points (mi_slam.h MI_NN_INDEX_MIN_POINTS)
 STOP_RUNNING, STOP_CONVERGED, STOP_MAX_ITERATIONS, STOP_NO_PAIRS, STOP_ERROR_INCREASED, STOP_TOLERANCE, STOP_SIGMA = range(7)
 (KERNEL_NN, KERNEL_MOMENTS, KERNEL_SOLVE, KERNEL_TRANSFORM, KERNEL_FINALIZE, KERNEL_ALLREDUCE, KERNEL_CPD_DENOM,
  KERNEL_CPD_CONTRACT, KERNEL_CPD_MSTEP, KERNEL_CPD_FGT) = range(10)

@@ -690,8 +690,9 @@ int resolve_nn_mode(const mi_ctx* c, int nn_mode, int m_local)
     const int forced = c->tune.nn_force_mode;
     if (forced == MI_NN_BRUTEFORCE || forced == MI_NN_TREE || forced == MI_NN_GRID) nn_mode = forced;
     if (nn_mode == MI_NN_BRUTEFORCE || nn_mode == MI_NN_TREE || nn_mode == MI_NN_GRID) return nn_mode;
-    // measured crossover on MI355X, every-pair against the cell grid, ms per ICP step at N = M (profiles/r02_crossover.log):
-    // 8 000: 0.050 / 0.056, 12 000: 0.065 / 0.060, 16 000: 0.087 / 0.066, 24 000: 0.143 / 0.074, 50 000: 0.473 / 0.082
+    // measured crossover on MI355X, every-pair against the cell grid, ms per ICP step at N = M (profiles/r03_crossover.log):
+    // 6 000: 0.042 / 0.042, 8 000: 0.048 / 0.046, 10 000: 0.056 / 0.048, 12 000: 0.063 / 0.047, 16 000: 0.085 / 0.051 -- the grid's
+    // index builds (0.3 ms per registration) are what keeps the switch at 10 000 rather than 7 000
     return m_local >= MI_NN_INDEX_MIN_POINTS ? MI_NN_GRID : MI_NN_BRUTEFORCE;
 }
 

@@ -55,7 +55,7 @@ enum {
     MI_NN_GRID = 3          /* exact search through a uniform cell grid over the fixed cloud; lanes the grid cannot serve cheaply
                                (no starting candidate, far outliers, crowded cells) walk the box hierarchy inside the same launch */
 };
-#define MI_NN_INDEX_MIN_POINTS 12000
+#define MI_NN_INDEX_MIN_POINTS 10000
 
 /* What a multi-GPU context (mi_ctx_create_dist) splits across its ranks.  Same registration result either way.
  *   TARGET: rank r owns fixed points [M*r/W, M*(r+1)/W) and ALL moving points; one ncclAllReduce(ncclUint64, ncclMin) of the
