@@ -8,7 +8,7 @@ A step is ONE ICP iteration of the hot path on clouds already resident in HBM: t
 search kernel (transform, previous iteration's error sums, exact nearest-neighbour search through the cell grid with the
 box-hierarchy fallback, moments of the new pairs), the rows reduction, and the solve kernel (previous iteration's stop rule,
 3x3 SVD Kabsch, compose).  The stop rule runs on the device every step but never fires (eps = 0).  With N > 1 the problem is
-fixed ("scaling": "strong"): the moving cloud is sharded over the ranks for the indexed searches (one 18-double RCCL sum
+fixed ("scaling": "strong"): the moving cloud is sharded over the ranks for the indexed searches (one 64 x 18-double RCCL sum
 all-reduce per iteration), the fixed cloud for the every-pair search (plus a ncclMin all-reduce of the packed keys), all inside
 libmislam.so over xGMI; torch.distributed (gloo) is only the bootstrap / barrier / max.
 
@@ -397,9 +397,9 @@ def main():
     breakdown = {capi.KERNEL_NAMES[k]: ctx.profile_get(k) for k in range(len(capi.KERNEL_NAMES))}
     if use_dist:
         ar = breakdown.get("allreduce", (0.0, 0))
-        if ar[1] > 0:        # the headline path's own collective: one 18-double sum per iteration (+ a 2-double one per host batch), event-timed
-            headline_allreduce = {"launches": ar[1], "ms_per_launch": ar[0] / ar[1], "payload_bytes": 8 * 18,
-                                  "collective": "ncclAllReduce(ncclDouble, ncclSum) of IcpState mom|err on the context's stream (mislam_api.hip allreduce_sum_f64)"
+        if ar[1] > 0:        # the headline path's own collective: one 64 x 18-double sum per iteration (+ a 2-double one per host batch), event-timed
+            headline_allreduce = {"launches": ar[1], "ms_per_launch": ar[0] / ar[1], "payload_bytes": 8 * 18 * 64,
+                                  "collective": "ncclAllReduce(ncclDouble, ncclSum) of the 64 reduced rows x (16 moments + 2 error sums) on the context's stream (mislam_api.hip allreduce_sum_f64)"
                                                 if rehearsal_transport != "gloo" else "caller's transport (gloo rehearsal)"}
     breakdown = {k: v[0] / v[1] for k, v in breakdown.items() if v[1] > 0 and extra > 0}
 
@@ -521,9 +521,9 @@ def main():
                        "dist_arithmetic": "cpu_rounding" if args.dist_mode == 0 else "fma",
                        "compose": "cpu_additive",
                        "parallelism": ("single GPU" if world == 1 else
-                                       "moving cloud sharded x%d, fixed cloud replicated, one 18-double RCCL sum all-reduce per iteration" % world
+                                       "moving cloud sharded x%d, fixed cloud replicated, one 64 x 18-double RCCL sum all-reduce per iteration" % world
                                        if pl["source_sharded"] else
-                                       "fixed cloud sharded x%d, RCCL u64-min all-reduce of the packed keys + one 18-double sum per iteration" % world),
+                                       "fixed cloud sharded x%d, RCCL u64-min all-reduce of the packed keys + one 64 x 18-double sum per iteration" % world),
                        "error_after_steps": err},
             "roofline": roof,
             "kernels_ms_per_step": breakdown,     # ms per launch, from the untimed follow-up iterations (every kernel event-timed)

@@ -483,6 +483,7 @@ __global__ void icp_mark_pending_kernel(IcpState* __restrict__ state)
 // ---------------------------------------------------------------------------------------------------------------
 int icp_row_count(int n) { return (n + ICP_ROW_POINTS - 1) / ICP_ROW_POINTS; }
 
+static_assert(ICP_REDUCED_ROWS == ICP_MAX_REDUCED_ROWS, "kernels.h and icp_rows.hpp agree");
 int icp_reduced_count(int nrows)
 {
     int g = (nrows + 31) / 32;           // at least ~32 rows per workgroup

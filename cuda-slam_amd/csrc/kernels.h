@@ -31,6 +31,7 @@ hipError_t nn_launch(const NnLaunch& a, hipStream_t stream);
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int ICP_MOMENTS = 16;              // count, sum b (3), sum a (3), sum a b^T (9)
 constexpr int ICP_ERRSUMS = 2;               // sum |a - b'|^2, kept pairs
+constexpr int ICP_REDUCED_ROWS = 64;          // rows icp_rows_reduce leaves at most (= ICP_MAX_REDUCED_ROWS of icp_rows.hpp): one per lane of the solve kernel
 constexpr int ICP_MAX_PARTIAL_BLOCKS = 512;   // 2 blocks per CU: enough loads in flight for the O(N) passes, few rows to reduce
 
 // mirror of the public MI_STOP_* values (mi_slam.h) for device code

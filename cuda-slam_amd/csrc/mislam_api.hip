@@ -778,7 +778,8 @@ static int reserve_rows(mi_ctx* c)
         MI_TRY(c->rows.reserve(rows));
         MI_HIP(hipMemsetAsync(c->rows.p, 0, sizeof(double) * c->rows.cap, c->stream));   // columns a path never writes stay finite
     }
-    MI_TRY(c->rows_reduced.reserve((size_t)64 * (ICP_MOMENTS + ICP_ERRSUMS)));
+    MI_TRY(c->rows_reduced.reserve((size_t)ICP_REDUCED_ROWS * (ICP_MOMENTS + ICP_ERRSUMS)));
+    MI_HIP(hipMemsetAsync(c->rows_reduced.p, 0, sizeof(double) * ICP_REDUCED_ROWS * (ICP_MOMENTS + ICP_ERRSUMS), c->stream));   // (rows past a rank's count: zero)
     MI_TRY(c->sched_order.reserve((size_t)icp_row_count(c->n_pad)));
     MI_TRY(c->sched_far.reserve((size_t)icp_row_count(c->n_pad)));
     MI_TRY(c->sched_counters.reserve(2));
@@ -1055,17 +1056,15 @@ static int icp_enqueue_iteration(mi_ctx* c)
         const IcpSchedule sched = make_schedule(c);
         int* cursors = c->fused ? sched.counters : nullptr;
         if (c->distributed()) {
-            // ONE all-reduce per iteration: this iteration's 16 moments and the previous iteration's 2 error sums (contiguous in
-            // the state block)
-            static_assert(offsetof(IcpState, err) == offsetof(IcpState, mom) + sizeof(double) * ICP_MOMENTS, "mom and err must be contiguous");
-            {
-                ProfScope ps(c, MI_KERNEL_SOLVE);
-                MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream, c->fused ? &sched : nullptr));
-                MI_HIP(icp_rows_to_state(c->d_state, c->rows_reduced.p, reduced, 3, c->stream));
-            }
-            { ProfScope ps(c, MI_KERNEL_ALLREDUCE); MI_TRY(allreduce_doubles(c, c->d_state->mom, ICP_MOMENTS + ICP_ERRSUMS)); }
+            // ONE all-reduce per iteration: this iteration's 16 moments and the previous iteration's 2 error sums ride together -- as
+            // the REDUCED ROWS themselves (64 x 18 doubles, the rows past this rank's own count are zero: every rank sends the same
+            // length whatever its share), so that the solve kernel adds them up exactly as on one GPU and no kernel sits between
+            // the reduction and the collective (a 9 KB all-reduce is as latency-bound as a 144-byte one)
+            (void)reduced;
+            { ProfScope ps(c, MI_KERNEL_SOLVE); MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream, c->fused ? &sched : nullptr)); }
+            { ProfScope ps(c, MI_KERNEL_ALLREDUCE); MI_TRY(allreduce_doubles(c, c->rows_reduced.p, ICP_REDUCED_ROWS * (ICP_MOMENTS + ICP_ERRSUMS))); }
             ProfScope ps(c, MI_KERNEL_SOLVE);
-            MI_HIP(icp_solve_deferred(c->d_state, nullptr, 0, c->icp.compose_mode, rules, 1, c->stream, cursors));
+            MI_HIP(icp_solve_deferred(c->d_state, c->rows_reduced.p, ICP_REDUCED_ROWS, c->icp.compose_mode, rules, 1, c->stream, cursors));
         } else {
             ProfScope ps(c, MI_KERNEL_SOLVE);
             MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream, c->fused ? &sched : nullptr));

@@ -59,12 +59,12 @@ enum {
 
 /* What a multi-GPU context (mi_ctx_create_dist) splits across its ranks.  Same registration result either way.
  *   TARGET: rank r owns fixed points [M*r/W, M*(r+1)/W) and ALL moving points; one ncclAllReduce(ncclUint64, ncclMin) of the
- *           N packed (min-dist, argmin) keys per iteration, then owner-accumulated moments/error + one 18-double sum all-reduce.
+ *           N packed (min-dist, argmin) keys per iteration, then owner-accumulated moments/error + one 64 x 18-double sum all-reduce.
  *           The every-pair search scales perfectly this way (its work is N*M/W per rank).
  *   SOURCE: every rank holds a replica of the fixed cloud (12 B/point: trivial at 288 GB) and 1/W of the moving points -- the
  *           64-point chunks of the moving cloud's Hilbert order dealt round-robin (rank r: chunks r, r+W, ...; contiguous
  *           slices [N*r/W, N*(r+1)/W) of the caller's order below 256*W points).  No per-point exchange at all, only one
- *           18-double sum all-reduce per iteration.  The indexed searches need this split to scale: their cost per moving
+ *           64 x 18-double sum all-reduce per iteration.  The indexed searches need this split to scale: their cost per moving
  *           point hardly depends on how many fixed points a rank holds.
  *   AUTO:   SOURCE when the search runs through an index (cell grid / box hierarchy), TARGET when it is the every-pair search. */
 enum {
