@@ -369,3 +369,44 @@ def test_multiplication_known_answer(ctx, capi):
         b, a = src[sel].astype(np.float64), tgt[idx[sel]].astype(np.float64)
         want = np.concatenate([[sel.sum()], b.sum(0), a.sum(0), (a[:, :, None] * b[:, None, :]).sum(0).reshape(9)])
         assert np.allclose(mom, want, rtol=1e-12, atol=1e-9)
+
+
+def test_upload_and_allocation_fallbacks_do_not_change_the_registration(ctx, capi, monkeypatch):
+    # MISLAM_PIN=0 (the runtime's pageable upload path instead of the context's pinned ring; read at context creation) in this process,
+    # MISLAM_POOL=0 (plain hipMalloc / hipFree instead of the stream-ordered pool; decided once per process) in a child process: how the
+    # bytes get there and where the buffers come from must not show in a single bit of the result
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    rng = np.random.default_rng(77)
+    before = rng.uniform(-5, 5, (60000, 3)).astype(np.float32)                  # 720 KB per cloud: through the ring
+    c, s = np.cos(0.1), np.sin(0.1)
+    after = (before[rng.permutation(len(before))].astype(np.float64) @ np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]]).T + 0.3).astype(np.float32)
+    p = capi.icp_params(max_iterations=12)
+    base = ctx.icp_register(before, after, p)
+
+    def digest(r):
+        return hashlib.sha256(np.asarray(r[0], np.float32).tobytes() + np.asarray(r[1], np.float32).tobytes() + np.int32(r[2]).tobytes() + np.float32(r[3]).tobytes()).hexdigest()
+
+    monkeypatch.setenv("MISLAM_PIN", "0")
+    with capi.Context(0) as c2:
+        assert digest(c2.icp_register(before, after, p)) == digest(base)
+    monkeypatch.delenv("MISLAM_PIN")
+    code = (
+        "import sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from conftest import load_package\n"
+        "capi = load_package().capi\n"
+        "rng = np.random.default_rng(77)\n"
+        "before = rng.uniform(-5, 5, (60000, 3)).astype(np.float32)\n"
+        "c, s = np.cos(0.1), np.sin(0.1)\n"
+        "after = (before[rng.permutation(len(before))].astype(np.float64) @ np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]]).T + 0.3).astype(np.float32)\n"
+        "with capi.Context(0) as ctx:\n"
+        "    r = ctx.icp_register(before, after, capi.icp_params(max_iterations=12))\n"
+        "print('DIGEST', hashlib.sha256(np.asarray(r[0], np.float32).tobytes() + np.asarray(r[1], np.float32).tobytes() + np.int32(r[2]).tobytes() + np.float32(r[3]).tobytes()).hexdigest())\n"
+    ) % os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MISLAM_POOL="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert ("DIGEST " + digest(base)) in out.stdout
