@@ -56,7 +56,8 @@ __host__ __device__ inline Rot2 symmetric_jacobi(float x, float y, float z)
     const float t = (tau > 0.f) ? 1.f / (tau + w) : 1.f / (tau - w);
     const float sign_t = t > 0.f ? 1.f : -1.f;
     const float n = 1.f / sqrtf(t * t + 1.f);
-    return Rot2{n, -sign_t * (y / fabsf(y)) * fabsf(t) * n};
+    // (y / |y| of Eigen's makeJacobi: +-1 exactly -- |y| >= FLT_MIN / 2 here -- so a sign copy, not a division)
+    return Rot2{n, -sign_t * copysignf(1.f, y) * fabsf(t) * n};
 }
 
 struct Svd3 {

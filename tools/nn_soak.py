@@ -32,7 +32,7 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     capi = load_package().capi
     ctx = capi.Context(0)
-    rng = np.random.default_rng(20261004)
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
     bad = 0
     for k in range(cases):
         n = int(10 ** rng.uniform(0, 5.48))
