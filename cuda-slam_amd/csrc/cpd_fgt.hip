@@ -55,6 +55,24 @@ __device__ __forceinline__ ArgMax wave_argmax(ArgMax a)
     return a;
 }
 
+// (distance, index) as ONE unsigned key that orders like beats(): a distance >= +0 orders like its bits, and among equal distances the
+// LOWER index must win a maximum -- so the index goes in complemented.  0 = no candidate (v < 0).
+__device__ __forceinline__ unsigned long long argmax_key(float v, int i)
+{
+    return v < 0.f ? 0ull : (((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xffffffffu - (unsigned int)i));
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k, int width)      // maximum over aligned groups of `width` lanes
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        if (off >= width) break;
+        const unsigned int lo = (unsigned int)__shfl_xor((int)(unsigned int)k, off, 64), hi = (unsigned int)__shfl_xor((int)(unsigned int)(k >> 32), off, 64);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        k = o > k ? o : k;
+    }
+    return k;
+}
+
 // PER > 0: every lane keeps its PER points (id = lane + r * 1024), their distances and labels in registers.
 // PER == 0: any n; distances and labels stay in global memory (each lane only ever touches its own entries).
 // The sweep is prefix-stable (the first k centres do not depend on K), so a finished sweep can be RESUMED: with start > 0 the
@@ -65,7 +83,9 @@ __global__ __launch_bounds__(1024) void fgt_kcenter_kernel(const float* __restri
                                                            const float* __restrict__ z, int n, int start, int K,
                                                            float* __restrict__ dist, int* __restrict__ indx)
 {
-    __shared__ ArgMax s_best[2][16];
+    // per wave: its best key and that point's coordinates.  Double-buffered: a wave can run at most one barrier ahead of the slowest reader
+    __shared__ unsigned long long s_key[2][16];
+    __shared__ float4 s_xyz[2][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NR = PER > 0 ? PER : 1;
     float px[NR], py[NR], pz[NR], pd[NR];
@@ -76,9 +96,12 @@ __global__ __launch_bounds__(1024) void fgt_kcenter_kernel(const float* __restri
         for (int r = 0; r < NR; r++) {
             const int j = tid + r * 1024, jc = min(j, n - 1);
             px[r] = x[jc]; py[r] = y[jc]; pz[r] = z[jc];
-            pd[r] = 0.f; pc[r] = 0;
+            // a point's distance to its nearest centre so far: +inf before the first centre (step 0 then takes every distance as it
+            // comes), -inf for the register slots past the cloud's end (never closer to anything, never a maximum) -- so that the
+            // sweep below needs no branch and no special first step
+            pd[r] = j < n ? __builtin_inff() : -__builtin_inff(); pc[r] = 0;
             if (start > 0) {
-                pd[r] = dist[jc]; pc[r] = indx[jc];
+                if (j < n) { pd[r] = dist[jc]; pc[r] = indx[jc]; }
                 if (j < n && pd[r] > best.v) best = {pd[r], j, px[r], py[r], pz[r]};
             }
         }
@@ -91,17 +114,21 @@ __global__ __launch_bounds__(1024) void fgt_kcenter_kernel(const float* __restri
     float cx = x[1], cy = y[1], cz = z[1];          // the first centre is point 1 (fgt.cpp:162)
     for (int step = start; step < K; step++) {
         if (step > 0) {
-            // this step's centre = FIRST maximum of the distance array (std::max_element, fgt.cpp:179)
-            best = wave_argmax(best);
-            const int buf = step & 1;   // double-buffered: a wave can run at most one barrier ahead of the slowest reader
-            if (lane == 0) s_best[buf][wave] = best;
-            __syncthreads();
-            ArgMax w = s_best[buf][0];
-#pragma unroll
-            for (int q = 1; q < 16; q++) {
-                const ArgMax o = s_best[buf][q];
-                if (beats(o.v, o.i, w.v, w.i)) w = o;
+            // this step's centre = FIRST maximum of the distance array (std::max_element, fgt.cpp:179): the maximum of the keys -- over the
+            // wave (12 exchanges of one word, where the five-field record took 30), whose holder alone writes its coordinates; then over
+            // the 16 waves, one key per lane of a group of 16 (8 exchanges and two LDS reads, where every lane read all 16 records)
+            const int buf = step & 1;
+            const unsigned long long mine = argmax_key(best.v, best.i);
+            const unsigned long long wmax = wave_max_u64(mine, 64);
+            if (wmax == 0ull ? lane == 0 : mine == wmax) {            // (keys of distinct points differ; no candidate at all: lane 0 says so)
+                s_key[buf][wave] = wmax;
+                s_xyz[buf][wave] = make_float4(best.x, best.y, best.z, 0.f);
             }
+            __syncthreads();
+            const unsigned long long kq = s_key[buf][lane & 15];
+            const unsigned long long kmax = wave_max_u64(kq, 16);
+            const int q = __builtin_ctzll(__builtin_amdgcn_ballot_w64(kq == kmax));      // (a lane of the first group of 16: q = its wave number)
+            const float4 w = s_xyz[buf][q & 15];
             cx = w.x; cy = w.y; cz = w.z;
         }
         best = {-1.f, 0x7fffffff, 0.f, 0.f, 0.f};
@@ -109,14 +136,14 @@ __global__ __launch_bounds__(1024) void fgt_kcenter_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < NR; r++) {
                 const int j = tid + r * 1024;
-                if (j < n) {
-                    const float d = len2(px[r] - cx, py[r] - cy, pz[r] - cz);
-                    float cur = pd[r];
-                    if (step == 0) cur = d;
-                    else if (d < cur) { cur = d; pc[r] = step; }         // strict <: fgt.cpp:187
-                    pd[r] = cur;
-                    if (cur > best.v) best = {cur, j, px[r], py[r], pz[r]};   // ascending j per lane: the first maximum stays
-                }
+                const float d = len2(px[r] - cx, py[r] - cy, pz[r] - cz);
+                const bool closer = d < pd[r];                           // strict <: fgt.cpp:187 (always at step 0, never for a slot past the end)
+                const float cur = closer ? d : pd[r];
+                pc[r] = closer ? step : pc[r];
+                pd[r] = cur;
+                const bool further = cur > best.v;                       // ascending j per lane: the first maximum stays
+                best.v = further ? cur : best.v; best.i = further ? j : best.i;
+                best.x = further ? px[r] : best.x; best.y = further ? py[r] : best.y; best.z = further ? pz[r] : best.z;
             }
         } else {
             for (int j = tid; j < n; j += 1024) {
