@@ -191,7 +191,8 @@ def whole_call(np, capi, ctx, n, repeats=3):
 
 
 def cpd_bunny(np, capi, ctx, world):
-    """cfg 4 (bunny 14 904 x 14 904, cpd-weight .3, scale free) through mi_cpd_register: exact P, and hybrid where one rank runs."""
+    """cfg 4 (bunny 14 904 x 14 904, cpd-weight .3, scale free) through mi_cpd_register: exact P (fixed cloud sharded over the ranks) and
+    the parser's default hybrid mode (replicated on every rank of a multi-GPU context)."""
     gold = os.path.join(ROOT, "tests", "golden")
     z = np.load(os.path.join(gold, "bunny_clouds.npz"))
     g = json.load(open(os.path.join(gold, "bunny_cpd.json")))
@@ -210,7 +211,7 @@ def cpd_bunny(np, capi, ctx, world):
                 out[label] = {"value": None, "ms": None, "skipped": str(e)}
         out["sigma2_cpu_sequential"]["note"] = ("cpu-slam's saturating sequential fp32 sum over all %.3g pairs, bit for bit (coherentpointdrift.cpp:126-139); "
                                                 "what a registration with sigma2_mode = MI_SIGMA2_CPU_SEQUENTIAL pays once, before its first E-step" % pairs)
-    modes = [("exact", capi.CPD_APPROX_NONE)] + ([("hybrid", capi.CPD_APPROX_HYBRID)] if world == 1 else [])
+    modes = [("exact", capi.CPD_APPROX_NONE), ("hybrid", capi.CPD_APPROX_HYBRID)]
     for label, approx in modes:
         p = capi.cpd_params(max_iterations=50, sigma2_init=g["sigma2_init"], approximation=approx)
         ctx.cpd_register(before, after, p)                       # warm-up: allocations, code load
@@ -252,6 +253,37 @@ def cpd_bunny(np, capi, ctx, world):
     return out
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks as a fresh child process tree -- `python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`, the driver's own launch line -- relay rank 0's
+    JSON line and return the child's exit code.  A child, not an exec; called before this process has imported the package or
+    touched the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_ranks, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    child = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    for line in child.stdout:                  # rank 0 prints ONE JSON line; anything else a rank writes to stdout goes to stderr
+        if line.lstrip().startswith("{") and '"metric"' in line:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = child.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write("bench.py: the %d-rank child printed %d result lines\n" % (n_ranks, lines))
+        return 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,13 +304,12 @@ def main():
                     help="search strategy (identical results): auto = the library default (cell grid at this size)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))       # (nothing has touched the GPU or imported the package yet)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world                          # under a launcher the launcher's world size is the truth
 
     # MISLAM_BENCH_FORCE_DIST=1 takes the multi-process path (gloo bootstrap, RCCL communicator) even with one rank:
     # the rehearsal a single-GPU box allows
@@ -291,6 +322,23 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
+
+    if os.environ.get("MISLAM_BENCH_DRYRUN") == "1":
+        # launcher check on a box WITHOUT a GPU (tests/test_bench_launch.py): bootstrap, one collective, one line, clean exit --
+        # no context is created, nothing is measured, and the line says so
+        import torch
+        seen = torch.tensor([float(1 << rank)], dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+            dist.barrier()
+        if rank == 0:
+            mask = int(seen.item())
+            print(json.dumps({"metric": "icp_iterations_per_s", "value": None, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "dry_run": "launcher flow only: no device touched, nothing measured",
+                              "rccl": {"nranks": world, "ranks_seen_mask": mask, "ranks_seen": bin(mask).count("1"), "transport": "gloo (dry run)"}}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     import numpy as np
     from __graft_entry__ import load_package

@@ -45,8 +45,10 @@ void set_error(const char* fmt, ...);
 // Device buffers that were outgrown: work already enqueued may still read them, so they are released at the next point where the
 // host has drained the stream anyway (retire_buffers, called behind the loads' and runs' own synchronisations) -- not behind a
 // device-wide synchronisation per buffer, which is what a load of forty buffers used to pay when a size was new.
-void retire_later(void* p);
-void retire_buffers();
+// The list is the CONTEXT's (mi_ctx::retired): a buffer outgrown inside a call on context A is released only behind a drain of A's own
+// stream, with A's device current -- never by another host thread's context, never on another device (round 3 kept one process-wide list).
+void retire_later(void* p);                        // into the list of the context whose call is running on this thread (CtxScope)
+void retire_buffers(struct ::mi_ctx* ctx);         // call right behind a synchronisation of ctx->stream, ctx->device current
 // Device memory comes out of the runtime's stream-ordered pool, kept whole (release threshold: never): hipFree of a plain
 // allocation costs ~0.2 ms on this machine (tools/alloc_probe.cpp) -- forty buffers outgrown by a new size were 8 ms -- the pool's
 // free is ~1 us and its memory is handed out again.  MISLAM_POOL=0 (or a runtime without the pool) falls back to hipMalloc / hipFree.
@@ -93,6 +95,7 @@ struct CpdWorkspace;   // cpd_api.hip
 
 struct mi_ctx {
     int device = 0;
+    std::vector<void*> retired;                          // outgrown device buffers waiting for the next drain of `stream` (retire_buffers)
     hipStream_t stream = nullptr;
     int rank = 0, world = 1;
     ncclComm_t comm = nullptr;
@@ -189,6 +192,21 @@ struct mi_ctx {
 };
 
 namespace mislam {
+
+// Every entry point that works on a context opens one: the context's device becomes current and buffers outgrown during the call
+// are retired into the context's own list.  On the way out, whatever is on that list is released if the stream happens to be
+// drained (the entry points that return host results end in a synchronisation), else it waits for the next one.
+struct CtxScope {
+    mi_ctx* ctx;
+    std::vector<void*>* outer;
+    explicit CtxScope(mi_ctx* c);
+    ~CtxScope();
+    CtxScope(const CtxScope&) = delete;
+    CtxScope& operator=(const CtxScope&) = delete;
+};
+#define MI_ENTER(c)                          \
+    MI_HIP(hipSetDevice((c)->device));       \
+    mislam::CtxScope mi_ctx_scope_(c)
 
 struct ProfScope {
     mi_ctx* c;

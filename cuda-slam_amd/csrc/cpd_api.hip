@@ -56,6 +56,7 @@ struct CpdWorkspace {
     int n_total = 0;                          // |after| over all ranks
     int k_chunks = 1, k_chunk_len = 0, x_chunks = 1, x_chunk_len = 0;
     bool sums_fresh = false;                  // the last exact E-step left the M-step's x-sums and k-sums in part_x / part_k
+    bool replicated = false;                  // multi-rank context, but this registration runs whole on every rank (the FGT modes): no collective
     mi_cpd_params params{};
 };
 
@@ -184,7 +185,7 @@ static int cpd_mstep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const
         MI_HIP(cpd_ksums(v, w->part_k.p, nkb, c->stream));
     }
     w->sums_fresh = false;
-    if (!c->distributed()) {
+    if (!c->distributed() || w->replicated) {
         MI_HIP(cpd_solve(w->d_state, w->part_x.p, nxb, w->part_k.p, nkb, rules, update_loop_state, c->stream));
         return MI_OK;
     }
@@ -211,11 +212,11 @@ static int cpd_init(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const CpdRules
     MI_HIP(cpd_init_sums(v, w->part_init.p, nb, c->stream));
     const int seq = sigma2_mode == MI_SIGMA2_CPU_SEQUENTIAL && !(sigma2_override > 0.f);
     if (seq) {
-        if (c->distributed()) { set_error("CPD: MI_SIGMA2_CPU_SEQUENTIAL needs a single-GPU context (one running sum over all pairs)"); return MI_ERR_INVALID_ARG; }
+        if (c->distributed() && !w->replicated) { set_error("CPD: MI_SIGMA2_CPU_SEQUENTIAL needs a single-GPU context (one running sum over all pairs)"); return MI_ERR_INVALID_ARG; }
         MI_TRY(w->sig_scratch.reserve(cpd_sigma2_scratch_bytes()));
         MI_HIP(cpd_sigma2_sequential(v, c->stream, w->sig_scratch.p, (int*)c->h_scratch));
     }
-    if (!c->distributed()) {
+    if (!c->distributed() || w->replicated) {
         MI_HIP(cpd_init_state(w->d_state, w->part_init.p, nb, rules, sigma2_override, seq, c->stream));
         return MI_OK;
     }
@@ -371,10 +372,6 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
 {
     MI_TRY(cpd_check(c, before_xyz, m_before, after_xyz, n_after, true));
     if (!params || !out_sR_t || !iterations || !error) { set_error("mi_cpd_register: null argument"); return MI_ERR_INVALID_ARG; }
-    if (c->world > 1 && params->approximation != MI_CPD_APPROX_NONE) {
-        set_error("mi_cpd_register: the FGT modes run on single-GPU contexts (the exact P shards over the fixed cloud)");
-        return MI_ERR_STATE;
-    }
     if (n_after < c->world) { set_error("mi_cpd_register: %d fixed points cannot be split over %d ranks", n_after, c->world); return MI_ERR_INVALID_ARG; }
     if (params->approximation < MI_CPD_APPROX_NONE || params->approximation > MI_CPD_APPROX_HYBRID) {
         set_error("mi_cpd_register: unknown approximation %d", params->approximation);
@@ -385,13 +382,18 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
         set_error("mi_cpd_register: the FGT modes need 1 <= order of truncation <= %d and >= 2 points per cloud", FGT_MAX_ORDER);
         return MI_ERR_INVALID_ARG;
     }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     CpdWorkspace* w = nullptr;
     MI_TRY(cpd_workspace(c, &w));
     w->params = *params;
-    // every rank is handed both clouds whole (as mi_icp_register) and keeps fixed points [lo, hi) -- mi_shard_range
+    // every rank is handed both clouds whole (as mi_icp_register) and keeps fixed points [lo, hi) -- mi_shard_range.
+    // The FGT modes ("full", and "hybrid" -- the reference parser's default, configparser.cpp:217) cluster the WHOLE fixed cloud and
+    // their E-step is O((N + M) K) -- milliseconds where the exact one takes seconds -- so on a multi-rank context they run
+    // REPLICATED: every rank keeps both clouds whole and does the same arithmetic in the same order (the same bits everywhere),
+    // no collective at all.  The exact P shards.
     int lo = 0, hi = n_after;
-    if (c->world > 1) (void)mi_shard_range(n_after, c->rank, c->world, &lo, &hi);
+    w->replicated = c->world > 1 && params->approximation != MI_CPD_APPROX_NONE;
+    if (c->world > 1 && !w->replicated) (void)mi_shard_range(n_after, c->rank, c->world, &lo, &hi);
     MI_TRY(cpd_load(c, w, before_xyz, m_before, after_xyz + 3 * (size_t)lo, hi - lo));
     w->n_total = n_after;
     const CpdView v = cpd_view(c, w);
@@ -462,9 +464,10 @@ extern "C" int mi_cpd_sigma_squared_mode(mi_ctx* c, const float* before_xyz, int
     MI_TRY(cpd_check(c, before_xyz, m, after_xyz, n));
     if (!sigma2) { set_error("mi_cpd_sigma_squared: null output"); return MI_ERR_INVALID_ARG; }
     if (sigma2_mode != MI_SIGMA2_EXACT && sigma2_mode != MI_SIGMA2_CPU_SEQUENTIAL) { set_error("mi_cpd_sigma_squared: bad sigma2_mode %d", sigma2_mode); return MI_ERR_INVALID_ARG; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     CpdWorkspace* w = nullptr;
     MI_TRY(cpd_workspace(c, &w));
+    w->replicated = false;
     MI_TRY(cpd_load(c, w, before_xyz, m, after_xyz, n));
     const CpdView v = cpd_view(c, w);
     mi_cpd_params p;
@@ -484,9 +487,10 @@ static int estep_primitive(mi_ctx* c, const float* y_xyz, int m, const float* x_
     MI_TRY(cpd_check(c, y_xyz, m, x_xyz, n));
     if (!p1 || !pt1 || !px || !L) { set_error("CPD E-step: null output"); return MI_ERR_INVALID_ARG; }
     if (!(sigma2 > 0.f)) { set_error("CPD E-step: sigma2 must be positive"); return MI_ERR_INVALID_ARG; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     CpdWorkspace* w = nullptr;
     MI_TRY(cpd_workspace(c, &w));
+    w->replicated = false;
     MI_TRY(cpd_load(c, w, y_xyz, m, x_xyz, n));
     CpdView v = cpd_view(c, w);
     memset(w->h_state, 0, sizeof(CpdState));
@@ -546,7 +550,7 @@ extern "C" int mi_fgt_kcenter(mi_ctx* c, const float* cloud_xyz, int n, int K, f
     if (!c) { set_error("mi_fgt_kcenter: null context"); return MI_ERR_INVALID_ARG; }
     if (!cloud_xyz || !centers_xyz || !cluster) { set_error("mi_fgt_kcenter: null argument"); return MI_ERR_INVALID_ARG; }
     if (n < 2 || K < 1 || K > FGT_MAX_CLUSTERS) { set_error("mi_fgt_kcenter: need n >= 2 and 1 <= K <= %d (n=%d, K=%d)", FGT_MAX_CLUSTERS, n, K); return MI_ERR_INVALID_ARG; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     CpdWorkspace* w = nullptr;
     MI_TRY(cpd_workspace(c, &w));
     c->icp_loaded = false;
@@ -581,9 +585,10 @@ extern "C" int mi_cpd_mstep(mi_ctx* c, const float* before_xyz, int m, const flo
 {
     MI_TRY(cpd_check(c, before_xyz, m, after_xyz, n));
     if (!p1 || !pt1 || !px || !out_R9 || !out_t3 || !scale || !sigma2) { set_error("mi_cpd_mstep: null argument"); return MI_ERR_INVALID_ARG; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     CpdWorkspace* w = nullptr;
     MI_TRY(cpd_workspace(c, &w));
+    w->replicated = false;
     MI_TRY(cpd_load(c, w, before_xyz, m, after_xyz, n));
     CpdView v = cpd_view(c, w);
     v.xw4 = nullptr;   // no E-step ran: skip the log-likelihood term

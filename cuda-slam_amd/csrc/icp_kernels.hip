@@ -491,13 +491,17 @@ int icp_reduced_count(int nrows)
     return g < 1 ? 1 : g;
 }
 
-hipError_t icp_rows_reduce(const double* rows, int nrows, double* part, hipStream_t s, const IcpSchedule* sched)
+// all_rows: write every one of the ICP_REDUCED_ROWS output rows, the ones past this cloud's own count as zeros (their workgroups find an
+// empty slice).  The multi-GPU path all-reduces the 64 rows IN PLACE: a rank whose share yields fewer rows than a neighbour's would
+// otherwise keep the neighbour's summed rows from the previous iteration and add them into the next collective.
+hipError_t icp_rows_reduce(const double* rows, int nrows, double* part, hipStream_t s, const IcpSchedule* sched, bool all_rows)
 {
     const int g = icp_reduced_count(nrows);
     const int per = (nrows + g - 1) / g;
+    const int n_sum = all_rows ? ICP_REDUCED_ROWS : g;
     IcpSchedule sc{};
     if (sched != nullptr) sc = *sched;
-    hipLaunchKernelGGL(icp_rows_reduce_kernel, dim3(sched != nullptr && sc.order != nullptr ? 2 * g : g), dim3(ROWS_REDUCE_THREADS), 0, s, rows, nrows, per, part, sc, g);
+    hipLaunchKernelGGL(icp_rows_reduce_kernel, dim3(sched != nullptr && sc.order != nullptr ? 2 * n_sum : n_sum), dim3(ROWS_REDUCE_THREADS), 0, s, rows, nrows, per, part, sc, n_sum);
     return hipGetLastError();
 }
 

@@ -120,7 +120,7 @@ struct IcpSchedule {
     int* counters;                         // 2 cursors, zeroed by the solve kernel
 };
 hipError_t icp_schedule_reset(const IcpSchedule& sched, int nrows, hipStream_t s);             // identity order, no flags
-hipError_t icp_rows_reduce(const double* rows, int nrows, double* part, hipStream_t s, const IcpSchedule* sched = nullptr);   // -> part[icp_reduced_count(nrows)][18]
+hipError_t icp_rows_reduce(const double* rows, int nrows, double* part, hipStream_t s, const IcpSchedule* sched = nullptr, bool all_rows = false);   // -> part[icp_reduced_count(nrows)][18]
 // reduced rows -> state->mom / state->err (which: 1 moments, 2 error sums, 3 both); the multi-GPU paths all-reduce them there
 hipError_t icp_rows_to_state(IcpState* state, const double* part, int count, int which, hipStream_t s);
 // K3 + K6, deferred: settles the PREVIOUS iteration's stop rule from the error sums (if state->err_pending), then -- unless it

@@ -34,27 +34,40 @@ void set_error(const char* fmt, ...)
 }  // namespace mislam
 
 namespace mislam {
-static std::mutex g_retired_mutex;
-static std::vector<void*> g_retired;
+static thread_local std::vector<void*>* t_retire_sink = nullptr;      // the running call's context list (CtxScope)
 double& alloc_ms_counter()
 {
     static thread_local double ms = 0.0;
     return ms;
 }
 double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void device_free(void* p);
 void retire_later(void* p)
 {
-    std::lock_guard<std::mutex> lock(g_retired_mutex);
-    g_retired.push_back(p);
+    if (t_retire_sink != nullptr) { t_retire_sink->push_back(p); return; }
+    (void)hipDeviceSynchronize();               // outside any context call (not a path the library takes): nothing may still read it after this
+    device_free(p);
 }
-// One allocation stream per device, with no work on it: the pool's stream-ordered calls complete at once there.  A buffer is only
-// ever freed behind a synchronisation of the stream that used it (retire_buffers, context destruction), so handing its memory out
-// again -- to this context or another -- is safe whatever stream the new owner works on.
+CtxScope::CtxScope(mi_ctx* c) : ctx(c), outer(t_retire_sink) { t_retire_sink = &c->retired; }
+CtxScope::~CtxScope()
+{
+    t_retire_sink = outer;
+    if (!ctx->retired.empty() && ctx->stream != nullptr && hipStreamQuery(ctx->stream) == hipSuccess) retire_buffers(ctx);
+    else (void)hipGetLastError();               // (hipErrorNotReady is not an error here)
+}
+// One allocation stream and one PRIVATE memory pool per device (hipMemPoolCreate; release threshold: never -- the library's buffers
+// are meant to be handed out again, not returned to the driver between calls).  The device's default pool is left alone: its
+// attributes belong to the host application.  The stream carries no work, so the pool's stream-ordered calls complete at once
+// there.  A buffer is only ever freed behind a synchronisation of the stream that used it (retire_buffers, context destruction),
+// so handing its memory out again -- to this context or another -- is safe whatever stream the new owner works on.  When the last
+// context on a device is destroyed the pool is trimmed to nothing (pool_context_gone).  MISLAM_POOL=0: plain hipMalloc / hipFree.
 static constexpr int MAX_DEVICES = 64;
 static hipStream_t g_alloc_stream[MAX_DEVICES] = {nullptr};
+static hipMemPool_t g_pool[MAX_DEVICES] = {nullptr};
+static int g_pool_contexts[MAX_DEVICES] = {0};
 static int g_use_pool = -1;                     // -1: not decided yet
 static std::mutex g_pool_mutex;
-static hipStream_t alloc_stream()
+static hipStream_t alloc_stream(hipMemPool_t* pool_out = nullptr)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
@@ -68,21 +81,31 @@ static hipStream_t alloc_stream()
         hipMemPool_t pool = nullptr;
         hipStream_t s = nullptr;
         unsigned long long keep = ~0ull;
-        if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess || hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess ||
+        hipMemPoolProps props;
+        memset(&props, 0, sizeof props);
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = dev;
+        if (hipMemPoolCreate(&pool, &props) != hipSuccess || hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess ||
             hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
             (void)hipGetLastError();
+            if (pool != nullptr) (void)hipMemPoolDestroy(pool);
             g_use_pool = 0;
             return nullptr;
         }
+        g_pool[dev] = pool;
         g_alloc_stream[dev] = s;
     }
+    if (pool_out) *pool_out = g_pool[dev];
     return g_alloc_stream[dev];
 }
 static bool g_pool_proven = false;               // a pool allocation has succeeded: the mode never changes after that
 hipError_t device_alloc(void** p, size_t bytes)
 {
-    if (hipStream_t s = alloc_stream()) {
-        hipError_t e = hipMallocAsync(p, bytes, s);
+    hipMemPool_t pool = nullptr;
+    if (hipStream_t s = alloc_stream(&pool)) {
+        hipError_t e = hipMallocFromPoolAsync(p, bytes, pool, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);          // (nothing else is ever on this stream: the memory is usable on any stream from here)
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         if (e == hipSuccess) { g_pool_proven = true; return e; }
@@ -98,14 +121,28 @@ void device_free(void* p)
     if (hipStream_t s = alloc_stream()) { (void)hipFreeAsync(p, s); return; }
     (void)hipFree(p);
 }
-// (called right behind a stream synchronisation: nothing still uses these)
-void retire_buffers()
+// context bookkeeping per device: the last one to go returns the pool's memory to the driver
+static void pool_context_created(int dev)
+{
+    if (dev < 0 || dev >= MAX_DEVICES) return;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_pool_contexts[dev] += 1;
+}
+static void pool_context_gone(int dev)
+{
+    if (dev < 0 || dev >= MAX_DEVICES) return;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    if (g_pool_contexts[dev] > 0) g_pool_contexts[dev] -= 1;
+    if (g_pool_contexts[dev] == 0 && g_pool[dev] != nullptr && g_alloc_stream[dev] != nullptr) {
+        (void)hipStreamSynchronize(g_alloc_stream[dev]);           // the frees enqueued by the destructor have landed
+        (void)hipMemPoolTrimTo(g_pool[dev], 0);
+    }
+}
+// (called right behind a synchronisation of the context's stream, its device current: nothing still uses these)
+void retire_buffers(mi_ctx* ctx)
 {
     std::vector<void*> v;
-    {
-        std::lock_guard<std::mutex> lock(g_retired_mutex);
-        v.swap(g_retired);
-    }
+    v.swap(ctx->retired);
     for (void* p : v) device_free(p);
 }
 }  // namespace mislam
@@ -154,7 +191,7 @@ extern "C" int mi_device_count(int* count)
 extern "C" int mi_ctx_preload(mi_ctx* c)
 {
     if (!c) { set_error("mi_ctx_preload: null context"); return MI_ERR_INVALID_ARG; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     MI_HIP(preload_nn_kernel()); MI_HIP(preload_nn_tree()); MI_HIP(preload_nn_grid()); MI_HIP(preload_icp_kernels()); MI_HIP(preload_cpd_kernels());
     MI_HIP(preload_cpd_fgt()); MI_HIP(preload_nicp_api()); MI_HIP(preload_prepare_api());
     return MI_OK;
@@ -170,6 +207,7 @@ static int ctx_create_common(int device, mi_ctx** out)
     MI_HIP(hipSetDevice(device));
     mi_ctx* c = new mi_ctx();
     c->device = device;
+    pool_context_created(device);
     // a failure half way releases what was created so far (mi_ctx_destroy copes with null members)
     const int rc = [&]() -> int {
         hipDeviceProp_t prop;
@@ -293,7 +331,7 @@ extern "C" int mi_ctx_rank(const mi_ctx* ctx, int* rank, int* world)
 extern "C" int mi_dist_info(mi_ctx* c, int* nranks, int* rank, unsigned long long* ranks_seen)
 {
     if (!c) { set_error("mi_dist_info: null context"); return MI_ERR_INVALID_ARG; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     int n = c->world, r = c->rank;
     if (c->comm) {
         MI_NCCL(ncclCommCount(c->comm, &n));
@@ -360,7 +398,7 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    retire_buffers();
+    retire_buffers(c);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->exchange_host) (void)hipHostFree(c->exchange_host);
     for (hipEvent_t e : c->pin_event) if (e) (void)hipEventDestroy(e);
@@ -384,15 +422,16 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    pool_context_gone(c->device);
     delete c;
 }
 
 extern "C" int mi_ctx_synchronize(mi_ctx* c)
 {
     if (!c) { set_error("mi_ctx_synchronize: null context"); return MI_ERR_INVALID_ARG; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     MI_HIP(hipStreamSynchronize(c->stream));
-    retire_buffers();
+    retire_buffers(c);
     return MI_OK;
 }
 
@@ -437,7 +476,7 @@ int mi_ctx::prof_collect()
 extern "C" int mi_profile_enable(mi_ctx* c, int enable)
 {
     if (!c) { set_error("mi_profile_enable: null context"); return MI_ERR_INVALID_ARG; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     MI_TRY(c->prof_collect());
     c->profile = enable != 0;
     return MI_OK;
@@ -453,7 +492,7 @@ extern "C" int mi_profile_select(mi_ctx* c, unsigned int kernel_mask)
 extern "C" int mi_profile_reset(mi_ctx* c)
 {
     if (!c) { set_error("mi_profile_reset: null context"); return MI_ERR_INVALID_ARG; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     MI_TRY(c->prof_collect());
     for (int k = 0; k < MI_KERNEL_COUNT; k++) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
     return MI_OK;
@@ -462,7 +501,7 @@ extern "C" int mi_profile_reset(mi_ctx* c)
 extern "C" int mi_profile_search_stats(mi_ctx* c, int enable, unsigned long long out[8])
 {
     if (!c) { set_error("mi_profile_search_stats: null context"); return MI_ERR_INVALID_ARG; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     const size_t words = (size_t)GRID_STATS_ROWS * 8;
 #ifdef MISLAM_DEV_WAVE_TIMELINE        // developer build: 4 words per wave of the last search behind the counters, dumped to $MISLAM_DEV_TIMELINE_FILE
     const size_t tl_words = (size_t)16 * (1u << 18);
@@ -497,7 +536,7 @@ extern "C" int mi_selftest_sort_pairs(mi_ctx* c, unsigned int* keys, int* values
         return MI_ERR_INVALID_ARG;
     }
     if (n == 0) return MI_OK;
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     DevBuf<unsigned int> k0, k1;
     DevBuf<int> v0, v1;
     DevBuf<unsigned char> temp;
@@ -515,7 +554,7 @@ extern "C" int mi_selftest_sort_pairs(mi_ctx* c, unsigned int* keys, int* values
 extern "C" int mi_profile_get(mi_ctx* c, int kernel, double* total_ms, long long* launches)
 {
     if (!c || kernel < 0 || kernel >= MI_KERNEL_COUNT) { set_error("mi_profile_get: bad argument"); return MI_ERR_INVALID_ARG; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     MI_TRY(c->prof_collect());
     if (total_ms) *total_ms = c->prof_ms[kernel];
     if (launches) *launches = c->prof_n[kernel];
@@ -866,7 +905,7 @@ static int icp_check_params(const mi_icp_params* p)
 extern "C" int mi_icp_reset(mi_ctx* c)
 {
     if (!c || !c->icp_loaded) { set_error("mi_icp_reset: no problem loaded"); return MI_ERR_STATE; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     state_identity(c->h_state);
     if (c->icp.max_iterations == 0) {   // "while (iterations < maxIterations)" never enters
         c->h_state->done = 1;
@@ -884,7 +923,7 @@ extern "C" int mi_icp_reset(mi_ctx* c)
     }
     MI_HIP(icp_schedule_reset(make_schedule(c), icp_row_count(c->n), c->stream));
     MI_HIP(hipStreamSynchronize(c->stream));
-    retire_buffers();
+    retire_buffers(c);
     return MI_OK;
 }
 
@@ -896,7 +935,7 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
     if (n_after < c->world || n_before < c->world) { set_error("mi_icp_load: fewer points (%d, %d) than ranks (%d)", n_before, n_after, c->world); return MI_ERR_INVALID_ARG; }
     MI_TRY(icp_check_params(params));
     if (params->sum_mode == MI_SUM_CPU_SEQUENTIAL && c->distributed()) { set_error("mi_icp_load: MI_SUM_CPU_SEQUENTIAL needs a single-GPU context (the running sums follow one global point order)"); return MI_ERR_INVALID_ARG; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     // mi_icp_load_times: host wall time per stage; with profiling on, the stream is drained at every mark
     const double t_begin = wall_ms();
     double t_mark = t_begin, a_mark = alloc_ms_counter();
@@ -1057,11 +1096,12 @@ static int icp_enqueue_iteration(mi_ctx* c)
         int* cursors = c->fused ? sched.counters : nullptr;
         if (c->distributed()) {
             // ONE all-reduce per iteration: this iteration's 16 moments and the previous iteration's 2 error sums ride together -- as
-            // the REDUCED ROWS themselves (64 x 18 doubles, the rows past this rank's own count are zero: every rank sends the same
-            // length whatever its share), so that the solve kernel adds them up exactly as on one GPU and no kernel sits between
+            // the REDUCED ROWS themselves (64 x 18 doubles, the rows past this rank's own count written as zeros EVERY iteration -- the
+            // collective is in place, and a rank with fewer rows than its neighbour would otherwise re-send the neighbour's sums: every
+            // rank sends the same length whatever its share), so that the solve kernel adds them up exactly as on one GPU and no kernel sits between
             // the reduction and the collective (a 9 KB all-reduce is as latency-bound as a 144-byte one)
             (void)reduced;
-            { ProfScope ps(c, MI_KERNEL_SOLVE); MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream, c->fused ? &sched : nullptr)); }
+            { ProfScope ps(c, MI_KERNEL_SOLVE); MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream, c->fused ? &sched : nullptr, true)); }
             { ProfScope ps(c, MI_KERNEL_ALLREDUCE); MI_TRY(allreduce_doubles(c, c->rows_reduced.p, ICP_REDUCED_ROWS * (ICP_MOMENTS + ICP_ERRSUMS))); }
             ProfScope ps(c, MI_KERNEL_SOLVE);
             MI_HIP(icp_solve_deferred(c->d_state, c->rows_reduced.p, ICP_REDUCED_ROWS, c->icp.compose_mode, rules, 1, c->stream, cursors));
@@ -1083,7 +1123,7 @@ static int icp_fetch_state(mi_ctx* c)
 {
     { StallProbe sp("fetch_state: enqueue copy"); MI_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream)); }
     { StallProbe sp("fetch_state: stream synchronize"); MI_HIP(hipStreamSynchronize(c->stream)); }
-    { StallProbe sp("fetch_state: retire buffers"); retire_buffers(); }
+    { StallProbe sp("fetch_state: retire buffers"); retire_buffers(c); }
     return MI_OK;
 }
 
@@ -1099,7 +1139,7 @@ extern "C" int mi_icp_auto_batch(long long n_moving_total, long long m_fixed_tot
 extern "C" int mi_icp_run(mi_ctx* c, int max_new_iterations, int* iterations_done)
 {
     if (!c || !c->icp_loaded) { set_error("mi_icp_run: no problem loaded"); return MI_ERR_STATE; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     MI_TRY(icp_fetch_state(c));
     const int passes_before = c->h_state->passes;
     int batch = c->icp.sync_every;
@@ -1140,7 +1180,7 @@ extern "C" int mi_icp_run(mi_ctx* c, int max_new_iterations, int* iterations_don
 extern "C" int mi_icp_result(mi_ctx* c, float out_T[16], int* iterations, float* error, int* stop_reason)
 {
     if (!c || !c->icp_loaded) { set_error("mi_icp_result: no problem loaded"); return MI_ERR_STATE; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     MI_TRY(icp_fetch_state(c));
     const IcpState* s = c->h_state;
     if (out_T) {
@@ -1184,7 +1224,7 @@ extern "C" int mi_nn_search_ex(mi_ctx* c, const float* src_xyz, int n, const flo
     if (n == 0) return MI_OK;
     if (m == 0) { set_error("mi_nn_search: empty target cloud"); return MI_ERR_INVALID_ARG; }
     if (m < c->world) { set_error("mi_nn_search: fewer targets than ranks"); return MI_ERR_INVALID_ARG; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     c->icp_loaded = false;   // the workspace is being reused
     const int n_pad = round_up(n, NN_SRC_PAD);
     MI_TRY(c->bx.reserve((size_t)n_pad)); MI_TRY(c->by.reserve((size_t)n_pad)); MI_TRY(c->bz.reserve((size_t)n_pad));
@@ -1209,7 +1249,7 @@ extern "C" int mi_nn_search_ex(mi_ctx* c, const float* src_xyz, int n, const flo
 // Shared set-up of mi_kabsch / mi_transform_mse: source -> (b, c), target -> tgt4, caller's correspondences -> keys.
 static int load_pairs(mi_ctx* c, const float* src_xyz, int n, const float* tgt_xyz, int m, const int* idx, const unsigned char* keep)
 {
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     c->icp_loaded = false;
     if (c->world != 1) { set_error("this primitive is single-GPU only"); return MI_ERR_STATE; }
     for (int i = 0; idx && i < n; i++)

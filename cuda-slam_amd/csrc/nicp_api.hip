@@ -310,7 +310,7 @@ extern "C" int mi_nicp_register(mi_ctx* c, const float* before_xyz, int m_before
     if (subcloud_idx)
         for (int i = 0; i < subcloud_n; i++)
             if (subcloud_idx[i] < 0 || subcloud_idx[i] >= m_before) { set_error("mi_nicp_register: subcloud_idx[%d] out of range", i); return MI_ERR_INVALID_ARG; }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
     c->icp_loaded = false;
 
     // ---- one pass over both clouds: centroids, Gram matrices, pair sums

@@ -254,7 +254,7 @@ extern "C" int mi_prepare_cloud(mi_ctx* c, const float* raw_xyz, int n_raw, cons
             set_error("mi_prepare_cloud: noise_rows must be ascending rows of the prepared cloud (entry %d = %d)", q, noise_rows[q]);
             return MI_ERR_INVALID_ARG;
         }
-    MI_HIP(hipSetDevice(c->device));
+    MI_ENTER(c);
 
     Scratch s;
     float *d_raw, *d_out, *d_partials, *d_noise_unit = nullptr, *d_outlier_unit = nullptr;

@@ -289,7 +289,9 @@ void mi_cpd_params_default(mi_cpd_params* p);
 /* out_sR_t: column-major 4x4 holding scale*R (cpdcuda.cu:360) and t; out_scale may be NULL.
  * On a multi-GPU context (mi_ctx_create_dist) every rank passes both clouds whole and keeps fixed points mi_shard_range(n_after);
  * one all-reduce of 24 doubles per EM iteration merges the M-step moments, every rank returns the same result.  The FGT modes
- * (approximation != MI_CPD_APPROX_NONE) need a single-rank context. */
+ * (approximation != MI_CPD_APPROX_NONE; hybrid is the reference parser's default, configparser.cpp:217) run REPLICATED there:
+ * every rank keeps both clouds whole and does the same arithmetic (their E-step is O((N + M) K)), no collective, the single-GPU
+ * run's bits on every rank. */
 int mi_cpd_register(mi_ctx* ctx, const float* before_xyz, int m_before, const float* after_xyz, int n_after,
                     const mi_cpd_params* params, float out_sR_t[16], float* out_scale, int* iterations, float* error);
 

@@ -82,6 +82,18 @@ def main():
             b = sctx.icp_register(sb, sa, p)
             assert a[2] == b[2] == 6 and frob(a[0], a[1], b[0], b[1]) < 1e-6, shard_mode
 
+        # shares whose REDUCED-ROW counts differ between the ranks (33 chunks of 64 points reduce to 2 rows, 32 chunks to 1): the
+        # in-place all-reduce of the 64 reduced rows must not carry a neighbour's sums of the previous iteration into the next
+        # one (it did until round 4: wrong moments from the second iteration on)
+        n_odd = 64 * 65 if world == 2 else 64 * 97
+        ob, oa = synth_cloud(n_odd, m=n_odd + 37, seed=11)[:2]
+        for nn_mode in (capi.NN_BRUTEFORCE, capi.NN_GRID):
+            for its in (2, 5):
+                p = capi.icp_params(eps=0.0, max_iterations=its, shard_mode=capi.SHARD_SOURCE, nn_mode=nn_mode)
+                a = dctx.icp_register(ob, oa, p)
+                b = sctx.icp_register(ob, oa, p)
+                assert a[2] == b[2] == its and frob(a[0], a[1], b[0], b[1]) < 1e-6 and abs(a[3] - b[3]) < 1e-7, (nn_mode, its, frob(a[0], a[1], b[0], b[1]))
+
         # rigid CPD with the fixed cloud sharded: the per-point sums are fp32 in a different order, hence 1e-4 like the
         # bar against cpu-slam itself
         for kw in (dict(max_iterations=50), dict(max_iterations=9, const_scale=1)):
@@ -90,13 +102,18 @@ def main():
             cb = sctx.cpd_register(before, after, cp)
             assert ca[3] == cb[3], (kw, ca[3], cb[3])
             assert frob(ca[0], ca[1], cb[0], cb[1]) < 1e-4 and abs(ca[2] - cb[2]) < 1e-5, kw
-        # the Fast Gauss Transform modes need the whole fixed cloud on one GPU
-        try:
-            dctx.cpd_register(before, after, capi.cpd_params(max_iterations=3, approximation=capi.CPD_APPROX_HYBRID))
-            raise AssertionError("the hybrid mode must be refused on %d ranks" % world)
-        except capi.MiSlamError:
-            pass
         assert calls[capi.EXCHANGE_SUM_F64] > 50
+        # the Fast Gauss Transform modes (hybrid is the reference parser's default, configparser.cpp:217) run REPLICATED on a
+        # multi-rank context: whole clouds on every rank, no collective, the single-GPU run's bits
+        n_sum = calls[capi.EXCHANGE_SUM_F64]
+        for approx, kw in ((capi.CPD_APPROX_HYBRID, dict(max_iterations=50)), (capi.CPD_APPROX_FULL, dict(max_iterations=5)),
+                           (capi.CPD_APPROX_HYBRID, dict(max_iterations=50, sigma2_mode=capi.SIGMA2_CPU_SEQUENTIAL))):
+            cp = capi.cpd_params(approximation=approx, **kw)
+            ca = dctx.cpd_register(before, after, cp)
+            cb = sctx.cpd_register(before, after, cp)
+            assert ca[3] == cb[3] and ca[2] == cb[2] and ca[4] == cb[4], (approx, kw, ca[3], cb[3])
+            assert np.array_equal(np.asarray(ca[0]), np.asarray(cb[0])) and np.array_equal(np.asarray(ca[1]), np.asarray(cb[1])), (approx, kw)
+        assert calls[capi.EXCHANGE_SUM_F64] == n_sum, "a replicated registration must not call the transport"
 
     dist.barrier()
     dist.destroy_process_group()
