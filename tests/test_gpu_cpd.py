@@ -100,9 +100,15 @@ def test_bunny_cpd_matches_cpu_slam(ctx, capi, golden, bunny):
     sR, t, scale, it, err = ctx.cpd_register(before, after, p)
     assert it == f["iterations"]
     d = frob(sR, t, f["sR"], f["t"])
-    print("bunny CPD |d(sR|t)|_F vs cpu-slam = %.3e" % d)
+    print("bunny CPD |d(sR|t)|_F vs cpu-slam = %.3e, final sigma^2 %.4g (cpu-slam %.4g)" % (d, err, f["error"]))
     assert d < 1e-4
-    assert abs(err - f["error"]) < 1e-4
+    # `error` is the final sigma^2 (cpdcuda.cu:355): at convergence a difference of O(10) sums, i.e. cancellation noise of the M-step's
+    # arithmetic -- cpu-slam's fp32 M-step lands on 6.7e-5, the fp64-summing restatement on 9.8e-5.  The HIP path sums in fp64 like
+    # the restatement: within 15 % of IT (measured: +5 % with the MFMA contraction, -2 % with the VALU one); against cpu-slam only
+    # the size of that noise can be stated (4e-5 on a quantity that started at 3.6)
+    o = golden.json("bunny_cpd_oracle.json")["final_scale_free"]
+    assert abs(err - o["error"]) <= 0.15 * o["error"]
+    assert abs(err - f["error"]) <= 6e-5
 
 
 def test_sigma_squared_cpu_sequential_is_cpu_slams_own_number(ctx, capi, oracle, golden, bunny):
