@@ -296,6 +296,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sizes", action="store_true", help="skip the N = 1e4 / 1e5 / 1e7 legs")
     ap.add_argument("--no-whole-call", action="store_true", help="skip the whole-registration legs (host buffers in, 50 iterations)")
+    ap.add_argument("--no-cpd", action="store_true", help="skip the CPD leg (cfg 4 on the bunny clouds)")
     ap.add_argument("--shard", choices=["auto", "target", "source"], default="auto",
                     help="what N > 1 GPUs split: auto = moving cloud for the indexed searches, fixed cloud for the every-pair search")
     ap.add_argument("--brute-ref-steps", type=int, default=2,
@@ -519,7 +520,7 @@ def main():
     # bunny clouds from cpu-slam's own sigma^2_0 -- exact P and the parser's default hybrid mode.  One GPU by default; with
     # MISLAM_BENCH_CPD=1 also on N > 1 (fixed cloud sharded, one 24-double all-reduce per EM iteration).
     cpd = None
-    if world == 1 or os.environ.get("MISLAM_BENCH_CPD") == "1":
+    if not args.no_cpd and (world == 1 or os.environ.get("MISLAM_BENCH_CPD") == "1"):
         cpd = cpd_bunny(np, capi, ctx, world)
 
     # Outside the timed region too: whole registrations on host buffers, as the reference times a SlamFunc

@@ -213,14 +213,15 @@ __global__ __launch_bounds__(64) void icp_rows_to_state_kernel(IcpState* __restr
 __device__ void solve_from_moments(const double* mom, const float* seq_b, const float* seq_a, float Ri[9], float ti[3])
 {
     const double n = mom[0];
-    const double cbx = mom[1] / n, cby = mom[2] / n, cbz = mom[3] / n;
-    const double cax = mom[4] / n, cay = mom[5] / n, caz = mom[6] / n;
+    const double inv_n = 1.0 / n;            // (n is a count: one fp64 division instead of six on the one-lane chain)
+    const double cbx = mom[1] * inv_n, cby = mom[2] * inv_n, cbz = mom[3] * inv_n;
+    const double cax = mom[4] * inv_n, cay = mom[5] * inv_n, caz = mom[6] * inv_n;
     const double ca[3] = {cax, cay, caz}, cb[3] = {cbx, cby, cbz};
     // H = sum (a - ca)(b - cb)^T = sum a b^T - n ca cb^T   (alignedAfter * alignedBefore^T, common.cpp:530)
     Mat3 H;
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) H.a[r][c] = (float)(mom[7 + 3 * r + c] - n * ca[r] * cb[c]);
-    const Kabsch3 k = kabsch_rotation(H);
+    const Kabsch3 k = kabsch_rotation<true>(H);     // (svd3.hpp SvdMath: hardware reciprocals and roots for the rotation parameters)
     // column-major like glm::mat3 (ConvertRotationMatrix, common.cpp:335-346)
     for (int c = 0; c < 3; c++)
         for (int r = 0; r < 3; r++) Ri[3 * c + r] = k.R.a[r][c];

@@ -19,6 +19,68 @@ struct Mat3 {
     float a[3][3];   // a[row][col]
 };
 
+// The solve runs on ONE lane, a chain of dependent instructions: what it costs is the length of that chain (round 3: ~3 600
+// instructions, among them 37 IEEE divisions at ~10 instructions each and 9 correctly rounded square roots).  FAST (device code
+// only) takes the quotients and roots that feed the rotations through the hardware approximations refined by fused multiply-adds:
+// v_rcp_f32 + two residual steps (6 instructions), v_rsq_f32 + one (4), the root as x * rsq + one (5).  Eigen's sweep order, skip
+// thresholds, sign fix and sort are untouched; the result moves by rounding, not in kind (bunny: 1.4e-5 from cpu-slam after 39
+// iterations, IEEE 1.2e-5).  FAST = false is the IEEE form (host code, and the non-iterative method, whose sign pattern is compared
+// with the reference's permutation by permutation).
+#ifndef MISLAM_SVD_REFINE
+#define MISLAM_SVD_REFINE 1
+#endif
+// (What matters is not the size of the rounding but its BIAS: a rotation whose c^2 + s^2 errs to one side scales U, V and so R, and
+// the ICP driver COMPOSES 40 of those -- measured on the bunny clouds: Newton steps written with separate multiplies and adds land
+// 4e-4 from cpu-slam after 39 iterations, the raw hardware forms 2.3e-5, IEEE 1.2e-5.  Hence residuals through fused multiply-adds:
+// each refinement step then ends in ONE rounding of an almost exact value, like the IEEE operation it replaces.)
+template <bool FAST>
+struct SvdMath {
+    static __host__ __device__ __forceinline__ float div(float a, float b)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (FAST) {
+            float r = __builtin_amdgcn_rcpf(b);
+#if MISLAM_SVD_REFINE
+            r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.f), r, r);           // r <- r + r (1 - b r)
+            const float q = a * r;
+            return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);          // q <- q + r (a - b q): the quotient to the last bit but for rare ties
+#else
+            return a * r;
+#endif
+        }
+#endif
+        return a / b;
+    }
+    static __host__ __device__ __forceinline__ float rsqrt(float x)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (FAST) {
+            float y = __builtin_amdgcn_rsqf(x);
+#if MISLAM_SVD_REFINE
+            y = __builtin_fmaf(0.5f * y, __builtin_fmaf(-x * y, y, 1.f), y);  // y <- y + (y / 2) (1 - x y^2)
+#endif
+            return y;
+        }
+#endif
+        return 1.f / sqrtf(x);
+    }
+    static __host__ __device__ __forceinline__ float sqrt(float x)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (FAST) {
+#if MISLAM_SVD_REFINE
+            const float y = __builtin_amdgcn_rsqf(x);                        // (x >= 1 at every call site: no 0 * inf)
+            const float r = x * y;
+            return __builtin_fmaf(__builtin_fmaf(-r, r, x), 0.5f * y, r);    // r <- r + (x - r^2) / (2 r)
+#else
+            return __builtin_amdgcn_sqrtf(x);
+#endif
+        }
+#endif
+        return sqrtf(x);
+    }
+};
+
 struct Rot2 {
     float c, s;
     __host__ __device__ bool identity() const { return c == 1.f && s == 0.f; }
@@ -47,15 +109,17 @@ __host__ __device__ inline void rotate_cols(Mat3& m, int p, int q, Rot2 j)
 }
 
 // Jacobi rotation diagonalising the symmetric 2x2 [[x, y], [y, z]]
+template <bool FAST = false>
 __host__ __device__ inline Rot2 symmetric_jacobi(float x, float y, float z)
 {
+    using M = SvdMath<FAST>;
     const float deno = 2.f * fabsf(y);
     if (deno < FLT_MIN) return Rot2{1.f, 0.f};
-    const float tau = (x - z) / deno;
-    const float w = sqrtf(tau * tau + 1.f);
-    const float t = (tau > 0.f) ? 1.f / (tau + w) : 1.f / (tau - w);
+    const float tau = M::div(x - z, deno);
+    const float w = M::sqrt(tau * tau + 1.f);
+    const float t = M::div(1.f, (tau > 0.f) ? tau + w : tau - w);
     const float sign_t = t > 0.f ? 1.f : -1.f;
-    const float n = 1.f / sqrtf(t * t + 1.f);
+    const float n = M::rsqrt(t * t + 1.f);
     // (y / |y| of Eigen's makeJacobi: +-1 exactly -- |y| >= FLT_MIN / 2 here -- so a sign copy, not a division)
     return Rot2{n, -sign_t * copysignf(1.f, y) * fabsf(t) * n};
 }
@@ -65,8 +129,10 @@ struct Svd3 {
     float S[3];
 };
 
+template <bool FAST = false>
 __host__ __device__ inline Svd3 svd3(const Mat3& A)
 {
+    using M = SvdMath<FAST>;
     const float precision = 2.f * FLT_EPSILON;
     float scale = 0.f;
     for (int r = 0; r < 3; r++)
@@ -75,9 +141,11 @@ __host__ __device__ inline Svd3 svd3(const Mat3& A)
 
     Mat3 W;
     Svd3 out;
+    // (FAST: one reciprocal of the scale; the singular values are scaled back by `scale` itself below, and R does not depend on it)
+    const float inv_scale = FAST ? M::div(1.f, scale) : 0.f;
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) {
-            W.a[r][c] = A.a[r][c] / scale;
+            W.a[r][c] = FAST ? A.a[r][c] * inv_scale : A.a[r][c] / scale;
             out.U.a[r][c] = out.V.a[r][c] = (r == c) ? 1.f : 0.f;
         }
     float max_diag = fmaxf(fabsf(W.a[0][0]), fmaxf(fabsf(W.a[1][1]), fabsf(W.a[2][2])));
@@ -96,9 +164,14 @@ __host__ __device__ inline Svd3 svd3(const Mat3& A)
                 const float tr = m00 + m11, d = m10 - m01;
                 if (fabsf(d) < FLT_MIN) sym = Rot2{1.f, 0.f};
                 else {
-                    const float u = tr / d;
-                    const float h = sqrtf(1.f + u * u);
-                    sym = Rot2{u / h, 1.f / h};
+                    const float u = M::div(tr, d);
+                    if (FAST) {
+                        const float ih = M::rsqrt(1.f + u * u);
+                        sym = Rot2{u * ih, ih};
+                    } else {
+                        const float h = sqrtf(1.f + u * u);
+                        sym = Rot2{u / h, 1.f / h};
+                    }
                 }
                 if (!sym.identity()) {
                     const float a0 = m00, a1 = m01, b0 = m10, b1 = m11;
@@ -106,7 +179,7 @@ __host__ __device__ inline Svd3 svd3(const Mat3& A)
                     m10 = -sym.s * a0 + sym.c * b0; m11 = -sym.s * a1 + sym.c * b1;
                 }
                 // ... then the Jacobi rotation of the symmetric block; left = sym * right^T
-                const Rot2 right = symmetric_jacobi(m00, m01, m11);
+                const Rot2 right = symmetric_jacobi<FAST>(m00, m01, m11);
                 const Rot2 left{sym.c * right.c + sym.s * right.s, sym.s * right.c - sym.c * right.s};
                 const Rot2 right_t{right.c, -right.s};
                 rotate_rows(W, p, q, left);
@@ -171,9 +244,10 @@ struct Kabsch3 {
     float det;
 };
 
+template <bool FAST = false>
 __host__ __device__ inline Kabsch3 kabsch_rotation(const Mat3& H)
 {
-    const Svd3 s = svd3(H);
+    const Svd3 s = svd3<FAST>(H);
     Kabsch3 k;
     k.det = det3(mul_abt(s.U, s.V));
     Mat3 Ud = s.U;

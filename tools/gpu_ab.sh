@@ -6,7 +6,7 @@ for rep in $(seq ${REPS:-1}); do
 for v in product "$@"; do
   if [ $v = product ]; then unset MISLAM_LIB; else export MISLAM_LIB=$GRAFT_REPO_ROOT/cuda-slam_amd/variants/libmislam_$v.so; fi
   echo "== $v"
-  timeout -k 10 300 python bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --no-sizes --brute-ref-steps 0 ${BENCH_ARGS} 2>&1 | python -c "
+  timeout -k 10 300 python bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --no-sizes --no-cpd --no-whole-call --brute-ref-steps 0 ${BENCH_ARGS} 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
