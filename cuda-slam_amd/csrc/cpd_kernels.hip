@@ -59,6 +59,27 @@ __device__ __forceinline__ float affinity(float index, float trunc_log)
     return exp_neg(index);
 }
 
+// The same affinity for TWO fixed points at once, as packed fp32 operations (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: the same IEEE
+// operations, two results per issue slot -- bit for bit what two calls of affinity() return).  The two points' coordinates are register
+// PAIRS straight out of the batched scalar loads; only the two v_exp_f32 stay single.
+typedef float cpd_f32x2 __attribute__((ext_vector_type(2)));
+template <bool TRUNC>
+__device__ __forceinline__ cpd_f32x2 affinity2(float mult, cpd_f32x2 ax, cpd_f32x2 ay, cpd_f32x2 az, float bx, float by, float bz, float trunc_log)
+{
+    const cpd_f32x2 dx = ax - (cpd_f32x2){bx, bx}, dy = ay - (cpd_f32x2){by, by}, dz = az - (cpd_f32x2){bz, bz};
+    const cpd_f32x2 d = (dx * dx + dy * dy) + dz * dz;
+    const cpd_f32x2 x = (cpd_f32x2){mult, mult} * d;
+    const cpd_f32x2 L_hi = {1.44269502162933349609375f, 1.44269502162933349609375f}, L_lo = {1.925963033500011e-08f, 1.925963033500011e-08f};
+    const cpd_f32x2 ln2 = {0.693147182464599609375f, 0.693147182464599609375f};
+    const cpd_f32x2 h = x * L_hi;
+    cpd_f32x2 r = __builtin_elementwise_fma(x, L_hi, -h);
+    r = __builtin_elementwise_fma(x, L_lo, r);
+    const cpd_f32x2 e = {__builtin_amdgcn_exp2f(h.x), __builtin_amdgcn_exp2f(h.y)};
+    cpd_f32x2 p = __builtin_elementwise_fma(e * r, ln2, e);
+    if (TRUNC) { p.x = x.x < trunc_log ? 0.f : p.x; p.y = x.y < trunc_log ? 0.f : p.y; }
+    return p;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // sigma^2 initialisation: sum_ij |b_i - a_j|^2 = N sum|b|^2 + M sum|a|^2 - 2 (sum a).(sum b), O(M+N) in fp64
 // (CalculateSigmaSquared, cpdcuda.cu:65-78, is O(M*N); see mi_slam.h on why the closed form is used)
@@ -377,28 +398,42 @@ __global__ __launch_bounds__(256) void cpd_contract_mfma_kernel(CpdView v)
     // (the NEXT block's coordinates and operand words are requested before the current block is worked on: a block's loads then
     //  have a whole block of arithmetic to arrive in, instead of being waited for where they are issued)
     int x = x_begin;
-    float cax[CPD_T], cay[CPD_T], caz[CPD_T], cb[CPD_T];
     const int n_blocks = (x_end - x_begin) / CPD_T;
-    if (n_blocks > 0) {
+    // Two register sets, A and B, taken in turns (round 4): while one block is worked on, the OTHER set's loads are in flight -- a block's
+    // coordinates (batched scalar loads) and operand words then have a whole block of arithmetic to arrive in.  (Round 3 requested the next
+    // block into a second set and COPIED it over at the end of the trip: the copies wait for every load of the trip, so each trip ended in
+    // s_waitcnt vmcnt(0) and began in s_waitcnt lgkmcnt(0) -- both round trips exposed.)
+    auto load_block = [&](float (&bx)[CPD_T], float (&by)[CPD_T], float (&bz)[CPD_T], float (&bw)[CPD_T], int xb) {
 #pragma unroll
-        for (int u = 0; u < CPD_T; u++) { cax[u] = v.ax[x + u]; cay[u] = v.ay[x + u]; caz[u] = v.az[x + u]; cb[u] = wrec[4 * (size_t)(x + u) + (lane & 3)]; }
-    }
-    for (int blk = 0; blk < n_blocks; blk++, x += CPD_T) {
-        float nax[CPD_T], nay[CPD_T], naz[CPD_T], nb[CPD_T];
-        const int xn = blk + 1 < n_blocks ? x + CPD_T : x;           // (the last block requests itself again: no branch in the loop)
+        for (int u = 0; u < CPD_T; u++) { bx[u] = v.ax[xb + u]; by[u] = v.ay[xb + u]; bz[u] = v.az[xb + u]; bw[u] = wrec[4 * (size_t)(xb + u) + (lane & 3)]; }
+    };
+    // two fixed points per trip: their affinities as packed operations (round 4: 15.4 -> ~9 vector instructions per pair, the figure of
+    // K7a, whose lanes own four fixed points and pack by themselves); the matrix instructions stay in x order -- the same bits
+    static_assert(CPD_T % 2 == 0, "fixed points are taken in pairs");
+    auto work_block = [&](const float (&bx)[CPD_T], const float (&by)[CPD_T], const float (&bz)[CPD_T], const float (&bw)[CPD_T]) {
 #pragma unroll
-        for (int u = 0; u < CPD_T; u++) { nax[u] = v.ax[xn + u]; nay[u] = v.ay[xn + u]; naz[u] = v.az[xn + u]; nb[u] = wrec[4 * (size_t)(xn + u) + (lane & 3)]; }
+        for (int u = 0; u < CPD_T; u += 2) {
+            cpd_f32x2 p[R];
 #pragma unroll
-        for (int u = 0; u < CPD_T; u++) {
-            float p[R];
+            for (int r = 0; r < R; r++)
+                p[r] = affinity2<TRUNC>(mult, (cpd_f32x2){bx[u], bx[u + 1]}, (cpd_f32x2){by[u], by[u + 1]}, (cpd_f32x2){bz[u], bz[u + 1]}, yx[r], yy[r], yz[r], v.trunc_log);
 #pragma unroll
-            for (int r = 0; r < R; r++) p[r] = affinity<TRUNC>(mult * sq_dist(cax[u], cay[u], caz[u], yx[r], yy[r], yz[r]), v.trunc_log);
-#pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(p[r], cb[u], acc[r], 0, 0, 0);
+            for (int r = 0; r < R; r++) {
+                acc[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(p[r].x, bw[u], acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(p[r].y, bw[u + 1], acc[r], 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int u = 0; u < CPD_T; u++) { cax[u] = nax[u]; cay[u] = nay[u]; caz[u] = naz[u]; cb[u] = nb[u]; }
+    };
+    float Ax[CPD_T], Ay[CPD_T], Az[CPD_T], Aw[CPD_T], Bx[CPD_T], By[CPD_T], Bz[CPD_T], Bw[CPD_T];
+    if (n_blocks > 0) load_block(Ax, Ay, Az, Aw, x);
+    int blk = 0;
+    for (; blk + 1 < n_blocks; blk += 2, x += 2 * CPD_T) {
+        load_block(Bx, By, Bz, Bw, x + CPD_T);
+        work_block(Ax, Ay, Az, Aw);
+        load_block(Ax, Ay, Az, Aw, blk + 2 < n_blocks ? x + 2 * CPD_T : x);      // (past the last block: request a loaded one again, no branch)
+        work_block(Bx, By, Bz, Bw);
     }
+    if (blk < n_blocks) { work_block(Ax, Ay, Az, Aw); x += CPD_T; }
     for (; x < x_end; x++) {
         const float ax = v.ax[x], ay = v.ay[x], az = v.az[x];
         const float b = wrec[4 * (size_t)x + (lane & 3)];
