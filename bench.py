@@ -40,6 +40,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0                      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD-32 x 2.4 GHz: fp32 lane-instructions/s (= 157.3 TFLOP/s / 2)
 VALU_WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 2  # a wave64 instruction occupies a SIMD-32 for two cycles (MI355X_MICROARCH.md constants)
+VALU_BUSY_CEILING = 1024 / 4 / 8           # what SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE can read at most: 1 024 SIMDs, one wave instruction per four
+                                           # cycles, GUI cycles summed over the 8 XCDs (tools/valu_probe reads 29.2 of it, the every-pair kernel 31.0)
 OPS_PER_PAIR = {0: 8.5, 1: 6.5}            # 3 sub + 3 mul + 2 add (or 1 mul + 2 fma) + 1/2 min3, per candidate pair
 SWEEP_SIZES = (10000, 100000, 10000000)
 
@@ -238,17 +240,36 @@ def cpd_bunny(np, capi, ctx, world):
             cal, cal_src = valu_calibration()
             if prof_c is not None and cal is not None and "kernels" in prof_c and world == 1:
                 sat = cal["kernels"]["valu_probe<0>"]["valu_busy_quadcycles_per_gui_cycle"]
-                ks = {k: v for k, v in prof_c["kernels"].items() if v.get("valu_busy_quadcycles_per_gui_cycle") and v.get("launch_ms")}
+                ceiling = cal.get("valu_busy_ceiling", VALU_BUSY_CEILING)
+                # the kernels of the EXACT mode only: the `<.., true>` instantiations are the hybrid mode's truncated E-step
+                ks = {k: v for k, v in prof_c["kernels"].items()
+                      if v.get("valu_busy_quadcycles_per_gui_cycle") and v.get("launch_ms") and not k.rstrip().endswith("true>")}
                 if ks:
                     t_all = sum(v["launch_ms"] for v in ks.values())
                     busy = sum(v["valu_busy_quadcycles_per_gui_cycle"] * v["launch_ms"] for v in ks.values()) / t_all
-                    leg["roofline"] = {"bound": "fp32-valu-issue", "achieved": busy, "peak": sat, "unit": "vector-pipe busy quad-cycles per GPU cycle",
-                                       "frac": busy / sat, "calibration_source": cal_src, "source": src,
-                                       "kernels": {k: {"launch_ms": v["launch_ms"], "frac": v["valu_busy_quadcycles_per_gui_cycle"] / sat,
+                    every_pair = cal["kernels"].get("nn_bruteforce_kernel", {}).get("valu_busy_quadcycles_per_gui_cycle")
+                    leg["roofline"] = {"bound": "fp32-valu-issue", "achieved": busy, "peak": ceiling, "unit": "vector-pipe busy quad-cycles per GPU cycle",
+                                       "frac": busy / ceiling,
+                                       "peak_is": "the counter's ceiling: 1 024 SIMDs / 4 cycles per wave instruction / 8 XCDs summed in GRBM_GUI_ACTIVE",
+                                       "probe_reads": sat, "every_pair_kernel_reads": every_pair, "frac_of_probe": busy / sat,
+                                       "calibration_source": cal_src, "source": src,
+                                       "kernels": {k: {"launch_ms": v["launch_ms"], "frac": v["valu_busy_quadcycles_per_gui_cycle"] / ceiling,
+                                                       "frac_of_probe": v["valu_busy_quadcycles_per_gui_cycle"] / sat,
                                                        "valu_instructions_per_pair": v["SQ_INSTS_VALU"] * 64.0 / pairs if v.get("SQ_INSTS_VALU") else None}
                                                    for k, v in ks.items()},
-                                       "note": "time-weighted over the two E-step kernels; packed instructions count by the time they hold the pipe, not as one; "
+                                       "note": "time-weighted over the two E-step kernels of the exact mode; packed instructions count by the time they hold the pipe, not as one; "
                                                "the contraction's 4 FMAs per pair run on the matrix pipe (MFMA 4x4x1) when that form is selected"}
+                    mf = [v["mfma"] for k, v in ks.items() if "mfma" in k and v.get("mfma")]
+                    if mf:      # north_star: "MFMA utilisation against the chip's peak" -- the contraction kernel's matrix pipe, from its own counter pass
+                        m0 = mf[0]
+                        leg["roofline"]["mfma_util"] = m0["mfma_util"]
+                        leg["roofline"]["mfma"] = {"busy_cycles_per_launch": m0["SQ_VALU_MFMA_BUSY_CYCLES"], "gpu_cycles_per_launch": m0["gpu_cycles"],
+                                                   "flops_on_matrix_pipe_per_launch": m0["mfma_flops_per_launch"],
+                                                   "contraction_flops_per_launch": m0["contraction_flops_per_launch"],
+                                                   "share_of_contraction_on_matrix_pipe": m0["mfma_flops_per_launch"] / m0["contraction_flops_per_launch"],
+                                                   "source": src,
+                                                   "note": "fp32 MFMA peak = fp32 vector peak on this chip; a 4-FMA-per-pair contraction beside ~9 vector "
+                                                           "instructions per pair of affinity arithmetic cannot fill the matrix pipe -- what it buys is those FMAs off the binding pipe"}
         out[label] = leg
     return out
 
@@ -437,6 +458,13 @@ def main():
     params = capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=nn_mode, shard_mode=shard_mode, sync_every=max(args.steps, 1))
     elapsed, nn_prof = timed_run(before, after, params, args.warmup, args.steps)
     R, t, iters, err, why = ctx.icp_result()
+    # the same steps with the library's OWN host-check interval (sync_every = 0 -> mi_icp_auto_batch: 16 at this size on one GPU): what a
+    # registration pays per iteration when the host looks at the state as often as mi_icp_run does by default (a flush + a read-back per batch)
+    params_default = capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=nn_mode, shard_mode=shard_mode, sync_every=0)
+    elapsed_default, _ = timed_run(before, after, params_default, args.warmup, args.steps)
+    auto_batch = capi.icp_auto_batch(n, m, world, pl["source_sharded"], not pl["indexed"])
+    # (the legs below continue from the headline's registration state: reload it)
+    timed_run(before, after, params, args.warmup, args.steps)
     headline_allreduce = None
     # per-kernel breakdown of a step: a few more (untimed) iterations with events around every kernel
     ctx.profile_enable(True)
@@ -550,9 +578,13 @@ def main():
                     # issues vector instructions at 8 waves per SIMD (packed instructions weigh by the time they hold the pipe)
                     probe = cal["kernels"]["valu_probe<0>"]
                     sat = probe["valu_busy_quadcycles_per_gui_cycle"]
+                    ceiling = cal.get("valu_busy_ceiling", VALU_BUSY_CEILING)
                     rate = prof_c["valu_wave_instructions_per_launch"] / (prof_c["avg_launch_ms"] * 1e-3)
-                    roof["issue"] = {"bound": "valu-issue", "achieved": prof_c["valu_busy_quadcycles_per_gui_cycle"], "peak": sat,
-                                     "unit": "vector-pipe busy quad-cycles per GPU cycle", "frac": prof_c["valu_busy_quadcycles_per_gui_cycle"] / sat,
+                    roof["issue"] = {"bound": "valu-issue", "achieved": prof_c["valu_busy_quadcycles_per_gui_cycle"], "peak": ceiling,
+                                     "unit": "vector-pipe busy quad-cycles per GPU cycle", "frac": prof_c["valu_busy_quadcycles_per_gui_cycle"] / ceiling,
+                                     "peak_is": "the counter's ceiling: 1 024 SIMDs / 4 cycles per wave instruction / 8 XCDs summed in GRBM_GUI_ACTIVE",
+                                     "probe_reads": sat, "every_pair_kernel_reads": cal["kernels"].get("nn_bruteforce_kernel", {}).get("valu_busy_quadcycles_per_gui_cycle"),
+                                     "frac_of_probe": prof_c["valu_busy_quadcycles_per_gui_cycle"] / sat,
                                      "calibration_source": cal_src, "same_code_as_profile": same_cmd,
                                      "wave_instructions_per_s": rate, "probe_wave_instructions_per_s": probe["wave_instructions_per_s"],
                                      "instruction_rate_over_probe": rate / probe["wave_instructions_per_s"],
@@ -575,6 +607,9 @@ def main():
                                        "fixed cloud sharded x%d, RCCL u64-min all-reduce of the packed keys + one 64 x 18-double sum per iteration" % world),
                        "error_after_steps": err},
             "roofline": roof,
+            "library_default_batch": {"sync_every": auto_batch, "iterations_per_s": args.steps / elapsed_default, "ms_per_step": elapsed_default / args.steps * 1e3,
+                                      "note": "the same timed steps with mi_icp_run's default host-check interval (mi_icp_auto_batch) instead of ONE check "
+                                              "behind all of them: every batch ends in a flush (transform + error of the last iteration) and a 256-byte read-back"},
             "kernels_ms_per_step": breakdown,     # ms per launch, from the untimed follow-up iterations (every kernel event-timed)
         }
         if use_dist and rehearsal_transport == "gloo":

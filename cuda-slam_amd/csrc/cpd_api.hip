@@ -162,12 +162,15 @@ static CpdRules cpd_rules(const CpdWorkspace* w, const mi_cpd_params* p)
     return r;
 }
 
+// workgroups of the M-step sums and of the E-step's post kernels (a quad of lanes per point there: 64 points per workgroup)
+static int cpd_sum_blocks(int n) { return std::max(1, std::min(ICP_MAX_PARTIAL_BLOCKS, (n + 63) / 64)); }
+
 static int use_mfma_contraction(const mi_ctx* c) { return c->tune.cpd_mfma; }   // MISLAM_CPD_MFMA, read at context creation
 
 static int cpd_estep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
 {
     // the two post kernels also accumulate the M-step's moments of what they have just produced (two launches less per EM iteration)
-    const int nxb = icp_reduce_blocks(w->n), nkb = icp_reduce_blocks(w->m);
+    const int nxb = cpd_sum_blocks(w->n), nkb = cpd_sum_blocks(w->m);
     { ProfScope ps(c, MI_KERNEL_CPD_DENOM); MI_HIP(cpd_denominators(v, c->stream)); }
     MI_HIP(cpd_post_denominators(v, c->stream, w->part_x.p, nxb));
     { ProfScope ps(c, MI_KERNEL_CPD_CONTRACT); MI_HIP(cpd_contract(v, use_mfma_contraction(c), c->stream)); }
@@ -178,7 +181,7 @@ static int cpd_estep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
 
 static int cpd_mstep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const CpdRules& rules, int update_loop_state)
 {
-    const int nxb = icp_reduce_blocks(w->n), nkb = icp_reduce_blocks(w->m);
+    const int nxb = cpd_sum_blocks(w->n), nkb = cpd_sum_blocks(w->m);
     ProfScope ps(c, MI_KERNEL_CPD_MSTEP);
     if (!w->sums_fresh) {
         MI_HIP(cpd_xsums(v, w->part_x.p, nxb, c->stream));
@@ -403,8 +406,13 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
     MI_TRY(cpd_fetch(c, w));
     int batch = params->sync_every;
     if (batch <= 0) {
+        // enough iterations per host check that the check (a 160-byte read-back: ~35 us of idle device) stays a few per cent of them, few
+        // enough that what is enqueued past the stopping iteration (kernels that return at once, ~15 us per iteration) stays small: about a
+        // millisecond of E-steps.  From the GLOBAL sizes (every rank of a multi-GPU context picks the same batch): the two passes over the
+        // pair space run at ~2.5e12 pairs/s on one GPU, the small kernels and gaps take ~60 us per iteration
         const double pairs = (double)m_before * (double)n_after;
-        batch = pairs >= 2e9 ? 1 : (pairs >= 2e8 ? 2 : 8);
+        const double est_s = 2.0 * pairs / 2.5e12 / (double)(w->replicated ? 1 : c->world) + 6e-5;
+        batch = std::max(1, std::min(8, (int)(1.2e-3 / est_s)));
     }
     if (params->approximation != MI_CPD_APPROX_NONE) batch = 1;   // the E-step's shape depends on sigma^2: host-stepped
     while (!w->h_state->done) {
@@ -509,7 +517,7 @@ static int estep_primitive(mi_ctx* c, const float* y_xyz, int m, const float* x_
         MI_TRY(cpd_estep_enqueue(c, w, v));
     }
     w->sums_fresh = false;               // (a stand-alone E-step: nothing of it is carried into a later M-step call)
-    const int nxb = icp_reduce_blocks(n);
+    const int nxb = cpd_sum_blocks(n);
     MI_HIP(cpd_xsums(v, w->part_x.p, nxb, c->stream));
     MI_HIP(hipMemcpyAsync(p1, w->p1.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
     MI_HIP(hipMemcpyAsync(pt1, w->pt1.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));

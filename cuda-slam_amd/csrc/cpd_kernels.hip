@@ -39,15 +39,22 @@ __device__ __forceinline__ float sq_dist(float ax, float ay, float az, float bx,
 // as a rounded product h plus its exact residual (fma) plus the low part of log2(e), 2^h comes from v_exp_f32 (1 ulp) and the
 // residual is applied to first order, 2^(h+r) = 2^h (1 + r ln 2) with |r| < 2^-23 |h|.  Max relative error ~2 ulp against
 // glibc's expf over [-104, 0]; results below FLT_MIN flush to zero (they add to a denominator >= c, c ~ 1e1..1e2).
+#ifndef MISLAM_CPD_EXP_FORM
+#define MISLAM_CPD_EXP_FORM 2              // 2: compensated (the text above); 0: v_exp_f32(x * log2 e) alone -- measurement only
+#endif
 __device__ __forceinline__ float exp_neg(float x)
 {
     const float L_hi = 1.44269502162933349609375f;     // float(log2 e)
-    const float L_lo = 1.925963033500011e-08f;         // log2 e - L_hi
     const float h = x * L_hi;
+#if MISLAM_CPD_EXP_FORM == 0
+    return __builtin_amdgcn_exp2f(h);
+#else
+    const float L_lo = 1.925963033500011e-08f;         // log2 e - L_hi
     float r = __builtin_fmaf(x, L_hi, -h);
     r = __builtin_fmaf(x, L_lo, r);
     const float e = __builtin_amdgcn_exp2f(h);
     return __builtin_fmaf(e * r, 0.693147182464599609375f, e);
+#endif
 }
 
 // One Gaussian affinity from its exponent.  TRUNC: the hybrid mode's truncated kernel (coherentpointdrift.cpp:193-196) --
@@ -72,10 +79,15 @@ __device__ __forceinline__ cpd_f32x2 affinity2(float mult, cpd_f32x2 ax, cpd_f32
     const cpd_f32x2 L_hi = {1.44269502162933349609375f, 1.44269502162933349609375f}, L_lo = {1.925963033500011e-08f, 1.925963033500011e-08f};
     const cpd_f32x2 ln2 = {0.693147182464599609375f, 0.693147182464599609375f};
     const cpd_f32x2 h = x * L_hi;
+    const cpd_f32x2 e = {__builtin_amdgcn_exp2f(h.x), __builtin_amdgcn_exp2f(h.y)};
+#if MISLAM_CPD_EXP_FORM == 0
+    cpd_f32x2 p = e;
+    (void)L_lo; (void)ln2;
+#else
     cpd_f32x2 r = __builtin_elementwise_fma(x, L_hi, -h);
     r = __builtin_elementwise_fma(x, L_lo, r);
-    const cpd_f32x2 e = {__builtin_amdgcn_exp2f(h.x), __builtin_amdgcn_exp2f(h.y)};
     cpd_f32x2 p = __builtin_elementwise_fma(e * r, ln2, e);
+#endif
     if (TRUNC) { p.x = x.x < trunc_log ? 0.f : p.x; p.y = x.y < trunc_log ? 0.f : p.y; }
     return p;
 }
@@ -287,25 +299,43 @@ __global__ __launch_bounds__(256) void cpd_denominator_kernel(CpdView v)
 // den_x = sum of chunk partials + c; Pt1[x] = 1 - c/den (coherentpointdrift.cpp:204-206); operand of the contraction.
 // With xpartials != null the kernel also accumulates the M-step's x-sums (cpd_xsums_kernel's terms, same grid, same order: the
 // same bits) -- one launch and one gap less per EM iteration.
+// Round 4: a QUAD of lanes per fixed point.  The chunk partials of one point are a chain of cache round trips (134 chunks on the bunny clouds,
+// eight loads in flight per trip: 17 trips), and with one lane per point only 59 workgroups have anything to do; each lane of the quad now adds
+// up a quarter of the chunks (in chunk order), the four quarter sums are added in quad order -- a fixed tree: bitwise reproducible -- and four
+// times as many workgroups are in flight.  10.7 -> ~5 us per launch.
+__device__ __forceinline__ float quad_sum_ordered(float s, int lane)
+{
+    const int base = lane & ~3;
+    const float s0 = __shfl(s, base, 64), s1 = __shfl(s, base + 1, 64), s2 = __shfl(s, base + 2, 64), s3 = __shfl(s, base + 3, 64);
+    return ((s0 + s1) + s2) + s3;
+}
+
 __global__ __launch_bounds__(256) void cpd_post_den_kernel(CpdView v, double* __restrict__ xpartials)
 {
     if (v.state->done != 0) return;
     const float c = v.state->constant;
+    const int lane = threadIdx.x & 63, part = threadIdx.x & 3;
+    const int ch_lo = (int)((long long)v.k_chunks * part / 4), ch_hi = (int)((long long)v.k_chunks * (part + 1) / 4);
     double acc[CPD_XSUMS] = {0};
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n; i += gridDim.x * 256) {
-        // the chunk partials are added in chunk order (fixed: bitwise reproducible); eight loads in flight per trip -- one load per
-        // trip made this a chain of ~140 cache round trips (32 us for a 5 us job)
+    const int n_round = (v.n + 63) / 64 * 64;            // whole quads and whole waves reach the shuffles
+    for (int i = blockIdx.x * 64 + (threadIdx.x >> 2); i < n_round; i += gridDim.x * 64) {
+        const bool live = i < v.n;
         float den = 0.f;
-        const float* __restrict__ part = v.den_part + i;
-        int ch = 0;
-        for (; ch + 8 <= v.k_chunks; ch += 8) {
-            float t[8];
+        if (live) {
+            // this lane's quarter of the chunk partials, in chunk order; eight loads in flight per trip
+            const float* __restrict__ part_i = v.den_part + i;
+            int ch = ch_lo;
+            for (; ch + 8 <= ch_hi; ch += 8) {
+                float t[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) t[u] = part[(size_t)(ch + u) * v.n];
+                for (int u = 0; u < 8; u++) t[u] = part_i[(size_t)(ch + u) * v.n];
 #pragma unroll
-            for (int u = 0; u < 8; u++) den += t[u];
+                for (int u = 0; u < 8; u++) den += t[u];
+            }
+            for (; ch < ch_hi; ch++) den += part_i[(size_t)ch * v.n];
         }
-        for (; ch < v.k_chunks; ch++) den += part[(size_t)ch * v.n];
+        den = quad_sum_ordered(den, lane);
+        if (!live || part != 0) continue;
         den += c;
         const float w = 1.0f / den;
         const float pt1 = 1.0f - c / den;
@@ -460,44 +490,52 @@ __global__ __launch_bounds__(256) void cpd_contract_mfma_kernel(CpdView v)
     }
 }
 
-// (with kpartials != null: + the M-step's k-sums, as cpd_ksums_kernel would add them)
+// (with kpartials != null: + the M-step's k-sums, as cpd_ksums_kernel would add them).  A quad of lanes per moving point, like cpd_post_den_kernel.
 __global__ __launch_bounds__(256) void cpd_post_contract_kernel(CpdView v, double* __restrict__ kpartials)
 {
     if (v.state->done != 0) return;
+    const int lane = threadIdx.x & 63, part = threadIdx.x & 3;
+    const int ch_lo = (int)((long long)v.x_chunks * part / 4), ch_hi = (int)((long long)v.x_chunks * (part + 1) / 4);
     double acc[CPD_KSUMS] = {0};
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < v.m; k += gridDim.x * 256) {
-    float p1 = 0.f, x = 0.f, y = 0.f, z = 0.f;
-    const float* __restrict__ pp = v.p1_part + k;
-    const float* __restrict__ pq = v.px_part + k;
-    int ch = 0;
-    for (; ch + 4 <= v.x_chunks; ch += 4) {                     // chunk order kept; sixteen loads in flight per trip
-        float a[4], bx[4], by[4], bz[4];
+    const int m_round = (v.m + 63) / 64 * 64;
+    for (int k = blockIdx.x * 64 + (threadIdx.x >> 2); k < m_round; k += gridDim.x * 64) {
+        const bool live = k < v.m;
+        float p1 = 0.f, x = 0.f, y = 0.f, z = 0.f;
+        if (live) {
+            const float* __restrict__ pp = v.p1_part + k;
+            const float* __restrict__ pq = v.px_part + k;
+            int ch = ch_lo;
+            for (; ch + 4 <= ch_hi; ch += 4) {                      // chunk order kept; sixteen loads in flight per trip
+                float a[4], bx[4], by[4], bz[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            a[u] = pp[(size_t)(ch + u) * v.m];
-            const float* __restrict__ px = pq + (size_t)(ch + u) * 3 * v.m;
-            bx[u] = px[0]; by[u] = px[v.m]; bz[u] = px[2 * (size_t)v.m];
-        }
+                for (int u = 0; u < 4; u++) {
+                    a[u] = pp[(size_t)(ch + u) * v.m];
+                    const float* __restrict__ px = pq + (size_t)(ch + u) * 3 * v.m;
+                    bx[u] = px[0]; by[u] = px[v.m]; bz[u] = px[2 * (size_t)v.m];
+                }
 #pragma unroll
-        for (int u = 0; u < 4; u++) { p1 += a[u]; x += bx[u]; y += by[u]; z += bz[u]; }
-    }
-    for (; ch < v.x_chunks; ch++) {
-        p1 += pp[(size_t)ch * v.m];
-        const float* __restrict__ px = pq + (size_t)ch * 3 * v.m;
-        x += px[0]; y += px[v.m]; z += px[2 * (size_t)v.m];
-    }
-    v.p1[k] = p1;
-    v.px[3 * (size_t)k] = x; v.px[3 * (size_t)k + 1] = y; v.px[3 * (size_t)k + 2] = z;
-    if (kpartials != nullptr) {
-        const float b[3] = {v.bx[k], v.by[k], v.bz[k]};
-        const float px[3] = {x, y, z};
-        acc[0] += (double)p1;
-        for (int r = 0; r < 3; r++) {
-            acc[1 + r] += (double)b[r] * p1;
-            for (int c = 0; c < 3; c++) acc[4 + 3 * r + c] += (double)b[r] * px[c];
-            acc[13] += (double)(b[r] * b[r]) * p1;                                            // :259
+                for (int u = 0; u < 4; u++) { p1 += a[u]; x += bx[u]; y += by[u]; z += bz[u]; }
+            }
+            for (; ch < ch_hi; ch++) {
+                p1 += pp[(size_t)ch * v.m];
+                const float* __restrict__ px = pq + (size_t)ch * 3 * v.m;
+                x += px[0]; y += px[v.m]; z += px[2 * (size_t)v.m];
+            }
         }
-    }
+        p1 = quad_sum_ordered(p1, lane); x = quad_sum_ordered(x, lane); y = quad_sum_ordered(y, lane); z = quad_sum_ordered(z, lane);
+        if (!live || part != 0) continue;
+        v.p1[k] = p1;
+        v.px[3 * (size_t)k] = x; v.px[3 * (size_t)k + 1] = y; v.px[3 * (size_t)k + 2] = z;
+        if (kpartials != nullptr) {
+            const float b[3] = {v.bx[k], v.by[k], v.bz[k]};
+            const float px[3] = {x, y, z};
+            acc[0] += (double)p1;
+            for (int r = 0; r < 3; r++) {
+                acc[1 + r] += (double)b[r] * p1;
+                for (int c = 0; c < 3; c++) acc[4 + 3 * r + c] += (double)b[r] * px[c];
+                acc[13] += (double)(b[r] * b[r]) * p1;                                            // :259
+            }
+        }
     }
     if (kpartials != nullptr) block_sum_store<CPD_KSUMS>(acc, kpartials + (size_t)blockIdx.x * CPD_KSUMS);
 }
@@ -691,7 +729,7 @@ hipError_t cpd_denominators(const CpdView& v, hipStream_t s)
 
 hipError_t cpd_post_denominators(const CpdView& v, hipStream_t s, double* xpartials, int nblocks)
 {
-    const int grid = xpartials != nullptr ? nblocks : (v.n + 255) / 256;
+    const int grid = xpartials != nullptr ? nblocks : (v.n + 63) / 64;           // (a quad of lanes per point: 64 points per workgroup and stride)
     hipLaunchKernelGGL(cpd_post_den_kernel, dim3(grid), dim3(256), 0, s, v, xpartials);
     return hipGetLastError();
 }
@@ -712,7 +750,7 @@ hipError_t cpd_contract(const CpdView& v, int use_mfma, hipStream_t s)
 
 hipError_t cpd_post_contract(const CpdView& v, hipStream_t s, double* kpartials, int nblocks)
 {
-    const int grid = kpartials != nullptr ? nblocks : (v.m + 255) / 256;
+    const int grid = kpartials != nullptr ? nblocks : (v.m + 63) / 64;
     hipLaunchKernelGGL(cpd_post_contract_kernel, dim3(grid), dim3(256), 0, s, v, kpartials);
     return hipGetLastError();
 }

@@ -212,3 +212,25 @@ def test_world1_rccl_context_runs_the_sharded_cpd_path(capi, golden, bunny):
         p = capi.cpd_params(max_iterations=20, sigma2_init=g["sigma2_init"], approximation=capi.CPD_APPROX_HYBRID)
         a, b = dctx.cpd_register(before, after, p), sctx.cpd_register(before, after, p)
         assert a[3] == b[3] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_sigma_squared_cpu_sequential_zero_head_and_exact_ties(ctx, capi, oracle):
+    # cpu-slam's running sum retraced in parallel (cpd_kernels.hip, binade-wise integer prefix sums) has two side paths the random cases
+    # never reach: a running sum that is still ZERO after whole blocks of 4 096 terms (coincident points: no binade yet, the blocks are
+    # retraced term by term), and terms that fall EXACTLY half way between two representable sums (round-to-even depends on the sum's
+    # parity: the block is retraced).  Both against the restatement's sequential fp32 sum, bit for bit.
+    rng = np.random.default_rng(77)
+    p = np.array([[1.5, -2.25, 0.75]], np.float32)
+    # (a) 3 x 9 000 leading pairs at distance zero, then ordinary terms
+    b = np.concatenate([np.repeat(p, 3, 0), rng.uniform(-3, 3, (40, 3)).astype(np.float32)])
+    a = np.concatenate([np.repeat(p, 9000, 0), rng.uniform(-3, 3, (700, 3)).astype(np.float32)])
+    assert np.float32(ctx.cpd_sigma_squared(b, a, capi.SIGMA2_CPU_SEQUENTIAL)) == np.float32(oracle.cpd_sigma_squared(b, a))
+    # (b) all pairs at distance zero: the sum never leaves zero
+    assert ctx.cpd_sigma_squared(np.repeat(p, 5, 0), np.repeat(p, 5000, 0), capi.SIGMA2_CPU_SEQUENTIAL) == 0.0
+    # (c) exact ties: the sum sits at 1.0 (ulp 2^-23) and meets terms of 2^-24 -- half an ulp -- and 3 * 2^-24, in both parities
+    tie = np.float32(2.0 ** -12)                          # dx = 2^-12 -> d^2 = 2^-24 exactly
+    b = np.zeros((1, 3), np.float32)
+    xs = [1.0, tie, tie, np.float32(2.0 ** -11.5), tie, 1.0, tie, np.float32(np.sqrt(3.0)) * tie, tie] + [tie] * 5000 + list(rng.uniform(0, 2, 300))
+    a = np.zeros((len(xs), 3), np.float32)
+    a[:, 0] = np.asarray(xs, np.float32)
+    assert np.float32(ctx.cpd_sigma_squared(b, a, capi.SIGMA2_CPU_SEQUENTIAL)) == np.float32(oracle.cpd_sigma_squared(b, a))

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Reduces the rocprofv3 outputs of tools/gpu_profiles_r03.sh (gpurun_out/r03_<pass>/) to the summaries bench.py reads from profiles/:
-    r03_bench_n1e6_kernel_stats.csv             rocprofv3 --stats per-kernel summary of the whole command
-    r03_bench_n1e6_nn_grid_timed_dispatches.csv the kernel-trace rows of the TIMED launches of the search kernel (avg_launch_ms recomputable)
-    r03_bench_n1e6_nn_grid_counters.json        per-launch means of the counters over those launches + what produced them (git head, source hash)
-    r03_valu_calibration.json                   the same SQ counters on tools/valu_probe and on the every-pair kernel of the same run
-    r03_cpd_estep_counters.json                 the CPD E-step kernels of the same run
+"""Reduces the rocprofv3 outputs of tools/gpu_profiles.sh (gpurun_out/<R>_<pass>/, R = round tag) to the summaries bench.py reads from profiles/:
+    <R>_bench_n1e6_kernel_stats.csv             rocprofv3 --stats per-kernel summary of the whole command
+    <R>_bench_n1e6_nn_grid_timed_dispatches.csv the kernel-trace rows of the TIMED launches of the search kernel (avg_launch_ms recomputable)
+    <R>_bench_n1e6_nn_grid_counters.json        per-launch means of the counters over those launches + what produced them (git head, source hash)
+    <R>_valu_calibration.json                   the same SQ counters on tools/valu_probe and on the every-pair kernel of the same run
+    <R>_cpd_estep_counters.json                 the CPD E-step kernels of the same run
 """
 import csv
 import glob
@@ -16,13 +16,14 @@ import subprocess
 import sys
 
 S, W = int(sys.argv[1]), int(sys.argv[2])
+R = os.environ.get("R", "r04")
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "gpurun_out")
 
 
 def rows(d, pat):
     out = []
-    for f in glob.glob(os.path.join(OUT, "r03_%s" % d, "**", "*%s" % pat), recursive=True):
+    for f in glob.glob(os.path.join(OUT, "%s_%s" % (R, d), "**", "*%s" % pat), recursive=True):
         out += list(csv.DictReader(open(f)))
     return out
 
@@ -49,12 +50,12 @@ SETS = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq1", SQ1), ("sq
         ("tcp", ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"]))
 
 # ---- kernel trace: per-kernel stats + the timed launches of the search kernel
-for f in glob.glob(os.path.join(OUT, "r03_stats", "**", "*kernel_stats.csv"), recursive=True):
-    shutil.copy(f, os.path.join(OUT, "r03_bench_n1e6_kernel_stats.csv"))
+for f in glob.glob(os.path.join(OUT, R + "_stats", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(OUT, R + "_bench_n1e6_kernel_stats.csv"))
 tr = [r for r in rows("stats", "kernel_trace.csv") if "nn_grid_kernel" in r["Kernel_Name"]]
 tr.sort(key=lambda r: int(r["Start_Timestamp"]))
 timed_rows = tr[W:W + S]
-with open(os.path.join(OUT, "r03_bench_n1e6_nn_grid_timed_dispatches.csv"), "w", newline="") as f:
+with open(os.path.join(OUT, R + "_bench_n1e6_nn_grid_timed_dispatches.csv"), "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["launch_of_this_kernel", "Dispatch_Id", "Kernel_Name", "Start_Timestamp", "End_Timestamp", "duration_ns"])
     for k, r in enumerate(timed_rows):
@@ -77,7 +78,7 @@ doc = {
     "command": "rocprofv3 --pmc <one pass per counter set> -- python3 bench.py --steps %d --warmup %d --no-cpu-baseline --no-sizes --no-whole-call; "
                "means over the %d TIMED launches of the search kernel (launches %d..%d of it)" % (S, W, S, W, W + S - 1),
     "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE / WRITE_SIZE are in KB; gfx950 FETCH_SIZE counts 64 B per 128 B request, so x2 on the read side",
-    "avg_launch_ms": mean(timed), "avg_launch_ms_source": "r03_bench_n1e6_nn_grid_timed_dispatches.csv (rocprofv3 --kernel-trace of the same command, same launches)",
+    "avg_launch_ms": mean(timed), "avg_launch_ms_source": R + "_bench_n1e6_nn_grid_timed_dispatches.csv (rocprofv3 --kernel-trace of the same command, same launches)",
     "traffic_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
     "algorithmic_bytes_per_launch": 32000000,
     "valu_wave_instructions_per_launch": c["SQ_INSTS_VALU"],
@@ -89,12 +90,15 @@ doc = {
     "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
     "per_launch_mean": c,
 }
-json.dump(doc, open(os.path.join(OUT, "r03_bench_n1e6_nn_grid_counters.json"), "w"), indent=1)
+json.dump(doc, open(os.path.join(OUT, R + "_bench_n1e6_nn_grid_counters.json"), "w"), indent=1)
 print(json.dumps({k: doc[k] for k in ("avg_launch_ms", "traffic_bytes_per_launch", "valu_wave_instructions_per_launch", "valu_instructions_per_wave",
                                       "lanes_active_of_64", "wait_any_over_wave_cycles", "l2_hit_rate")}))
 
 # ---- calibration: the probe kernels (known instruction count, 8 waves per SIMD) and the every-pair kernel under the same counters
-cal = {"command": "rocprofv3 --pmc <SQ sets> -- tools/valu_probe (and the nn_bruteforce_kernel launches of the bench command above)",
+# what the busy ratio can read at most: one quad-cycle per vector instruction, 1 024 SIMDs issuing one every four cycles, GRBM_GUI_ACTIVE summed
+# over the 8 XCDs -> 1024 / 4 / 8 = 32 (state every `issue` fraction against this, with the probe's own reading beside it)
+VALU_BUSY_CEILING = 1024 / 4 / 8
+cal = {"valu_busy_ceiling": VALU_BUSY_CEILING, "command": "rocprofv3 --pmc <SQ sets> -- tools/valu_probe (and the nn_bruteforce_kernel launches of the bench command above)",
        "note": "SQ_ACTIVE_INST_VALU counts quad-cycles in which a wave has a vector instruction executing, summed over waves; GRBM_GUI_ACTIVE is "
                "summed over the 8 XCDs.  Their ratio on a kernel that only issues vector instructions at 8 waves per SIMD is what `saturated` "
                "means for that ratio; a kernel's `issue.frac` is its own ratio over that one.", "kernels": {}}
@@ -118,7 +122,7 @@ if bf.get("SQ_INSTS_VALU") and bft:
     bf["wave_instructions_per_s"] = bf["SQ_INSTS_VALU"] / (bf["launch_ms"] * 1e-3)
     bf["valu_busy_quadcycles_per_gui_cycle"] = bf["SQ_ACTIVE_INST_VALU"] / bf["GRBM_GUI_ACTIVE"]
 cal["kernels"]["nn_bruteforce_kernel"] = bf
-json.dump(cal, open(os.path.join(OUT, "r03_valu_calibration.json"), "w"), indent=1)
+json.dump(cal, open(os.path.join(OUT, R + "_valu_calibration.json"), "w"), indent=1)
 print(json.dumps({k: {kk: v.get(kk) for kk in ("wave_instructions_per_s", "valu_busy_quadcycles_per_gui_cycle")} for k, v in cal["kernels"].items()}))
 
 # ---- CPD E-step kernels of the same run
@@ -133,6 +137,18 @@ for kn in names:
     e["launch_ms"] = mean(t) * 1e-6 if t else None
     if e.get("SQ_ACTIVE_INST_VALU") and e.get("GRBM_GUI_ACTIVE"):
         e["valu_busy_quadcycles_per_gui_cycle"] = e["SQ_ACTIVE_INST_VALU"] / e["GRBM_GUI_ACTIVE"]
+    # the matrix pipe: its own pass (SQ_VALU_MFMA_BUSY_CYCLES counts cycles in which a SIMD's matrix pipe is busy, summed over the SIMDs;
+    # GRBM_GUI_ACTIVE of that pass is summed over the 8 XCDs)
+    m = {k: mean(counter_series("mfma", k, kn)) for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE")}
+    if m.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None and m.get("GRBM_GUI_ACTIVE"):
+        cycles = m["GRBM_GUI_ACTIVE"] / 8.0
+        e["mfma"] = {"SQ_VALU_MFMA_BUSY_CYCLES": m["SQ_VALU_MFMA_BUSY_CYCLES"], "SQ_INSTS_VALU_MFMA_MOPS_F32": m["SQ_INSTS_VALU_MFMA_MOPS_F32"],
+                     "SQ_INSTS_MFMA": m.get("SQ_INSTS_MFMA"), "gpu_cycles": cycles,
+                     "mfma_util": m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024.0),
+                     "mfma_flops_per_launch": (m["SQ_INSTS_VALU_MFMA_MOPS_F32"] or 0.0) * 512.0,
+                     "contraction_flops_per_launch": pairs * 8.0,
+                     "note": "mfma_util = busy cycles / (GPU cycles x 1 024 SIMDs); MOPS_F32 counts 512 flops each; the contraction P~ [X|1] is "
+                             "pairs x 4 multiply-adds = pairs x 8 flops, all of it on the matrix pipe when the MFMA form runs"}
     cpd["kernels"][kn.split("(")[0][-60:]] = e
-json.dump(cpd, open(os.path.join(OUT, "r03_cpd_estep_counters.json"), "w"), indent=1)
+json.dump(cpd, open(os.path.join(OUT, R + "_cpd_estep_counters.json"), "w"), indent=1)
 print(json.dumps({k: v.get("valu_busy_quadcycles_per_gui_cycle") for k, v in cpd["kernels"].items()}))
