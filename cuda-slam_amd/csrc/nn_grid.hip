@@ -714,6 +714,12 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
     else hard = grid_search<FMA, STATS>(g, q, valid, near_word, best, bidx, bslot, n_cand, n_rows) && valid;   // (all lanes: the loops run in step)
 #endif
     const bool walked = __builtin_amdgcn_ballot_w64(hard) != 0ull;
+    // the first iterations of a registration move the cloud by many cells: the starting candidates (previous matches) are STALE, and a walk
+    // that enters the children in index order meets the true neighbourhood late; there the nearest child goes first (a lane vote per step)
+#ifndef MISLAM_GRID_COLD_PASSES
+#define MISLAM_GRID_COLD_PASSES 6
+#endif
+    const bool cold = FUSED && a.state->passes < MISLAM_GRID_COLD_PASSES;
 #ifdef MISLAM_DEV_WAVE_TIMELINE
     tl_scan = wall_clock64();
 #endif
@@ -729,7 +735,7 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
 #ifdef MISLAM_DEV_WALK_CAP               // (only once the registration is past its cold iterations, whose long walks are the point of them)
         tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves, FUSED && a.state->passes >= 8 ? MISLAM_DEV_WALK_CAP : 1 << 30);
 #else
-        tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves);
+        tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves, cold);
 #endif
 #ifdef MISLAM_DEV_WALK_PRIO
         __builtin_amdgcn_s_setprio(0);

@@ -106,7 +106,7 @@ __device__ __forceinline__ f32x2 box6_bound2(const float* __restrict__ pr, const
 
 template <bool FMA, bool STATS>
 __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float p[3], float& best, unsigned int& bidx,
-                                               unsigned int& n_nodes, unsigned int& n_leaves
+                                               unsigned int& n_nodes, unsigned int& n_leaves, bool nearest_first = false
 #ifdef MISLAM_DEV_WALK_CAP               // timing experiment (tools/build_variant.sh): the walk gives up after this many steps -- wrong answers
                                                , int dev_steps_left = 1 << 30
 #endif
@@ -219,7 +219,7 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
                 // first the child that is the nearest one for most lanes -- worth a vote only while some lane has no candidate
                 // yet (a good first descent is all its pruning); lanes that came with one prune by it whatever the order
                 int f = __builtin_ctz(mask);
-                if (__builtin_amdgcn_ballot_w64(!(best < inf)) != 0ull) {
+                if (nearest_first || __builtin_amdgcn_ballot_w64(!(best < inf)) != 0ull) {
                     float minb = inf;
 #pragma unroll
                     for (int j = 0; j < 8; j++) minb = ((mask >> j) & 1u) ? fminf(minb, lb[j]) : minb;
