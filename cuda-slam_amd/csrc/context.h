@@ -114,6 +114,20 @@ struct mi_ctx {
         int fgt_resume = 1;                              // MISLAM_FGT_RESUME=0: re-cluster the fixed cloud from scratch every E-step
     } tune;
 
+    // ---- a second lane for the loads (round 4): mi_icp_load uploads and indexes the FIXED cloud on `aux` (hierarchy) and `aux2` (cell grid)
+    // while the moving cloud is uploaded and ordered on `stream`; the helpers enqueue on work_stream() and take their scratch from the set
+    // `lane` names (0: the buffers below, 1: the *2 copies), so two lanes never share a scratch buffer.  Everything else runs on `stream`.
+    hipStream_t aux = nullptr, aux2 = nullptr;
+    hipEvent_t aux_event[3] = {nullptr, nullptr, nullptr};
+    hipStream_t lane_stream = nullptr;                   // null: `stream`
+    int lane = 0;
+    hipStream_t work_stream() const { return lane_stream ? lane_stream : stream; }
+    mislam::DevBuf<float> staging2;
+    mislam::DevBuf<unsigned int> tcodes2_in, tcodes2_out;
+    mislam::DevBuf<int> torder2_in;
+    mislam::DevBuf<float> tbbox2, gbbox;
+    mislam::DevBuf<unsigned char> tsort_temp2;
+
     // ---- workspace shared by the drivers
     mislam::DevBuf<float> staging;                       // AoS upload/download staging
     // pinned host staging of the cloud uploads (host_to_device): the runtime's own pageable-copy path stalls for 20-50 ms every
@@ -207,6 +221,13 @@ struct CtxScope {
 #define MI_ENTER(c)                          \
     MI_HIP(hipSetDevice((c)->device));       \
     mislam::CtxScope mi_ctx_scope_(c)
+
+// the helpers called inside enqueue on `s` and use scratch set `lane` (mi_ctx::work_stream)
+struct LaneScope {
+    mi_ctx* c;
+    LaneScope(mi_ctx* ctx, hipStream_t s, int lane) : c(ctx) { c->lane_stream = s; c->lane = lane; }
+    ~LaneScope() { c->lane_stream = nullptr; c->lane = 0; }
+};
 
 struct ProfScope {
     mi_ctx* c;

@@ -214,6 +214,9 @@ static int ctx_create_common(int device, mi_ctx** out)
         MI_HIP(hipGetDeviceProperties(&prop, device));
         c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         MI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        MI_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+        MI_HIP(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
+        for (hipEvent_t& e : c->aux_event) MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         MI_HIP(hipMalloc((void**)&c->d_state, sizeof(IcpState)));
         MI_HIP(hipHostMalloc((void**)&c->h_state, sizeof(IcpState), hipHostMallocDefault));
         memset(c->h_state, 0, sizeof(IcpState));
@@ -398,6 +401,8 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->aux) (void)hipStreamSynchronize(c->aux);
+    if (c->aux2) (void)hipStreamSynchronize(c->aux2);
     retire_buffers(c);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->exchange_host) (void)hipHostFree(c->exchange_host);
@@ -405,7 +410,8 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
     cpd_workspace_destroy(c);
-    c->staging.release();
+    c->staging.release(); c->staging2.release(); c->tcodes2_in.release(); c->tcodes2_out.release(); c->torder2_in.release(); c->tbbox2.release();
+    c->gbbox.release(); c->tsort_temp2.release();
     c->bx.release(); c->by.release(); c->bz.release();
     c->cx.release(); c->cy.release(); c->cz.release(); c->ax.release(); c->ay.release(); c->az.release();
     c->tx.release(); c->ty.release(); c->tz.release();
@@ -421,6 +427,9 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->h_state) (void)hipHostFree(c->h_state);
+    for (hipEvent_t e : c->aux_event) if (e) (void)hipEventDestroy(e);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->aux2) (void)hipStreamDestroy(c->aux2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     pool_context_gone(c->device);
     delete c;
@@ -603,9 +612,10 @@ NnPlan plan_nn(const mi_ctx* ctx, int n, int m_local)
 
 int host_to_device(mi_ctx* c, void* dst_dev, const void* src_host, size_t bytes)
 {
+    const hipStream_t ws = c->work_stream();
     constexpr size_t PIECE = mi_ctx::PIN_PIECE;
     if (bytes < PIECE / 4 || c->pin == nullptr) {     // small: the runtime's path is fine (and synchronous for pageable memory)
-        MI_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+        MI_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ws));
         return MI_OK;
     }
     for (size_t o = 0; o < bytes; o += PIECE) {       // the copy of piece k overlaps the transfers of the pieces before it
@@ -614,8 +624,8 @@ int host_to_device(mi_ctx* c, void* dst_dev, const void* src_host, size_t bytes)
         if (c->pin_busy & (1u << k)) { MI_HIP(hipEventSynchronize(c->pin_event[k])); c->pin_busy &= ~(1u << k); }   // (sixteen pieces ago: long done)
         char* slot = c->pin + (size_t)k * PIECE;
         memcpy(slot, (const char*)src_host + o, nb);
-        MI_HIP(hipMemcpyAsync((char*)dst_dev + o, slot, nb, hipMemcpyHostToDevice, c->stream));
-        MI_HIP(hipEventRecord(c->pin_event[k], c->stream));
+        MI_HIP(hipMemcpyAsync((char*)dst_dev + o, slot, nb, hipMemcpyHostToDevice, ws));
+        MI_HIP(hipEventRecord(c->pin_event[k], ws));
         c->pin_busy |= 1u << k;
     }
     return MI_OK;
@@ -623,11 +633,12 @@ int host_to_device(mi_ctx* c, void* dst_dev, const void* src_host, size_t bytes)
 
 int upload_soa(mi_ctx* c, const float* host_aos, int n, int n_pad, float* x, float* y, float* z, float4* packed)
 {
-    MI_TRY(c->staging.reserve((size_t)3 * n));
-    MI_TRY(host_to_device(c, c->staging.p, host_aos, sizeof(float) * 3 * (size_t)n));
-    MI_HIP(aos_to_soa(c->staging.p, n, n_pad, x, y, z, packed, c->stream));
-    // the staging buffer is reused by the next upload: keep stream order, and a pageable-memory copy is already
-    // synchronous with respect to the host buffer
+    DevBuf<float>& staging = c->lane == 1 ? c->staging2 : c->staging;
+    MI_TRY(staging.reserve((size_t)3 * n));
+    MI_TRY(host_to_device(c, staging.p, host_aos, sizeof(float) * 3 * (size_t)n));
+    MI_HIP(aos_to_soa(staging.p, n, n_pad, x, y, z, packed, c->work_stream()));
+    // the staging buffer is reused by the next upload of the same lane: stream order keeps them apart, and a pageable-memory copy is
+    // already synchronous with respect to the host buffer
     return MI_OK;
 }
 
@@ -635,15 +646,21 @@ int upload_soa(mi_ctx* c, const float* host_aos, int n, int n_pad, float* x, flo
 static int morton_args(mi_ctx* c, const float* x, const float* y, const float* z, int m, int* order_out, MortonArgs* out)
 {
     const size_t sort_bytes = tree_sort_temp_bytes(m);
-    MI_TRY(c->tcodes_in.reserve((size_t)m)); MI_TRY(c->tcodes_out.reserve((size_t)m));
-    MI_TRY(c->torder_in.reserve((size_t)m));
-    MI_TRY(c->tbbox.reserve(256 * 6 + 8));
-    MI_TRY(c->tsort_temp.reserve(sort_bytes + 16));
+    const bool second = c->lane == 1;                   // (the lane's own scratch set: two sorts may be in flight, one per lane)
+    DevBuf<unsigned int>& codes_in = second ? c->tcodes2_in : c->tcodes_in;
+    DevBuf<unsigned int>& codes_out = second ? c->tcodes2_out : c->tcodes_out;
+    DevBuf<int>& order_in = second ? c->torder2_in : c->torder_in;
+    DevBuf<float>& bbox = second ? c->tbbox2 : c->tbbox;
+    DevBuf<unsigned char>& temp = second ? c->tsort_temp2 : c->tsort_temp;
+    MI_TRY(codes_in.reserve((size_t)m)); MI_TRY(codes_out.reserve((size_t)m));
+    MI_TRY(order_in.reserve((size_t)m));
+    MI_TRY(bbox.reserve(256 * 6 + 8));
+    MI_TRY(temp.reserve(sort_bytes + 16));
     MortonArgs a{};
     a.x = x; a.y = y; a.z = z; a.m = m;
-    a.bbox_partials = c->tbbox.p; a.bbox = c->tbbox.p + 256 * 6;
-    a.codes_in = c->tcodes_in.p; a.codes_out = c->tcodes_out.p; a.order_in = c->torder_in.p; a.order_out = order_out;
-    a.sort_temp = c->tsort_temp.p; a.sort_temp_bytes = sort_bytes;
+    a.bbox_partials = bbox.p; a.bbox = bbox.p + 256 * 6;
+    a.codes_in = codes_in.p; a.codes_out = codes_out.p; a.order_in = order_in.p; a.order_out = order_out;
+    a.sort_temp = temp.p; a.sort_temp_bytes = sort_bytes;
     *out = a;
     return MI_OK;
 }
@@ -667,7 +684,7 @@ static int ensure_tree(mi_ctx* c, int m_local, int index_base)
     a.index_base = index_base; a.n_leaves = n_leaves; a.n_pad = n_pad;
     a.pts = c->tpts.p; a.boxes = c->tboxes.p;
     a.leaf_soa = c->tleaf.p; a.leaf_idx = c->tidx.p; a.boxes6 = c->tboxes6.p;
-    MI_HIP(tree_build(a, c->stream));
+    MI_HIP(tree_build(a, c->work_stream()));
     c->tree.boxes6 = c->tboxes6.p;
     c->tree.leaf_soa = c->tleaf.p; c->tree.leaf_idx = c->tidx.p;
     c->tree.n_pad = n_pad; c->tree.height = height; c->tree.n_leaves = n_leaves;
@@ -680,12 +697,13 @@ static int ensure_tree(mi_ctx* c, int m_local, int index_base)
 static int ensure_grid(mi_ctx* c, int m_local, int index_base)
 {
     if (c->grid_valid) return MI_OK;
-    MI_TRY(c->tbbox.reserve(256 * 6 + 8));
-    float* d_bbox = c->tbbox.p + 256 * 6;
-    MI_HIP(cloud_bbox(c->tx.p, c->ty.p, c->tz.p, m_local, c->tbbox.p, d_bbox, c->stream));
+    const hipStream_t ws = c->work_stream();
+    MI_TRY(c->gbbox.reserve(256 * 6 + 8));              // (its own: a Morton sort's bounding box may be in flight on another lane)
+    float* d_bbox = c->gbbox.p + 256 * 6;
+    MI_HIP(cloud_bbox(c->tx.p, c->ty.p, c->tz.p, m_local, c->gbbox.p, d_bbox, ws));
     float* bbox = c->h_scratch;                        // (pinned: a read-back into pageable memory goes through the runtime's staging)
-    MI_HIP(hipMemcpyAsync(bbox, d_bbox, 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    { StallProbe sp("grid: bounding-box synchronize"); MI_HIP(hipStreamSynchronize(c->stream)); }
+    MI_HIP(hipMemcpyAsync(bbox, d_bbox, 6 * sizeof(float), hipMemcpyDeviceToHost, ws));
+    { StallProbe sp("grid: bounding-box synchronize"); MI_HIP(hipStreamSynchronize(ws)); }
     StallProbe sp_rest("grid: reserve + enqueue build");
     NnGridView g{};
     grid_plan(bbox, m_local, c->tune.grid_points_per_cell, &g);
@@ -705,7 +723,7 @@ static int ensure_grid(mi_ctx* c, int m_local, int index_base)
     a.x = c->tx.p; a.y = c->ty.p; a.z = c->tz.p; a.m = m_local; a.index_base = index_base;
     a.view = g; a.cell_fill = c->gfill.p; a.scan_tmp = c->gscan.p; a.pts_out = c->gpts.p; a.cell_start_out = c->gstart.p; a.slot_of_out = c->gslot_of.p;
     a.near_out = c->gnear.p; a.near_tmp = c->gnear_tmp.p;
-    MI_HIP(grid_build(a, c->stream));
+    MI_HIP(grid_build(a, ws));
     c->grid = g;
     c->grid_valid = true;
     return MI_OK;
@@ -719,8 +737,8 @@ static int sort_sources(mi_ctx* c, const float* sx, const float* sy, const float
     MI_TRY(c->sorder.reserve((size_t)n));
     MortonArgs ma{};
     MI_TRY(morton_args(c, sx, sy, sz, n, c->sorder.p, &ma));
-    MI_HIP(morton_order(ma, c->stream));
-    MI_HIP(permute_soa(sx, sy, sz, c->sorder.p, n, n_pad, dx, dy, dz, c->stream));
+    MI_HIP(morton_order(ma, c->work_stream()));
+    MI_HIP(permute_soa(sx, sy, sz, c->sorder.p, n, n_pad, dx, dy, dz, c->work_stream()));
     return MI_OK;
 }
 
@@ -1001,18 +1019,42 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
         MI_HIP(invert_order(c->sorder.p, n_before, c->sinv.p, c->stream));
     }
     MI_TRY(mark(2));
-    MI_TRY(upload_target_shard(c, after_xyz, n_after, c->source_sharded));
-    MI_TRY(mark(3));
+    // The FIXED cloud's share of the load -- upload, box hierarchy, cell grid -- depends on nothing the moving cloud's does, so it runs
+    // on its own lanes (round 4): the upload and the hierarchy on `aux`, the grid (behind the upload) on `aux2`, their own scratch sets,
+    // while `stream` is still ordering the moving cloud.  The host only copies into the pinned ring and enqueues; its one wait -- the grid's
+    // bounding box -- is a wait for the fixed cloud's upload, which it would have sat out anyway.  `stream` then waits for both lanes.
+    // (With profiling on, everything stays on `stream`, stage by stage: mi_icp_load_times drains it at every mark.)
+    const bool lanes = !c->profile && c->aux != nullptr && c->aux2 != nullptr;
+    const int m_local_pre = [&] { int lo = 0, hi = n_after; if (!c->source_sharded) shard_range(n_after, c->rank, c->world, &lo, &hi); return hi - lo; }();
     // The grid search carries the whole O(N) part of the iteration (nn_grid.hip) unless a stand-alone step has to come between
     // the search and the sums: the key all-reduce of a sharded fixed cloud, or cpu-slam's sequential running sums.
+    const int mode = resolve_nn_mode(c, params->nn_mode, m_local_pre);
+    {
+        LaneScope ls(c, lanes ? c->aux : nullptr, lanes ? 1 : 0);
+        MI_TRY(upload_target_shard(c, after_xyz, n_after, c->source_sharded));
+        if (lanes) MI_HIP(hipEventRecord(c->aux_event[0], c->aux));           // the fixed cloud is on the device
+    }
+    MI_TRY(mark(3));
     const int m_local = c->shard_hi - c->shard_lo;
-    const int mode = resolve_nn_mode(c, params->nn_mode, m_local);
     c->fused = mode == MI_NN_GRID && (!c->distributed() || c->source_sharded) && params->sum_mode == MI_SUM_EXACT;
     if (mode != MI_NN_BRUTEFORCE) {          // build the indexes now, not inside the first timed iteration
-        MI_TRY(ensure_tree(c, m_local, c->shard_lo));
+        {
+            LaneScope ls(c, lanes ? c->aux : nullptr, lanes ? 1 : 0);
+            MI_TRY(ensure_tree(c, m_local, c->shard_lo));
+        }
         MI_TRY(mark(4));
-        if (mode == MI_NN_GRID) MI_TRY(ensure_grid(c, m_local, c->shard_lo));
+        if (mode == MI_NN_GRID) {
+            if (lanes) MI_HIP(hipStreamWaitEvent(c->aux2, c->aux_event[0], 0));
+            LaneScope ls(c, lanes ? c->aux2 : nullptr, 0);                    // (the grid build has its own scratch; lane 0's sort scratch is not touched)
+            MI_TRY(ensure_grid(c, m_local, c->shard_lo));
+        }
         MI_TRY(mark(5));
+    }
+    if (lanes) {                             // everything after the load runs on `stream`: it waits for both lanes here, once
+        MI_HIP(hipEventRecord(c->aux_event[1], c->aux));
+        MI_HIP(hipEventRecord(c->aux_event[2], c->aux2));
+        MI_HIP(hipStreamWaitEvent(c->stream, c->aux_event[1], 0));
+        MI_HIP(hipStreamWaitEvent(c->stream, c->aux_event[2], 0));
     }
     c->icp_loaded = true;
     MI_TRY(mi_icp_reset(c));
@@ -1156,6 +1198,9 @@ extern "C" int mi_icp_run(mi_ctx* c, int max_new_iterations, int* iterations_don
     while (!c->h_state->done && (max_new_iterations < 0 || enqueued < max_new_iterations)) {
         int todo = batch;
         if (max_new_iterations >= 0) todo = std::min(todo, max_new_iterations - enqueued);
+        // a run capped at max_iterations is not enqueued past the cap (the device would turn the surplus into launches that return at once:
+        // 14 of them behind a 50-iteration run in batches of 16)
+        if (c->icp.max_iterations >= 0) todo = std::max(1, std::min(todo, c->icp.max_iterations - c->h_state->iterations));
         hipEvent_t dev_e0 = nullptr, dev_e1 = nullptr;
         if (g_stall_ms > 0) { (void)hipEventCreate(&dev_e0); (void)hipEventCreate(&dev_e1); (void)hipEventRecord(dev_e0, c->stream); }
         { StallProbe sp("run: enqueue batch"); for (int b = 0; b < todo; b++) MI_TRY(icp_enqueue_iteration(c)); }
