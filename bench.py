@@ -103,7 +103,7 @@ def search_source_hash():
 def committed_profile(workload, kernel, steps, warmup):
     """The committed rocprofv3 --pmc summary (profiles/*_counters.json) for this workload and kernel, and whether it was taken
     with THIS run's --steps / --warmup (the search's cost depends on which iterations are timed) on THIS code (source hash of
-    the search kernel).  bench.py cannot run counter passes itself: they need their own rocprofv3 runs (tools/gpu_profiles_r03.sh)."""
+    the search kernel).  bench.py cannot run counter passes itself: they need their own rocprofv3 runs (tools/gpu_profiles.sh)."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True):
         try:
             d = json.load(open(path))

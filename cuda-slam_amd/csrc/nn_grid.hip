@@ -499,11 +499,7 @@ __device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, uns
         if (dealt) { s.kbest = kbest; s.bslot = bslot; return; }
     }
 #endif
-#ifdef MISLAM_DEV_BLOCK_CAP             // timing experiment (counting build only): wrong answers
-    for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < e4 && !(STATS && BLOCK && t >= MISLAM_DEV_BLOCK_CAP)) != 0ull; t += GRID_TRIP) {
-#else
     for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < e4) != 0ull; t += GRID_TRIP) {
-#endif
 #ifdef MISLAM_DEV_WAVE_TIMELINE
         if (BLOCK) s.trips_block += 1; else s.trips_rest += 1;
 #endif
@@ -640,10 +636,6 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
 #else
 #define MI_TL_STAMP(var, dep) do { } while (0)
 #endif
-#ifdef MISLAM_DEV_WALK_CLOCK
-    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-    unsigned long long pre_cycles = 0, life_cycles = 0;
-#endif
     unsigned int chunk = xcd_chunk(blockIdx.x, gridDim.x, TREE_XCD_CHUNKS * (256 / GRID_BLOCK));
     if (FUSED) chunk = (unsigned int)a.order[chunk];          // walking chunks first (IcpSchedule): speed only
     const int i = (int)(chunk * GRID_BLOCK) + tid;
@@ -701,7 +693,6 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
     // (every lane asks -- a lane without a point has q = 0, some cell of the grid: no branch, so nothing waits for the byte here)
     const unsigned int near_word = g.occupied_near[cell_of(g, q[0], q[1], q[2])];
     bool hard = false;
-    unsigned long long walk_cycles = 0;
     unsigned int n_cand = 0u, n_rows = 0u, n_nodes = 0u, n_leaves = 0u;
     // A chunk most of whose lanes ended beyond the grid's reach last time (they will again: the flags move slowly) skips the scan:
     // all its lanes walk, each from its own starting candidate -- the walk is exact by itself, the few lanes the scan would have
@@ -723,30 +714,7 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
 #ifdef MISLAM_DEV_WAVE_TIMELINE
     tl_scan = wall_clock64();
 #endif
-#ifndef MISLAM_DEV_SKIP_WALK          // timing experiments only (tools/build_variant.sh): wrong answers for the lanes concerned
-    if (hard) {
-#ifdef MISLAM_DEV_WALK_CLOCK
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        pre_cycles = t0 - t_begin;
-#endif
-#ifdef MISLAM_DEV_WALK_PRIO
-        __builtin_amdgcn_s_setprio(MISLAM_DEV_WALK_PRIO);
-#endif
-#ifdef MISLAM_DEV_WALK_CAP               // (only once the registration is past its cold iterations, whose long walks are the point of them)
-        tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves, FUSED && a.state->passes >= 8 ? MISLAM_DEV_WALK_CAP : 1 << 30);
-#else
-        tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves, cold);
-#endif
-#ifdef MISLAM_DEV_WALK_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#ifdef MISLAM_DEV_WALK_CLOCK
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        walk_cycles = t1 - t0;
-        life_cycles = t1 - t_begin;
-#endif
-    }
-#endif
+    if (hard) tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves, cold);
     // the point's index again, from the chunk number (a scalar) as far as the compiler can tell a different one: kept from the prologue it
     // would sit in two vector registers through the whole search, which is short of them
     unsigned int chunk_again = chunk;
@@ -760,17 +728,10 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
         unsigned long long* srow = a.stats + (size_t)(blockIdx.x % GRID_STATS_ROWS) * 8;
         unsigned int c0 = valid ? n_cand : 0u, c1 = valid ? n_rows : 0u;
         unsigned int v0 = hard ? n_nodes : 0u, v1 = hard ? n_leaves : 0u;
-        unsigned long long wc = hard ? walk_cycles : 0ull;
-#ifdef MISLAM_DEV_WALK_CLOCK
-        unsigned long long pc = hard ? pre_cycles : 0ull, lc = hard ? life_cycles : 0ull;
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) { pc = max(pc, (unsigned long long)__shfl_xor(pc, m, 64)); lc = max(lc, (unsigned long long)__shfl_xor(lc, m, 64)); }
-#endif
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) {
             c0 += __shfl_xor(c0, m, 64); c1 += __shfl_xor(c1, m, 64);
             v0 = max(v0, (unsigned int)__shfl_xor(v0, m, 64)); v1 = max(v1, (unsigned int)__shfl_xor(v1, m, 64));
-            wc = max(wc, (unsigned long long)__shfl_xor(wc, m, 64));
         }
         const unsigned long long nh = __builtin_popcountll(__builtin_amdgcn_ballot_w64(hard)), nv = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid));
 #ifdef MISLAM_DEV_WAVE_TIMELINE
@@ -788,17 +749,10 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
             atomicAdd(&srow[2], nh);
             atomicAdd(&srow[3], nv);
             if (walked) {                                       // hierarchy nodes and leaves visited, waves walking
-#ifdef MISLAM_DEV_WALK_CLOCK            // (developer build: [4] sum of walk times, [5] sum of times before the walk, [7] longest wave start -> end of walk)
-                atomicAdd(&srow[4], wc);
-                atomicAdd(&srow[5], pc);
-                atomicAdd(&srow[6], 1ull);
-                atomicMax(&srow[7], lc);
-#else
                 atomicAdd(&srow[4], (unsigned long long)v0);
                 atomicAdd(&srow[5], (unsigned long long)v1);
                 atomicAdd(&srow[6], 1ull);
                 atomicMax(&srow[7], (unsigned long long)(v0 + v1));     // the longest walk, in steps
-#endif
             }
         }
     }

@@ -107,9 +107,6 @@ __device__ __forceinline__ f32x2 box6_bound2(const float* __restrict__ pr, const
 template <bool FMA, bool STATS>
 __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float p[3], float& best, unsigned int& bidx,
                                                unsigned int& n_nodes, unsigned int& n_leaves, bool nearest_first = false
-#ifdef MISLAM_DEV_WALK_CAP               // timing experiment (tools/build_variant.sh): the walk gives up after this many steps -- wrong answers
-                                               , int dev_steps_left = 1 << 30
-#endif
                                                )
 {
     const float* __restrict__ boxes6 = t.boxes6;
@@ -172,11 +169,7 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
         unsigned long long pend = 0ull;                         // byte w: children of the wave's wide-level-w ancestor still to visit
         int node = 0, wl = 0, level = 0;                        // wave-uniform
         bool have = true;
-#ifdef MISLAM_DEV_WALK_CAP
-        while (have && dev_steps_left-- > 0) {
-#else
         while (have) {
-#endif
             const int un = __builtin_amdgcn_readfirstlane(node);   // uniform by construction; say so, so the loads below are scalar
             const int k = wl == 0 ? k0 : 3;
             const int base = ((un + 1) << k) - 1;                   // first of the 2^k descendants k levels down
