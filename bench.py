@@ -217,15 +217,22 @@ def cpd_bunny(np, capi, ctx, world):
     for label, approx in modes:
         p = capi.cpd_params(max_iterations=50, sigma2_init=g["sigma2_init"], approximation=approx)
         ctx.cpd_register(before, after, p)                       # warm-up: allocations, code load
-        ctx.profile_enable(True)
+        walls = []
+        for _ in range(3):                                       # the call as a caller makes it: no events on the stream
+            t0 = time.perf_counter()
+            sR, t, scale, it, err = ctx.cpd_register(before, after, p)
+            walls.append(time.perf_counter() - t0)               # host buffers in, result out: upload included
+        wall = min(walls)
+        ctx.profile_enable(True)                                 # once more with HIP events around every kernel, for the breakdown only
         ctx.profile_select(None)
         ctx.profile_reset()
         t0 = time.perf_counter()
-        sR, t, scale, it, err = ctx.cpd_register(before, after, p)
-        wall = time.perf_counter() - t0                          # host buffers in, result out: upload included
+        ctx.cpd_register(before, after, p)
+        wall_profiled = time.perf_counter() - t0
         prof = {capi.KERNEL_NAMES[k]: ctx.profile_get(k) for k in range(len(capi.KERNEL_NAMES))}
         ctx.profile_enable(False)
-        leg = {"iterations": it, "ms_total": wall * 1e3, "ms_per_em_iteration": wall * 1e3 / max(it, 1),
+        leg = {"iterations": it, "ms_total": wall * 1e3, "ms_per_em_iteration": wall * 1e3 / max(it, 1), "ms_total_all": [w * 1e3 for w in walls],
+               "ms_total_with_events_around_every_kernel": wall_profiled * 1e3,
                "kernels_ms_per_launch": {k: v[0] / v[1] for k, v in prof.items() if v[1] > 0}}
         if label == "exact":
             f = g["final_scale_free"]

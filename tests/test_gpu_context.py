@@ -25,3 +25,40 @@ def test_preload_at_creation_through_the_environment(capi, monkeypatch):
         rng = np.random.default_rng(2)
         a = rng.uniform(-1, 1, (300, 3)).astype(np.float32)
         assert c.icp_register(a, a + np.float32(0.05), capi.icp_params(eps=0.0, max_iterations=2))[2] == 2
+
+
+def test_contexts_in_turn_and_in_threads_with_changing_sizes(capi):
+    # Round 4: each context retires its outgrown buffers on its OWN list (released behind a drain of its own stream), device memory
+    # comes out of a private pool, and a load runs on three streams with two scratch sets.  Registrations of changing sizes, on two
+    # contexts taken in turns and then from two host threads at once, must give the bits a fresh context gives for the same clouds.
+    import threading
+    from conftest import synth_cloud
+    sizes = [12000, 150000, 30000, 400000, 20000, 90000]
+    clouds = {n: synth_cloud(n, seed=n)[:2] for n in sizes}
+    p = capi.icp_params(eps=0.0, max_iterations=4)
+    want = {}
+    for n in sizes:
+        with capi.Context(0) as fresh:
+            want[n] = fresh.icp_register(*clouds[n], p)
+
+    def same(a, b):
+        return a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[3] == b[3]
+
+    with capi.Context(0) as c1, capi.Context(0) as c2:
+        for k, n in enumerate(sizes + sizes[::-1]):                      # growing and shrinking, alternating contexts
+            assert same((c1 if k % 2 == 0 else c2).icp_register(*clouds[n], p), want[n]), n
+        bad = []
+
+        def work(ctx, order):
+            for n in order:
+                if not same(ctx.icp_register(*clouds[n], p), want[n]):
+                    bad.append(n)
+        t1 = threading.Thread(target=work, args=(c1, sizes * 2))
+        t2 = threading.Thread(target=work, args=(c2, sizes[::-1] * 2))
+        t1.start(); t2.start(); t1.join(); t2.join()
+        assert not bad, bad
+        # a search primitive and a CPD call between registrations reuse the same workspace
+        i1, d1 = c1.nn_search(clouds[12000][0], clouds[30000][1])
+        i2, d2 = c2.nn_search(clouds[12000][0], clouds[30000][1])
+        assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+        assert same(c1.icp_register(*clouds[150000], p), want[150000])
