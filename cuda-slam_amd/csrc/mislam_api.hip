@@ -557,6 +557,7 @@ extern "C" int mi_selftest_sort_pairs(mi_ctx* c, unsigned int* keys, int* values
     MI_HIP(hipMemcpyAsync(keys, k1.p, sizeof(unsigned int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     MI_HIP(hipMemcpyAsync(values, v1.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     MI_HIP(hipStreamSynchronize(c->stream));
+    k0.release(); k1.release(); v0.release(); v1.release(); temp.release();      // (DevBuf has no destructor: the call's own scratch goes back to the pool here)
     return MI_OK;
 }
 
