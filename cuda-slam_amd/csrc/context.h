@@ -202,6 +202,7 @@ struct mi_ctx {
 
     int prof_begin(int kernel);
     int prof_end();
+    int prof_span(int kernel, hipEvent_t* e0, hipEvent_t* e1);   // a span whose events the LAUNCH records (hipExtLaunchKernelGGL); null events if `kernel` is not being timed
     int prof_collect();
 };
 

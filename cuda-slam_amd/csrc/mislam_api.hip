@@ -447,16 +447,39 @@ extern "C" int mi_ctx_synchronize(mi_ctx* c)
 // ---------------------------------------------------------------------------------------------------------------
 // profiling: HIP events on the context's own stream around each kernel launch
 // ---------------------------------------------------------------------------------------------------------------
+// Timing events WITHOUT the system-scope release a default event performs when it is recorded (hipEventDisableSystemFence): behind the search
+// kernel that release writes back ~20 MB of dirty L2 lines, twice per step.  MISLAM_PROF_EVENT_FLAGS overrides (developer switch).
+static unsigned int c_prof_event_flags()
+{
+    static const unsigned int flags = [] { const char* e = getenv("MISLAM_PROF_EVENT_FLAGS"); return e ? (unsigned int)strtoul(e, nullptr, 0) : (unsigned int)hipEventDisableSystemFence; }();
+    return flags;
+}
+
 int mi_ctx::prof_begin(int kernel)
 {
     ProfileSpan s{};
     s.kernel = kernel;
     for (hipEvent_t* e : {&s.e0, &s.e1}) {
         if (!event_pool.empty()) { *e = event_pool.back(); event_pool.pop_back(); }
-        else MI_HIP(hipEventCreate(e));
+        else MI_HIP(hipEventCreateWithFlags(e, c_prof_event_flags()));
     }
     MI_HIP(hipEventRecord(s.e0, stream));
     spans.push_back(s);
+    return MI_OK;
+}
+
+int mi_ctx::prof_span(int kernel, hipEvent_t* e0, hipEvent_t* e1)
+{
+    *e0 = *e1 = nullptr;
+    if (!(profile && ((prof_mask >> kernel) & 1u))) return MI_OK;
+    ProfileSpan s{};
+    s.kernel = kernel;
+    for (hipEvent_t* e : {&s.e0, &s.e1}) {
+        if (!event_pool.empty()) { *e = event_pool.back(); event_pool.pop_back(); }
+        else MI_HIP(hipEventCreateWithFlags(e, c_prof_event_flags()));
+    }
+    spans.push_back(s);
+    *e0 = s.e0; *e1 = s.e1;
     return MI_OK;
 }
 
@@ -1125,8 +1148,9 @@ static int icp_enqueue_iteration(mi_ctx* c)
         a.filter_pairs = c->icp.filter_pairs; a.max_distance_squared = c->icp.max_distance_squared;
         a.rows = c->rows.p;
         a.order = c->sched_order.p; a.far = c->sched_far.p;
-        ProfScope ps(c, MI_KERNEL_NN);
-        MI_HIP(nn_grid_query(c->grid, c->tree, a, v.fma, c->stream));
+        hipEvent_t e0 = nullptr, e1 = nullptr;           // timed, if at all, by events attached to the launch itself (nn_grid_query)
+        MI_TRY(c->prof_span(MI_KERNEL_NN, &e0, &e1));
+        MI_HIP(nn_grid_query(c->grid, c->tree, a, v.fma, c->stream, e0, e1));
     } else {
         // K1 (+ C1), K2
         MI_TRY(launch_nn(c, c->cx.p, c->cy.p, c->cz.p, c->n, m_local, c->shard_lo, v.fma, &c->d_state->done, c->icp.nn_mode));

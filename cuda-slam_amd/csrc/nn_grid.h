@@ -88,7 +88,7 @@ struct GridSearchArgs {
     const int* order;                      // work order (IcpSchedule): workgroup at position p takes chunk order[p]; null = identity
     unsigned char* far;                    // out: far[chunk] = this chunk's wave walked the hierarchy
 };
-hipError_t nn_grid_query(const NnGridView& g, const NnTreeView& t, const GridSearchArgs& a, int fma, hipStream_t s);
+hipError_t nn_grid_query(const NnGridView& g, const NnTreeView& t, const GridSearchArgs& a, int fma, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 const char* nn_grid_kernel_name(bool fused);
 
 }  // namespace mislam

@@ -33,6 +33,7 @@
 // (LeastSquaresSVD's sums, :168-201) -> one row of partial sums per workgroup (icp_rows.hpp).  The transformed cloud is never
 // written: 20 bytes read + 8 written per moving point besides the search's own traffic.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 
@@ -786,13 +787,18 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
 
 const char* nn_grid_kernel_name(bool) { return "nn_grid_kernel"; }
 
-hipError_t nn_grid_query(const NnGridView& g, const NnTreeView& t, const GridSearchArgs& a, int fma, hipStream_t s)
+// e0 / e1 (both or neither): events that take the kernel's own start and stop timestamps (hipExtLaunchKernelGGL: they ride on the dispatch
+// packet's completion signal).  What mi_profile_* times the search with: two hipEventRecord around the launch are two more packets the
+// command processor has to work through between kernels -- 8.6 us per ICP step at 1e6 points, where the attached events cost nothing.
+hipError_t nn_grid_query(const NnGridView& g, const NnTreeView& t, const GridSearchArgs& a, int fma, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
     if (a.n <= 0) return hipSuccess;
     const dim3 grid((a.n + GRID_BLOCK - 1) / GRID_BLOCK), block(GRID_BLOCK);
     const bool fused = a.state != nullptr;
     if (fused && (a.order == nullptr || a.far == nullptr || a.rows == nullptr || a.match_slot == nullptr)) return hipErrorInvalidValue;   // (the fused kernel does not test for them)
-#define MI_GRID_LAUNCH(F, U, S) hipLaunchKernelGGL((nn_grid_kernel<F, U, S>), grid, block, 0, s, g, t, a)
+    const bool timed = e0 != nullptr && e1 != nullptr;
+#define MI_GRID_LAUNCH(F, U, S) do { if (timed) hipExtLaunchKernelGGL((nn_grid_kernel<F, U, S>), grid, block, 0, s, e0, e1, 0, g, t, a); \
+                                     else hipLaunchKernelGGL((nn_grid_kernel<F, U, S>), grid, block, 0, s, g, t, a); } while (0)
     if (a.stats != nullptr) {          // counting build of the same kernel (mi_profile_search_stats)
         if (fused) { if (fma) MI_GRID_LAUNCH(true, true, true); else MI_GRID_LAUNCH(false, true, true); }
         else { if (fma) MI_GRID_LAUNCH(true, false, true); else MI_GRID_LAUNCH(false, false, true); }
