@@ -15,5 +15,7 @@ unset MISLAM_BENCH_FORCE_DIST
 export MISLAM_BENCH_DEVICE=0 MISLAM_BENCH_TRANSPORT=gloo MISLAM_BENCH_CPD=1
 step bench_rehearsal2_auto timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29536 bench.py --gpus 2 --steps 10 --warmup 2
 step bench_rehearsal4_auto timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29537 bench.py --gpus 4 --steps 10 --warmup 2
+# ... and WITHOUT a launcher: bench.py starts its own ranks (what an unattended N-GPU lease may run)
+step bench_selflaunch2 timeout -k 10 300 python bench.py --gpus 2 --steps 10 --warmup 2 --no-whole-call
 step bench_rehearsal2_target_brute timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29538 bench.py --gpus 2 --steps 3 --warmup 1 --nn brute --shard target --points 200000
 exit 0
