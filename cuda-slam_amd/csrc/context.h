@@ -169,7 +169,8 @@ struct mi_ctx {
     mislam::DevBuf<float4> gpts;                         // cell grid (nn_grid.h): points sorted by cell
     mislam::DevBuf<unsigned int> gstart, gfill, gscan;   // cell offsets, build cursors, scan scratch
     mislam::DevBuf<unsigned int> gslot_of;               // fixed point -> its slot in gpts
-    mislam::DevBuf<unsigned char> gnear, gnear_tmp;      // per cell: a fixed point within the scan's reach (NnGridView::occupied_near), scratch
+    mislam::DevBuf<unsigned int> grow_occ;               // per cell: which of the 5 x 5 cell rows around it hold a point within reach (NnGridView::row_occ)
+    mislam::DevBuf<unsigned char> gnear_tmp;             // build scratch
     mislam::DevBuf<unsigned int> match_slot;             // fused ICP: per moving point, the slot of its current match
     mislam::NnGridView grid{};
     bool grid_valid = false;

@@ -422,7 +422,7 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     c->tleaf.release(); c->tidx.release(); c->tboxes6.release(); c->nn_stats.release();
     c->gpts.release(); c->gstart.release(); c->gfill.release(); c->gscan.release(); c->rows.release(); c->rows_reduced.release();
     c->sched_order.release(); c->sched_far.release(); c->sched_counters.release(); c->gslot_of.release(); c->match_slot.release();
-    c->gnear.release(); c->gnear_tmp.release();
+    c->grow_occ.release(); c->gnear_tmp.release();
     for (auto& s : c->spans) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->d_state) (void)hipFree(c->d_state);
@@ -733,7 +733,7 @@ static int ensure_grid(mi_ctx* c, int m_local, int index_base)
     grid_plan(bbox, m_local, c->tune.grid_points_per_cell, &g);
     const size_t n_cells = (size_t)g.nx * g.ny * g.nz;
     MI_TRY(c->gpts.reserve((size_t)m_local + GRID_PTS_PAD));
-    MI_TRY(c->gnear.reserve(n_cells)); MI_TRY(c->gnear_tmp.reserve(n_cells));
+    MI_TRY(c->grow_occ.reserve(n_cells)); MI_TRY(c->gnear_tmp.reserve(n_cells));
     MI_TRY(c->gstart.reserve(n_cells + 1 + 3));           // (+3: a row's offsets are fetched four words at a time)
     MI_TRY(c->gfill.reserve(n_cells + 1));
     MI_TRY(c->gscan.reserve((n_cells + 1) / 1024 + 2));
@@ -741,12 +741,12 @@ static int ensure_grid(mi_ctx* c, int m_local, int index_base)
     g.pts = c->gpts.p;
     g.cell_start = c->gstart.p;
     g.slot_of = c->gslot_of.p;
-    g.occupied_near = c->gnear.p;
+    g.row_occ = c->grow_occ.p;
     g.index_base = index_base;
     GridBuildArgs a{};
     a.x = c->tx.p; a.y = c->ty.p; a.z = c->tz.p; a.m = m_local; a.index_base = index_base;
     a.view = g; a.cell_fill = c->gfill.p; a.scan_tmp = c->gscan.p; a.pts_out = c->gpts.p; a.cell_start_out = c->gstart.p; a.slot_of_out = c->gslot_of.p;
-    a.near_out = c->gnear.p; a.near_tmp = c->gnear_tmp.p;
+    a.row_occ_out = c->grow_occ.p; a.near_tmp = c->gnear_tmp.p;
     MI_HIP(grid_build(a, ws));
     c->grid = g;
     c->grid_valid = true;

@@ -36,8 +36,9 @@ struct NnGridView {
                                            // copies of the last one
     const unsigned int* cell_start;        // nx*ny*nz + 1 offsets into pts
     const unsigned int* slot_of;           // local index of a fixed point (global - index_base) -> its slot in pts
-    const unsigned char* occupied_near;    // per cell: 1 iff some fixed point lies in a cell within GRID_REACH_CELLS (Chebyshev) of it --
-                                           // 0 tells a query in that cell that its scan cannot meet a single candidate
+    const unsigned int* row_occ;           // per cell (cx, cy, cz): bit oz * 5 + oy set iff the cell ROW (cy + oy - 2, cz + oz - 2) holds a fixed point in
+                                           // cells cx - 2 .. cx + 2 (GRID_REACH_CELLS).  0 tells a query in that cell that its scan cannot meet a single
+                                           // candidate; a clear bit, that the scan need not look at that row (round 4)
     int index_base;                        // global index of this shard's point 0
     float ox, oy, oz;                      // lower corner of the bounding box
     float inv_h;                           // cells per unit length; cell coordinate of p on an axis: floor((p - o) * inv_h)
@@ -59,7 +60,7 @@ struct GridBuildArgs {
     float4* pts_out;
     unsigned int* cell_start_out;
     unsigned int* slot_of_out;
-    unsigned char* near_out;               // nx*ny*nz bytes (NnGridView::occupied_near)
+    unsigned int* row_occ_out;             // nx*ny*nz words (NnGridView::row_occ)
     unsigned char* near_tmp;               // nx*ny*nz bytes of scratch
 };
 hipError_t grid_build(const GridBuildArgs& a, hipStream_t s);

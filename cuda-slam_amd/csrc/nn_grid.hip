@@ -207,8 +207,9 @@ __global__ void grid_pad_kernel(float4* __restrict__ pts, int m)
     if (threadIdx.x < GRID_PTS_PAD) pts[m + threadIdx.x] = pts[m - 1];
 }
 
-// occupied_near, three separable passes: a cell's run of x-neighbours is one contiguous stretch of pts (two offsets tell whether it
-// holds a point), then OR over the y- and the z-neighbours
+// row_occ (NnGridView): first, per cell, whether its run of x-neighbours -- one contiguous stretch of pts: two offsets tell -- holds a point;
+// then, per cell, those flags of the 5 x 5 rows around it as one word
+static_assert(GRID_REACH_CELLS == 2, "row_occ holds the 5 x 5 rows within two cells");
 __global__ __launch_bounds__(256) void grid_near_x_kernel(NnGridView g, const unsigned int* __restrict__ cell_start, unsigned int n_cells,
                                                           unsigned char* __restrict__ out)
 {
@@ -220,17 +221,22 @@ __global__ __launch_bounds__(256) void grid_near_x_kernel(NnGridView g, const un
     out[c] = cell_start[row + hi + 1] > cell_start[row + lo] ? 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void grid_near_axis_kernel(const unsigned char* __restrict__ in, unsigned int n_cells, int stride, int dim,
-                                                             unsigned char* __restrict__ out)
+__global__ __launch_bounds__(256) void grid_row_occ_kernel(NnGridView g, const unsigned char* __restrict__ near_x, unsigned int n_cells,
+                                                           unsigned int* __restrict__ out)
 {
     const unsigned int c = blockIdx.x * 256u + threadIdx.x;
     if (c >= n_cells) return;
-    const int i = (int)((c / (unsigned int)stride) % (unsigned int)dim);      // this cell's coordinate on the axis
-    unsigned char v = 0;
+    const int x = (int)(c % (unsigned int)g.nx), y = (int)((c / (unsigned int)g.nx) % (unsigned int)g.ny), z = (int)(c / ((unsigned int)g.nx * (unsigned int)g.ny));
+    unsigned int w = 0u;
 #pragma unroll
-    for (int d = -GRID_REACH_CELLS; d <= GRID_REACH_CELLS; d++)
-        if (i + d >= 0 && i + d < dim) v |= in[(long long)c + (long long)d * stride];
-    out[c] = v;
+    for (int oz = 0; oz < 5; oz++)
+#pragma unroll
+        for (int oy = 0; oy < 5; oy++) {
+            const int iy = y + oy - 2, iz = z + oz - 2;
+            if (iy >= 0 && iy < g.ny && iz >= 0 && iz < g.nz && near_x[((unsigned int)iz * (unsigned int)g.ny + (unsigned int)iy) * (unsigned int)g.nx + (unsigned int)x] != 0)
+                w |= 1u << (oz * 5 + oy);
+        }
+    out[c] = w;
 }
 
 hipError_t grid_build(const GridBuildArgs& a, hipStream_t s)
@@ -250,9 +256,8 @@ hipError_t grid_build(const GridBuildArgs& a, hipStream_t s)
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(pb), dim3(256), 0, s, g, a.x, a.y, a.z, a.m, a.index_base, a.cell_fill, a.pts_out, a.slot_of_out);
     hipLaunchKernelGGL(grid_pad_kernel, dim3(1), dim3(64), 0, s, a.pts_out, a.m);
     const unsigned int cb = (n_cells + 255u) / 256u;
-    hipLaunchKernelGGL(grid_near_x_kernel, dim3(cb), dim3(256), 0, s, g, a.cell_start_out, n_cells, a.near_out);
-    hipLaunchKernelGGL(grid_near_axis_kernel, dim3(cb), dim3(256), 0, s, a.near_out, n_cells, g.nx, g.ny, a.near_tmp);
-    hipLaunchKernelGGL(grid_near_axis_kernel, dim3(cb), dim3(256), 0, s, a.near_tmp, n_cells, g.nx * g.ny, g.nz, a.near_out);
+    hipLaunchKernelGGL(grid_near_x_kernel, dim3(cb), dim3(256), 0, s, g, a.cell_start_out, n_cells, a.near_tmp);
+    hipLaunchKernelGGL(grid_row_occ_kernel, dim3(cb), dim3(256), 0, s, g, a.near_tmp, n_cells, a.row_occ_out);
     return hipGetLastError();
 }
 
@@ -419,7 +424,7 @@ __device__ __forceinline__ bool grid_deal_scan(const float4* __restrict__ pts, c
 // One batch: takes up to GRID_BATCH rows off `mask`, scans cells [x0, x1] of each that lies within r2.  BLOCK: the rows are the (up to)
 // 2 x 2 rows [blk.y0, blk.y1] x [blk.z0, blk.z1] of the nearest block instead -- named directly, their two gaps per axis computed once.
 struct GridBlockRows { int y0, y1, z0, z1; };
-// `reach` (BLOCK only): occupied_near of the query's cell, a byte that is still on its way from memory when the block's offsets are
+// `reach` (BLOCK only): row_occ of the query's cell, a word that is still on its way from memory when the block's offsets are
 // requested -- it only decides whether their runs count, so the two round trips overlap.
 template <bool FMA, bool STATS, bool BLOCK>
 __device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, unsigned int& mask, int x0, int x1, float r2, const GridBlockRows& blk,
@@ -529,7 +534,7 @@ __device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, uns
 // met, because r2 only shrinks and every row test and cell range uses an r2 that is at least the final one.  So if the final best
 // is within cap2 the answer is exact; otherwise (nothing near: the query lies outside the fixed cloud, or has no starting
 // candidate and sits in an empty region) the lane gives up.  cap2 is the square of (a hair less than) GRID_DU_MAX cells.
-// `reach_word` = occupied_near of the query's cell: 0 says no cell the scan could visit holds a point.  `lane_on`: the lane has a point.
+// `reach_word` = row_occ of the query's cell: 0 says no cell the scan could visit holds a point, a clear bit that its row holds none.  `lane_on`: the lane has a point.
 template <bool FMA, bool STATS>
 __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3], bool lane_on, unsigned int reach_word, float& best, unsigned int& bidx,
                                             unsigned int& bslot, unsigned int& n_cand, unsigned int& n_rows
@@ -586,7 +591,9 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
         const int y0 = (int)fmaxf(fy0, 0.f), y1 = (int)fminf(fy1, (float)(g.ny - 1));
         const int z0 = (int)fmaxf(fz0, 0.f), z1 = (int)fminf(fz1, (float)(g.nz - 1));
         const bool covered = x0 >= xa0 && x1 <= xa1;           // the block's rows need no second look
-        mask = s.alive ? grid_rows_mask(y0 - s.cy + GRID_ROWS_R, y1 - s.cy + GRID_ROWS_R, z0 - s.cz + GRID_ROWS_R, z1 - s.cz + GRID_ROWS_R) & ~(covered ? block : 0u) : 0u;
+        // (& reach_word: rows that hold no point within the scan's cells are never looked at -- row_occ; round 3 found them empty one batch of four
+        // at a time, 2.3 batches per scan wave where one lane in five has any rows left)
+        mask = s.alive ? grid_rows_mask(y0 - s.cy + GRID_ROWS_R, y1 - s.cy + GRID_ROWS_R, z0 - s.cz + GRID_ROWS_R, z1 - s.cz + GRID_ROWS_R) & ~(covered ? block : 0u) & reach_word : 0u;
     }
     // ---- the leftover rows -- about one lane in five has any (its neighbour lies beyond the block, or the radius still pokes out of it),
     // one to four each, more at the cloud's edge -- four per lane and round, their trips dealt out over the wave like the block's.  (Round 3
@@ -690,9 +697,9 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
     }
 
     MI_TL_STAMP(tl_p3, best);
-    // occupied_near of the query's (clamped) cell: 0 = the scan could not meet a single point (requested here, ahead of the scan)
+    // row_occ of the query's (clamped) cell: 0 = the scan could not meet a single point; a clear bit = nothing in that row (requested here, ahead of the scan)
     // (every lane asks -- a lane without a point has q = 0, some cell of the grid: no branch, so nothing waits for the byte here)
-    const unsigned int near_word = g.occupied_near[cell_of(g, q[0], q[1], q[2])];
+    const unsigned int near_word = g.row_occ[cell_of(g, q[0], q[1], q[2])];
     bool hard = false;
     unsigned int n_cand = 0u, n_rows = 0u, n_nodes = 0u, n_leaves = 0u;
     // A chunk most of whose lanes ended beyond the grid's reach last time (they will again: the flags move slowly) skips the scan:
