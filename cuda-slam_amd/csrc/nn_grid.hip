@@ -342,19 +342,38 @@ __device__ __forceinline__ unsigned int grid_trip_round(int c) { return (unsigne
 #define MISLAM_GRID_DEAL_GAIN 1          // deal when the passes (plus this) are fewer than the longest lane's trips
 #endif
 constexpr unsigned int GRID_DEAL_MAX = MISLAM_GRID_DEAL_MAX;
+// The wave's LDS (one wave per workgroup; 4.9 KB: 32 workgroups fit a CU's 160 KB)
+struct GridWaveLds {
+    unsigned int deal_p[GRID_DEAL_MAX];              // trip -> slot of its first candidate
+    unsigned char deal_owner[GRID_DEAL_MAX];         // trip -> the lane it belongs to
+    float4 deal_q[64];                               // per OWNER: its query (w: the radius its leftover rows are tested with)
+    unsigned long long deal_key[64];                 // per OWNER: running minimum of the keys found for it
+    unsigned int deal_slot[64];                      // per OWNER: where that minimum sits in pts
+    // the leftover rows dealt out (grid_rows_dealt): one record per lane that has rows, packed in lane order
+    unsigned int rec_first[64];                      // rank -> number of rows before this lane's | lane << 16
+    unsigned int rec_rows[64];                       // rank -> its row mask
+    unsigned int own_x[64];                          // per OWNER: cell range x0 | x1 << 16
+    unsigned int own_c[64];                          // per OWNER: its own row cy | cz << 16
+    unsigned int own_cand[64];                       // per OWNER: candidates its rows hold (the budget)
+};
+__device__ __forceinline__ GridWaveLds& grid_wave_lds()
+{
+    __shared__ GridWaveLds lds;
+    return lds;
+}
 // Returns false (nothing done) if dealing does not pay or does not fit; true: kbest / bslot hold the lane's results.
+// `owner_lane`: the lane the trips are tested FOR (the lane itself, or -- leftover rows dealt out -- the lane whose row it scans; then
+// `own_setup` is false: the owners' queries and keys are in LDS already).
 template <bool FMA>
 __device__ __forceinline__ bool grid_deal_scan(const float4* __restrict__ pts, const float q[3], unsigned int n_trips, unsigned int e1, unsigned int e2,
                                                unsigned int e3, unsigned int b0, unsigned int b1, unsigned int b2, unsigned int b3,
-                                               unsigned long long& kbest, unsigned int& bslot, unsigned int& dev_passes)
+                                               unsigned long long& kbest, unsigned int& bslot, unsigned int& dev_passes,
+                                               unsigned int owner_lane, bool own_setup)
 {
     static_assert(GRID_TRIP == 4, "a dealt trip is four candidates");
-    // (3.6 KB of LDS per wave -- one wave per workgroup; at 7 waves per SIMD a CU's 160 KB leave 5.8 KB each)
-    __shared__ unsigned int deal_p[GRID_DEAL_MAX];             // trip -> slot of its first candidate
-    __shared__ unsigned char deal_owner[GRID_DEAL_MAX];        // trip -> the lane it belongs to
-    __shared__ float4 deal_q[64];                              // per OWNER: its query
-    __shared__ unsigned long long deal_key[64];                // per OWNER: running minimum of the keys found for it
-    __shared__ unsigned int deal_slot[64];                     // per OWNER: where that minimum sits in pts
+    GridWaveLds& L = grid_wave_lds();
+    unsigned int* deal_p = L.deal_p; unsigned char* deal_owner = L.deal_owner; float4* deal_q = L.deal_q;
+    unsigned long long* deal_key = L.deal_key; unsigned int* deal_slot = L.deal_slot;
     const int lane = (int)threadIdx.x & 63;
     if (__builtin_amdgcn_ballot_w64(n_trips >= 32u) != 0ull) return false;
     // counts -> exclusive prefix, total and maximum, bit by bit: ballots, mbcnt and scalar arithmetic, no exchange
@@ -377,9 +396,11 @@ __device__ __forceinline__ bool grid_deal_scan(const float4* __restrict__ pts, c
     if (total > GRID_DEAL_MAX || passes + MISLAM_GRID_DEAL_GAIN >= longest) return false;
     auto below = [](unsigned long long m) { return (unsigned int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u)); };
     const unsigned int first = below(B0) + 2u * below(B1) + 4u * below(B2) + 8u * below(B3) + 16u * below(B4);
-    deal_q[lane] = make_float4(q[0], q[1], q[2], 0.f);
-    deal_key[lane] = kbest;
-    const unsigned char mine = (unsigned char)lane;
+    if (own_setup) {
+        deal_q[lane] = make_float4(q[0], q[1], q[2], 0.f);
+        deal_key[lane] = kbest;
+    }
+    const unsigned char mine = (unsigned char)owner_lane;
     for (unsigned int k = 0; k < longest; k++) {                // (wave-uniform bound: the lane with the most trips)
         if (k < n_trips) {
             const unsigned int t = k * GRID_TRIP;
@@ -498,7 +519,7 @@ __device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, uns
 #ifndef MISLAM_GRID_NO_DEAL
     {
         unsigned int dev_passes = 0u;
-        const bool dealt = grid_deal_scan<FMA>(pts, s.q, e4 / GRID_TRIP, e1, e2, e3, b0, b1, b2, b3, kbest, bslot, dev_passes);
+        const bool dealt = grid_deal_scan<FMA>(pts, s.q, e4 / GRID_TRIP, e1, e2, e3, b0, b1, b2, b3, kbest, bslot, dev_passes, (unsigned int)threadIdx.x & 63u, true);
 #ifdef MISLAM_DEV_WAVE_TIMELINE
         if (BLOCK) s.trips_block += dev_passes; else s.trips_rest += dev_passes;
 #endif
@@ -526,6 +547,136 @@ __device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, uns
     }
     s.kbest = kbest;
     s.bslot = bslot;
+}
+
+// The leftover rows of a wave DEALT OUT, one row per lane.  Taken four per lane and batch (grid_batch) a wave needed as many batches
+// as its busiest lane has rows / 4 -- 2.3 on average (profiles/r04_wave_timeline.log), ~240 vector instructions each for everyone,
+// while most lanes have no row left at all.  Here every lane that has rows writes ONE record (its mask, and how many rows the lanes
+// before it hold: a prefix sum by ballots), and lane L takes row L of the wave -- it finds the record by a binary search over the
+// prefix sums, the row as the n-th set bit of the record's mask, and tests it for its OWNER: the owner's query, radius, cell range
+// and own row come from LDS, the result goes back through an LDS minimum, exactly as for dealt trips.  Every row is tested with the
+// radius the owner had when the rows were dealt (grid_batch re-reads it between batches): a superset, never a miss.
+#ifndef MISLAM_GRID_ROWS_DEALT
+#define MISLAM_GRID_ROWS_DEALT 1
+#endif
+__device__ __forceinline__ int nth_set_bit(unsigned int m, unsigned int n)      // position of set bit number n (from 0) of m; n < popcount(m)
+{
+    int pos = 0;
+    unsigned int c = (unsigned int)__builtin_popcount(m & 0xffffu);
+    if (n >= c) { n -= c; pos = 16; m >>= 16; }
+    c = (unsigned int)__builtin_popcount(m & 0xffu);
+    if (n >= c) { n -= c; pos += 8; m >>= 8; }
+    c = (unsigned int)__builtin_popcount(m & 0xfu);
+    if (n >= c) { n -= c; pos += 4; m >>= 4; }
+    c = (unsigned int)__builtin_popcount(m & 3u);
+    if (n >= c) { n -= c; pos += 2; m >>= 2; }
+    if (n >= (m & 1u)) pos += 1;
+    return pos;
+}
+template <bool FMA, bool STATS>
+__device__ __forceinline__ void grid_rows_dealt(const NnGridView& g, GridLane& s, unsigned int mask, int x0, int x1, float r2)
+{
+    GridWaveLds& L = grid_wave_lds();
+    const float4* __restrict__ pts = g.pts;
+    const unsigned int* __restrict__ cell_start = g.cell_start;
+    const unsigned int lane = (unsigned int)threadIdx.x & 63u;
+    if (!s.alive || x1 < x0) mask = 0u;
+    const unsigned int k = (unsigned int)__builtin_popcount(mask);              // <= 25
+    const unsigned long long B0 = __builtin_amdgcn_ballot_w64((k & 1u) != 0u), B1 = __builtin_amdgcn_ballot_w64((k & 2u) != 0u),
+                             B2 = __builtin_amdgcn_ballot_w64((k & 4u) != 0u), B3 = __builtin_amdgcn_ballot_w64((k & 8u) != 0u),
+                             B4 = __builtin_amdgcn_ballot_w64((k & 16u) != 0u);
+    const unsigned int total = (unsigned int)__builtin_popcountll(B0) + 2u * (unsigned int)__builtin_popcountll(B1) + 4u * (unsigned int)__builtin_popcountll(B2) +
+                               8u * (unsigned int)__builtin_popcountll(B3) + 16u * (unsigned int)__builtin_popcountll(B4);
+    auto below = [](unsigned long long m) { return (unsigned int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u)); };
+    const unsigned int first = below(B0) + 2u * below(B1) + 4u * below(B2) + 8u * below(B3) + 16u * below(B4);
+    const unsigned long long producers = B0 | B1 | B2 | B3 | B4;
+    const unsigned int n_rec = (unsigned int)__builtin_popcountll(producers), rank = below(producers);
+    L.deal_q[lane] = make_float4(s.q[0], s.q[1], s.q[2], r2);
+    L.deal_key[lane] = s.kbest;
+    L.own_x[lane] = (unsigned int)x0 | ((unsigned int)x1 << 16);
+    L.own_c[lane] = (unsigned int)s.cy | ((unsigned int)s.cz << 16);
+    L.own_cand[lane] = 0u;
+    if (mask != 0u) { L.rec_first[rank] = first | (lane << 16); L.rec_rows[rank] = mask; }
+    __syncthreads();                                            // (one wave per workgroup: orders the LDS traffic)
+    for (unsigned int base = 0; base < total; base += 64u) {    // (wave-uniform; one round unless the wave has more than 64 rows left)
+        const unsigned int c = base + lane;
+        const bool have = c < total;
+        unsigned int lo = 0u;                                   // the last record that starts at or before row c
+#pragma unroll
+        for (unsigned int w = 32u; w != 0u; w >>= 1) {
+            const unsigned int j = lo + w;
+            const unsigned int f = L.rec_first[j & 63u] & 0xffffu;
+            lo = (j < n_rec && f <= c) ? j : lo;
+        }
+        const unsigned int rec = L.rec_first[lo], rows = have ? L.rec_rows[lo] : 1u;
+        const unsigned int owner = have ? rec >> 16 : lane;
+        const int b = nth_set_bit(rows, have ? c - (rec & 0xffffu) : 0u);
+        const int oz = (b * ((256 + GRID_ROWS_W - 1) / GRID_ROWS_W)) >> 8, oy = b - GRID_ROWS_W * oz;   // b / W, b % W
+        const float4 oq = L.deal_q[owner];
+        const unsigned int ox = L.own_x[owner], oc = L.own_c[owner];
+        const int iy = (int)(oc & 0xffffu) + oy - GRID_ROWS_R, iz = (int)(oc >> 16) + oz - GRID_ROWS_R;
+        const float gy = gap_cells(cell_u(oq.y, g.oy, g.inv_h), iy) * g.h_lo, gz = gap_cells(cell_u(oq.z, g.oz, g.inv_h), iz) * g.h_lo;
+        // a row is skipped only if it is strictly farther than the search radius: then it cannot win or tie
+        const bool ok = have && gy * gy + gz * gz <= oq.w;
+        const unsigned int rb = ((unsigned int)iz * (unsigned int)g.ny + (unsigned int)iy) * (unsigned int)g.nx;
+        const unsigned int S = cell_start[ok ? rb + (ox & 0xffffu) : 0u];
+        int C = (int)(cell_start[ok ? rb + (ox >> 16) + 1u : 0u] - S);
+        if (STATS) s.n_rows += ok ? 1u : 0u;
+        // crowded (one row beyond a lane's whole budget): not scanned, and the owner gives up -- the hierarchy takes over
+        const bool crowded = C > GRID_CAND_BUDGET;
+        if (ok) atomicAdd(&L.own_cand[owner], crowded ? (unsigned int)(2 * GRID_CAND_BUDGET) : (unsigned int)C);
+        C = crowded ? 0 : C;
+        const unsigned int e = grid_trip_round(C);
+        const unsigned int t_last = e >= GRID_TRIP ? e - GRID_TRIP : 0u;
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+        s.batches_rest += 1;
+#endif
+#ifndef MISLAM_GRID_NO_DEAL
+        {
+            // the trips of the dealt rows, dealt in turn (3.6 lockstep trips per round without, 1.6 passes + trips with: the rows' runs
+            // differ in length); kbest / bslot: the lane's OWN -- the deal ends with every lane collecting what was found for it
+            unsigned int dev_passes = 0u;
+            const bool dealt = grid_deal_scan<FMA>(pts, s.q, e / GRID_TRIP, e, e, e, S, S, S, S, s.kbest, s.bslot, dev_passes, owner, false);
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+            s.trips_rest += dev_passes;
+#endif
+            if (dealt) continue;
+        }
+#endif
+        unsigned long long kb = L.deal_key[owner];
+        const unsigned long long kb0 = kb;
+        unsigned int slot = 0u;
+        for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < e) != 0ull; t += GRID_TRIP) {
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+            s.trips_rest += 1;
+#endif
+            const unsigned int p = S + min(t, t_last);
+            const float4* __restrict__ pp = pts + p;
+            float4 cs[GRID_TRIP];
+#pragma unroll
+            for (unsigned int j4 = 0; j4 < GRID_TRIP; j4++) cs[j4] = pp[j4];
+#pragma unroll
+            for (unsigned int j4 = 0; j4 < GRID_TRIP; j4++) {
+                const float d = sq3<FMA>(cs[j4].x - oq.x, cs[j4].y - oq.y, cs[j4].z - oq.z);
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(cs[j4].w);
+                const bool better = key < kb;
+                kb = better ? key : kb;
+                slot = better ? p + j4 : slot;
+            }
+        }
+        const bool won = C > 0 && kb < kb0;
+        if (won) atomicMin(&L.deal_key[owner], kb);
+        // LDS operations of one wave complete in program order: every lane now reads the minimum, and whoever holds it says where
+        if (won && L.deal_key[owner] == kb) L.deal_slot[owner] = slot;
+        __syncthreads();
+    }
+    __syncthreads();
+    const unsigned long long kfin = L.deal_key[lane];
+    if (kfin < s.kbest) { s.kbest = kfin; s.bslot = L.deal_slot[lane]; }
+    const int cand = (int)L.own_cand[lane];
+    if (cand > s.budget) s.alive = false;
+    s.budget -= min(cand, s.budget);
+    __syncthreads();                                            // (the records are read: the next use of the arrays may write)
 }
 
 // Grid part of one lane's search.  Returns true if the lane gave up (it must then walk the hierarchy from (best, bidx)).
@@ -599,6 +750,13 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
     // one to four each, more at the cloud's edge -- four per lane and round, their trips dealt out over the wave like the block's.  (Round 3
     // first dealt the ROWS out, one per lane, before there was a way to deal trips: git show eefc579:cuda-slam_amd/csrc/nn_grid.hip; with the
     // trips dealt the two are as fast, at 1e5, 1e6 and 1e7 points, and this is the shorter code.)
+#if MISLAM_GRID_ROWS_DEALT
+    if (__builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) {
+        const int x0 = (int)fmaxf(fx0, 0.f), x1 = (int)fminf(fx1, (float)(g.nx - 1));
+        grid_rows_dealt<FMA, STATS>(g, s, mask, x0, x1, r2);
+        mask = 0u;
+    }
+#endif
     while (__builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) {
         // the cells of a row from the radius as it stands now: one range for the whole batch (a superset of what each row's own
         // gap would leave of it)
