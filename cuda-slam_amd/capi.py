@@ -35,7 +35,7 @@ EXPORTS = [
     "mi_ctx_create_exchange", "mi_ctx_preload", "mi_ctx_rank", "mi_dist_info", "mi_shard_range", "mi_source_share", "mi_pack_key", "mi_unpack_key", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_icp_params_default", "mi_icp_params_cuda_slam",
     "mi_icp_register", "mi_icp_load", "mi_icp_reset", "mi_icp_run", "mi_icp_auto_batch", "mi_icp_result", "mi_nn_search", "mi_nn_search_ex", "mi_cross_moments", "mi_kabsch",
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_sigma_squared_mode", "mi_cpd_estep",
-    "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
+    "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_kcenter_guided", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
     "mi_prepare_params_default", "mi_prepare_cloud",
     "mi_cpd_mstep", "mi_profile_enable", "mi_profile_select", "mi_profile_reset", "mi_profile_get", "mi_icp_load_times", "mi_profile_search_stats", "mi_selftest_sort_pairs", "mi_nn_kernel_name",
 ]
@@ -396,6 +396,18 @@ class Context:
         cluster = np.empty(cloud.shape[0], np.int32)
         _check(lib().mi_fgt_kcenter(self._h, _fp(cloud), cloud.shape[0], int(K), _fp(centers), cluster.ctypes.data_as(_i)))
         return centers, cluster
+
+    def fgt_kcenter_guided(self, cloud, K, guess):
+        """-> centers, cluster, picked (the sweep's choices), verified (leading entries of `guess` that were the sweep's own; -1: no replay)"""
+        cloud = _cloud(cloud)
+        guess = np.ascontiguousarray(guess, np.int32)
+        centers = np.empty((K, 3), np.float32)
+        cluster = np.empty(cloud.shape[0], np.int32)
+        picked = np.empty(K, np.int32)
+        verified = C.c_int(-2)
+        _check(lib().mi_fgt_kcenter_guided(self._h, _fp(cloud), cloud.shape[0], int(K), guess.ctypes.data_as(_i), int(guess.shape[0]), _fp(centers),
+                                           cluster.ctypes.data_as(_i), picked.ctypes.data_as(_i), C.byref(verified)))
+        return centers, cluster, picked, verified.value
 
     def cpd_mstep(self, before, after, p1, pt1, px, const_scale, scale=1.0, sigma2=0.0):
         before, after = _cloud(before), _cloud(after)

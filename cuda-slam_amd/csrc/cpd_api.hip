@@ -22,8 +22,15 @@ struct FgtSide {
     DevBuf<float> dist, xc;
     DevBuf<int> indx, memb, off;
     DevBuf<unsigned char> sweep;   // scratch of the grid-wide sweep (large clouds)
+    DevBuf<int> picked, replay_state;             // the sweep's choices; the replay's verdict (fgt_replay_kernel)
+    DevBuf<unsigned long long> replay_partial;
     int swept_K = 0;            // the fixed cloud only: centres of the sweep dist/indx currently hold (0 = none); see fgt_kcenter_kernel
-    void release() { dist.release(); xc.release(); indx.release(); memb.release(); off.release(); sweep.release(); swept_K = 0; }
+    int guess_K = 0;            // the moving cloud only: leading entries of `picked` the last E-step's sweep left -- the next one's guess
+    void release()
+    {
+        dist.release(); xc.release(); indx.release(); memb.release(); off.release(); sweep.release(); picked.release(); replay_state.release();
+        replay_partial.release(); swept_K = 0; guess_K = 0;
+    }
 };
 
 // Fast-Gauss-Transform E-step workspace ("approximation-type" full / hybrid)
@@ -103,6 +110,7 @@ static int cpd_load(mi_ctx* c, CpdWorkspace* w, const float* before_xyz, int m, 
 {
     c->icp_loaded = false;   // the moving-cloud buffers are shared with the ICP driver
     w->fgt.a.swept_K = 0;    // a new fixed cloud: its clustering starts over
+    w->fgt.y.guess_K = 0;    // a new moving cloud: nothing to guess its sweep from
     w->m = m; w->n = n; w->n_total = n;
     w->m_pad = round_up_i(m, NN_SRC_PAD);
     w->n_pad = round_up_i(n, NN_SRC_PAD);
@@ -283,9 +291,25 @@ static int fgt_side(mi_ctx* c, FgtWork* f, FgtSide* sd, const float* x, const fl
     MI_TRY(f->sort_temp.reserve(std::max<size_t>(fgt_sort_temp_bytes(n), 16)));
     if (n > FGT_GRID_SWEEP_MIN_POINTS) MI_TRY(sd->sweep.reserve(FGT_SWEEP_SCRATCH_BYTES));
     out->sweep_scratch = n > FGT_GRID_SWEEP_MIN_POINTS ? sd->sweep.p : nullptr;
+    // (picked: never shrunk below what a guess still needs -- reserve() keeps the contents when the capacity suffices, and K only grows
+    // within a registration; a reallocation loses the guess, so it is dropped with it)
+    if (sd->picked.cap < (size_t)K) sd->guess_K = 0;
+    MI_TRY(sd->picked.reserve(std::max<size_t>((size_t)K, 1024))); MI_TRY(sd->replay_state.reserve(1));
+    out->picked = sd->picked.p; out->guess = 0; out->replay_partial = nullptr; out->replay_state = sd->replay_state.p;
     out->x = x; out->y = y; out->z = z; out->n = n; out->K = K; out->k_done = 0;
     out->dist = sd->dist.p; out->indx = sd->indx.p;
     out->memb = sd->memb.p; out->off = sd->off.p; out->xc = sd->xc.p;
+    return MI_OK;
+}
+
+// cl->picked[0 .. guess) holds a guess: size the replay's scratch and arm it (guess < 2: nothing to replay)
+static int fgt_arm_replay(mi_ctx* c, FgtSide* sd, FgtClusters* cl, int guess)
+{
+    (void)c;
+    const int lim = fgt_replay_limit(guess, cl->K);
+    if (lim < 1) return MI_OK;
+    MI_TRY(sd->replay_partial.reserve((size_t)lim * (size_t)fgt_replay_waves(cl->n)));
+    cl->guess = guess; cl->replay_partial = sd->replay_partial.p;
     return MI_OK;
 }
 
@@ -323,7 +347,10 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
     MI_TRY(f->kt1.reserve((size_t)Sa * w->n)); MI_TRY(f->v4.reserve(4 * (size_t)Sy * w->m));
     const size_t temp = f->sort_temp.cap;
     // Kt1 = K^T 1: sources = moving cloud, unit weights, queried at the fixed cloud   (cpdutils.cpp:42-43)
+    // (the moving cloud's sweep: last E-step's choices replayed and checked in parallel, MISLAM_FGT_REPLAY=0: swept step by step every time)
+    MI_TRY(fgt_arm_replay(c, &f->y, &cy, c->tune.fgt_replay != 0 ? f->y.guess_K : 0));
     MI_HIP(fgt_cluster(cy, f->sort_temp.p, temp, c->stream));
+    f->y.guess_K = K;
     MI_HIP(fgt_model(cy, nullptr, hsigma, t, f->By.p, c->stream));
     MI_HIP(fgt_predict(v.ax, v.ay, v.az, w->n, cy.xc, f->By.p, K, 1, hsigma, ratio_of_far_field, t, Sa, f->kt1.p, c->stream));
     MI_HIP(fgt_post_kt1(f->kt1.p, Sa, v.ax, v.ay, v.az, w->n, ndi, v.pt1, v.xw4, c->stream));
@@ -566,11 +593,45 @@ extern "C" int mi_fgt_kcenter(mi_ctx* c, const float* cloud_xyz, int n, int K, f
     MI_TRY(c->bx.reserve(n_pad)); MI_TRY(c->by.reserve(n_pad)); MI_TRY(c->bz.reserve(n_pad));
     MI_TRY(upload_soa(c, cloud_xyz, n, n_pad, c->bx.p, c->by.p, c->bz.p, nullptr));
     FgtClusters cl{};
+    w->fgt.y.guess_K = 0;                // (the buffers of the moving side now hold another cloud's sweep)
     MI_TRY(fgt_side(c, &w->fgt, &w->fgt.y, c->bx.p, c->by.p, c->bz.p, n, K, &cl));
     MI_HIP(fgt_cluster(cl, w->fgt.sort_temp.p, w->fgt.sort_temp.cap, c->stream));
     MI_HIP(hipMemcpyAsync(cluster, cl.indx, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     MI_HIP(hipMemcpyAsync(centers_xyz, cl.xc, sizeof(float) * 3 * (size_t)K, hipMemcpyDeviceToHost, c->stream));
     MI_HIP(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+extern "C" int mi_fgt_kcenter_guided(mi_ctx* c, const float* cloud_xyz, int n, int K, const int* guess, int n_guess, float* centers_xyz, int* cluster,
+                                     int* picked, int* verified)
+{
+    if (!c) { set_error("mi_fgt_kcenter_guided: null context"); return MI_ERR_INVALID_ARG; }
+    if (!cloud_xyz || !centers_xyz || !cluster || (n_guess > 0 && !guess)) { set_error("mi_fgt_kcenter_guided: null argument"); return MI_ERR_INVALID_ARG; }
+    if (n < 2 || K < 1 || K > FGT_MAX_CLUSTERS || n_guess < 0) { set_error("mi_fgt_kcenter_guided: need n >= 2, 1 <= K <= %d, n_guess >= 0 (n=%d, K=%d, n_guess=%d)", FGT_MAX_CLUSTERS, n, K, n_guess); return MI_ERR_INVALID_ARG; }
+    for (int i = 0; i < n_guess; i++)
+        if (guess[i] < 0 || guess[i] >= n) { set_error("mi_fgt_kcenter_guided: guess[%d] = %d is not a point of the cloud", i, guess[i]); return MI_ERR_INVALID_ARG; }
+    MI_ENTER(c);
+    CpdWorkspace* w = nullptr;
+    MI_TRY(cpd_workspace(c, &w));
+    c->icp_loaded = false;
+    w->fgt.y.guess_K = 0;
+    const int n_pad = round_up_i(n, NN_SRC_PAD);
+    MI_TRY(c->bx.reserve(n_pad)); MI_TRY(c->by.reserve(n_pad)); MI_TRY(c->bz.reserve(n_pad));
+    MI_TRY(upload_soa(c, cloud_xyz, n, n_pad, c->bx.p, c->by.p, c->bz.p, nullptr));
+    FgtClusters cl{};
+    MI_TRY(fgt_side(c, &w->fgt, &w->fgt.y, c->bx.p, c->by.p, c->bz.p, n, K, &cl));
+    const int g = std::min(n_guess, K);
+    if (g > 0) MI_HIP(hipMemcpyAsync(cl.picked, guess, sizeof(int) * (size_t)g, hipMemcpyHostToDevice, c->stream));
+    MI_HIP(hipMemsetAsync(cl.replay_state, 0xff, sizeof(int), c->stream));            // (-1: no replay ran)
+    MI_TRY(fgt_arm_replay(c, &w->fgt.y, &cl, g));
+    MI_HIP(fgt_cluster(cl, w->fgt.sort_temp.p, w->fgt.sort_temp.cap, c->stream));
+    MI_HIP(hipMemcpyAsync(cluster, cl.indx, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP(hipMemcpyAsync(centers_xyz, cl.xc, sizeof(float) * 3 * (size_t)K, hipMemcpyDeviceToHost, c->stream));
+    if (picked) MI_HIP(hipMemcpyAsync(picked, cl.picked, sizeof(int) * (size_t)K, hipMemcpyDeviceToHost, c->stream));
+    int state = -1;
+    MI_HIP(hipMemcpyAsync(&state, cl.replay_state, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    MI_HIP(hipStreamSynchronize(c->stream));
+    if (verified) *verified = state;
     return MI_OK;
 }
 

@@ -32,7 +32,17 @@ struct FgtClusters {
     int* off;                   // [K+1] cluster k owns memb[off[k] .. off[k+1])
     float* xc;                  // [K][3] cluster means
     void* sweep_scratch;        // FGT_SWEEP_SCRATCH_BYTES, used by the grid-wide sweep (may be null for small clouds)
+    int* picked;                // [K]   id of the point the sweep chose as centre k (written by every sweep)
+    // guess > 1 (and k_done == 0): picked[0 .. guess) holds a GUESS of the sweep's choices -- the previous E-step's, for a cloud that
+    // only underwent a similarity transform since -- to be replayed and checked in parallel instead of swept step by step
+    // (fgt_replay_kernel).  Needs the two buffers below; the result does not depend on the guess.
+    int guess;
+    unsigned long long* replay_partial;   // [fgt_replay_limit(guess, K)][fgt_replay_waves(n)]
+    int* replay_state;                    // [1]  -> the number of leading steps of the guess that were verified
 };
+constexpr int FGT_REPLAY_MAX_CENTRES = 4000;       // centres a replay stages in LDS (16 bytes each)
+int fgt_replay_waves(int n);
+int fgt_replay_limit(int guess, int K);
 
 size_t fgt_sort_temp_bytes(int n);     // scratch fgt_cluster needs for its member-list sort
 // K-centre clustering + member lists + cluster means; everything a model build needs

@@ -19,6 +19,7 @@
 // evaluation order only.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 
 #include "cpd_fgt.h"
@@ -78,11 +79,15 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k,
 // The sweep is prefix-stable (the first k centres do not depend on K), so a finished sweep can be RESUMED: with start > 0 the
 // kernel picks up the distances and labels steps 0..start-1 left in dist/indx and runs steps start..K-1 only.  The fixed cloud
 // of a CPD run is clustered this way: K grows as sigma^2 shrinks, and each new E-step only adds the missing centres.
+// `picked[k]` receives the id of centre k (the sweep's own record of what it chose: next E-step's guess, see fgt_replay_kernel);
+// start_ptr != null: the number of finished steps is read from the device (what a replay verified) instead of `start`.
 template <int PER>
 __global__ __launch_bounds__(1024) void fgt_kcenter_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                           const float* __restrict__ z, int n, int start, int K,
-                                                           float* __restrict__ dist, int* __restrict__ indx)
+                                                           const float* __restrict__ z, int n, int start, const int* __restrict__ start_ptr, int K,
+                                                           float* __restrict__ dist, int* __restrict__ indx, int* __restrict__ picked)
 {
+    if (start_ptr != nullptr) start = *start_ptr;
+    if (start >= K) return;                         // (a replay that covered every step: dist / indx are final)
     // per wave: its best key and that point's coordinates.  Double-buffered: a wave can run at most one barrier ahead of the slowest reader
     __shared__ unsigned long long s_key[2][16];
     __shared__ float4 s_xyz[2][16];
@@ -130,7 +135,8 @@ __global__ __launch_bounds__(1024) void fgt_kcenter_kernel(const float* __restri
             const int q = __builtin_ctzll(__builtin_amdgcn_ballot_w64(kq == kmax));      // (a lane of the first group of 16: q = its wave number)
             const float4 w = s_xyz[buf][q & 15];
             cx = w.x; cy = w.y; cz = w.z;
-        }
+            if (tid == 0) picked[step] = (int)(0xffffffffu - (unsigned int)kmax);
+        } else if (tid == 0) picked[0] = 1;
         best = {-1.f, 0x7fffffff, 0.f, 0.f, 0.f};
         if (PER > 0) {
 #pragma unroll
@@ -174,8 +180,9 @@ __global__ __launch_bounds__(1024) void fgt_kcenter_kernel(const float* __restri
 __global__ __launch_bounds__(256) void fgt_sweep_step_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                              const float* __restrict__ z, int n, const ArgMax* __restrict__ cur, int step,
                                                              int scan_only, float* __restrict__ dist, int* __restrict__ indx,
-                                                             ArgMax* __restrict__ partials)
+                                                             ArgMax* __restrict__ partials, int* __restrict__ picked)
 {
+    if (step == 0 && !scan_only && blockIdx.x == 0 && threadIdx.x == 0) picked[0] = 1;
     __shared__ ArgMax s_best[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float cx, cy, cz;
@@ -206,7 +213,8 @@ __global__ __launch_bounds__(256) void fgt_sweep_step_kernel(const float* __rest
     }
 }
 
-__global__ __launch_bounds__(256) void fgt_sweep_pick_kernel(const ArgMax* __restrict__ partials, int count, ArgMax* __restrict__ cur)
+__global__ __launch_bounds__(256) void fgt_sweep_pick_kernel(const ArgMax* __restrict__ partials, int count, ArgMax* __restrict__ cur,
+                                                             int* __restrict__ picked_slot)
 {
     __shared__ ArgMax s_best[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -222,7 +230,103 @@ __global__ __launch_bounds__(256) void fgt_sweep_pick_kernel(const ArgMax* __res
         ArgMax w = s_best[0];
         for (int q = 1; q < 4; q++) if (beats(s_best[q].v, s_best[q].i, w.v, w.i)) w = s_best[q];
         *cur = w;
+        *picked_slot = w.i;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The sweep REPLAYED.  The farthest-point sweep is a chain -- centre k is the arg-max of the distances centres 0..k-1 leave -- and
+// on one workgroup it costs ~1.2 us per step; but CPD clusters the moving cloud again every E-step, and between two E-steps that
+// cloud only undergoes a similarity transform: the sweep picks the same points in the same order unless rounding flips a near-tie.
+// So the previous E-step's picks are a GUESS, and a guess can be checked without a chain: with the centres known, every point's
+// running minimum over them is independent of every other point (one lane per point, the centres broadcast from LDS), and "the
+// arg-max before centre i is applied is the guessed point i" is one reduction per step.  replay<ARGMAX = true> does both in one
+// pass over the whole chip and posts each wave's arg-max per step; check reduces those over the waves and leaves in state[0] the
+// first step the guess fails at (or the guess's length).  If it failed, a second replay<false> restores distances and labels after
+// only the verified steps (it exits at once if all held); the chain kernel then resumes from state[0].  Distances, labels and
+// the tie rules are the chain's own arithmetic: the result is the chain's, bit for bit, whatever the guess was.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    // quads (xor 1, xor 2), halves of a row (row_half_mirror), rows of 16 (row_mirror): maxima are idempotent, mirrors do
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true)));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)),
+                r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// One wave per workgroup, P points per lane: id = (workgroup * P + r) * 64 + lane.  limit_ptr != null (the second pass): the number of
+// centres is read from the device, and the launch has nothing to do if it is skip_if_ge or more.
+template <int P, bool ARGMAX>
+__global__ __launch_bounds__(64) void fgt_replay_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
+                                                        const int* __restrict__ picked, int limit, const int* __restrict__ limit_ptr, int skip_if_ge,
+                                                        float* __restrict__ dist, int* __restrict__ indx, unsigned long long* __restrict__ partial,
+                                                        int* __restrict__ state)
+{
+    extern __shared__ float4 s_centre[];
+    int lim = limit;
+    if (limit_ptr != nullptr) { lim = *limit_ptr; if (lim >= skip_if_ge) return; }
+    const int lane = (int)threadIdx.x;
+    if (ARGMAX && blockIdx.x == 0 && lane == 0) state[0] = lim;          // no step disproved yet (the check kernel lowers it)
+    for (int i = lane; i < lim; i += 64) { const int j = picked[i]; s_centre[i] = make_float4(x[j], y[j], z[j], 0.f); }
+    __syncthreads();
+    float px[P], py[P], pz[P], pd[P];
+    int pc[P];
+#pragma unroll
+    for (int r = 0; r < P; r++) {
+        const int j = ((int)blockIdx.x * P + r) * 64 + lane, jc = min(j, n - 1);
+        px[r] = x[jc]; py[r] = y[jc]; pz[r] = z[jc];
+        pd[r] = j < n ? __builtin_inff() : -__builtin_inff(); pc[r] = 0;      // as in fgt_kcenter_kernel
+    }
+    const size_t W = gridDim.x;
+    for (int i = 0; i < lim; i++) {
+        if (ARGMAX && i > 0) {
+            // what the sweep picks as centre i: the FIRST maximum of the distances as centres 0..i-1 leave them (fgt.cpp:179)
+            float bv = pd[0];
+            int br = 0;
+#pragma unroll
+            for (int r = 1; r < P; r++) { const bool further = pd[r] > bv; bv = further ? pd[r] : bv; br = further ? r : br; }   // ascending ids per lane
+            const float wv = wave_max_f32(bv);
+            unsigned long long tied = __builtin_amdgcn_ballot_w64(bv == wv);
+            int first;
+            if (P == 1) first = (int)blockIdx.x * 64 + __builtin_ctzll(tied);          // ids ascend with the lane
+            else {
+                const int id = ((int)blockIdx.x * P + br) * 64 + lane;
+                first = 0x7fffffff;
+                while (tied != 0ull) { first = min(first, __builtin_amdgcn_readlane(id, __builtin_ctzll(tied))); tied &= tied - 1ull; }
+            }
+            if (lane == 0) partial[(size_t)i * W + blockIdx.x] = argmax_key(wv, first);
+        }
+        const float4 c = s_centre[i];
+#pragma unroll
+        for (int r = 0; r < P; r++) {
+            const float d = len2(px[r] - c.x, py[r] - c.y, pz[r] - c.z);
+            const bool closer = d < pd[r];                               // strict <: fgt.cpp:187
+            pc[r] = closer ? i : pc[r];
+            pd[r] = closer ? d : pd[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < P; r++) {
+        const int j = ((int)blockIdx.x * P + r) * 64 + lane;
+        if (j < n) { indx[j] = pc[r]; dist[j] = pd[r]; }
+    }
+}
+
+// one wave per step i in [1, lim): the maximum of the W keys posted for it names the point the sweep picks as centre i
+__global__ __launch_bounds__(256) void fgt_replay_check_kernel(const unsigned long long* __restrict__ partial, int W, const int* __restrict__ picked,
+                                                               int lim, int* __restrict__ state)
+{
+    const int lane = (int)threadIdx.x & 63, i = 1 + (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && picked[0] != 1) atomicMin(&state[0], 0);      // centre 0 is point 1 (fgt.cpp:162)
+    if (i >= lim) return;
+    unsigned long long k = 0ull;
+    for (int q = lane; q < W; q += 64) { const unsigned long long o = partial[(size_t)i * (size_t)W + q]; k = o > k ? o : k; }
+    k = wave_max_u64(k, 64);
+    if (lane == 0 && (k == 0ull || (int)(0xffffffffu - (unsigned int)k) != picked[i])) atomicMin(&state[0], i);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -544,25 +648,58 @@ __global__ __launch_bounds__(256) void fgt_post_px_kernel(const float* __restric
 constexpr size_t FGT_LIST_MAX_COUNTERS = (size_t)1 << 22;
 size_t fgt_sort_temp_bytes(int) { return sizeof(int) * (FGT_LIST_MAX_COUNTERS + 65536 + 16); }
 
+int fgt_replay_points_per_lane(int n) { return n <= 65536 ? 1 : (n <= 262144 ? 4 : 16); }
+int fgt_replay_waves(int n) { const int per = 64 * fgt_replay_points_per_lane(n); return (n + per - 1) / per; }
+int fgt_replay_limit(int guess, int K) { return guess < 2 ? 0 : std::min(std::min(guess, K), FGT_REPLAY_MAX_CENTRES); }
+
+template <bool ARGMAX>
+static void launch_replay(const FgtClusters& c, int lim, const int* limit_ptr, int skip_if_ge, hipStream_t s)
+{
+    const int P = fgt_replay_points_per_lane(c.n), W = fgt_replay_waves(c.n);
+    const size_t lds = sizeof(float4) * (size_t)lim;
+#define MI_REPLAY(PP) hipLaunchKernelGGL((fgt_replay_kernel<PP, ARGMAX>), dim3(W), dim3(64), lds, s, c.x, c.y, c.z, c.n, c.picked, lim, limit_ptr, skip_if_ge, \
+                                         c.dist, c.indx, c.replay_partial, c.replay_state)
+    if (P == 1) MI_REPLAY(1); else if (P == 4) MI_REPLAY(4); else MI_REPLAY(16);
+#undef MI_REPLAY
+}
+
 hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_bytes, hipStream_t s)
 {
-    const int start = c.k_done > 0 && c.k_done < c.K ? c.k_done : 0;
-    if (c.n > FGT_GRID_SWEEP_MIN_POINTS && c.sweep_scratch != nullptr) {
+    int start = c.k_done > 0 && c.k_done < c.K ? c.k_done : 0;
+    const int* start_ptr = nullptr;
+    const int lim = start == 0 && c.replay_partial != nullptr && c.replay_state != nullptr ? fgt_replay_limit(c.guess, c.K) : 0;
+    if (lim > 0) {
+        // the guess replayed and checked (fgt_replay_kernel); what it leaves: dist / indx after state[0] verified steps
+        launch_replay<true>(c, lim, nullptr, 0, s);
+        hipLaunchKernelGGL(fgt_replay_check_kernel, dim3(std::max(1, (lim - 1 + 3) / 4)), dim3(256), 0, s, c.replay_partial, fgt_replay_waves(c.n), c.picked, lim, c.replay_state);
+        launch_replay<false>(c, lim, c.replay_state, lim, s);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        start_ptr = c.replay_state;
+        if (c.n > FGT_GRID_SWEEP_MIN_POINTS) {                        // the grid-wide sweep is driven from the host: it needs the number
+            e = hipMemcpyAsync(&start, c.replay_state, sizeof(int), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return e;
+            start_ptr = nullptr;
+        }
+    }
+    if (start_ptr == nullptr && start >= c.K) { /* every step replayed and verified */ }
+    else if (c.n > FGT_GRID_SWEEP_MIN_POINTS && c.sweep_scratch != nullptr) {
         // large clouds: one grid-wide launch per step (update + per-workgroup arg-max) and a one-workgroup pick in between --
         // two launches per centre instead of one workgroup streaming the whole cloud K times
         ArgMax* cur = reinterpret_cast<ArgMax*>(c.sweep_scratch);
         ArgMax* partials = cur + 1;
         int G = (c.n + 256 * 8 - 1) / (256 * 8);
         if (G > FGT_GRID_SWEEP_BLOCKS) G = FGT_GRID_SWEEP_BLOCKS;
-        if (start > 0) hipLaunchKernelGGL(fgt_sweep_step_kernel, dim3(G), dim3(256), 0, s, c.x, c.y, c.z, c.n, cur, 0, 1, c.dist, c.indx, partials);
+        if (start > 0) hipLaunchKernelGGL(fgt_sweep_step_kernel, dim3(G), dim3(256), 0, s, c.x, c.y, c.z, c.n, cur, 0, 1, c.dist, c.indx, partials, c.picked);
         for (int step = start; step < c.K; step++) {
-            if (step > 0) hipLaunchKernelGGL(fgt_sweep_pick_kernel, dim3(1), dim3(256), 0, s, partials, G, cur);
-            hipLaunchKernelGGL(fgt_sweep_step_kernel, dim3(G), dim3(256), 0, s, c.x, c.y, c.z, c.n, cur, step, 0, c.dist, c.indx, partials);
+            if (step > 0) hipLaunchKernelGGL(fgt_sweep_pick_kernel, dim3(1), dim3(256), 0, s, partials, G, cur, c.picked + step);
+            hipLaunchKernelGGL(fgt_sweep_step_kernel, dim3(G), dim3(256), 0, s, c.x, c.y, c.z, c.n, cur, step, 0, c.dist, c.indx, partials, c.picked);
         }
     }
-    else if (c.n <= 4 * 1024) hipLaunchKernelGGL(fgt_kcenter_kernel<4>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, c.K, c.dist, c.indx);
-    else if (c.n <= 16 * 1024) hipLaunchKernelGGL(fgt_kcenter_kernel<16>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, c.K, c.dist, c.indx);
-    else hipLaunchKernelGGL(fgt_kcenter_kernel<0>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, c.K, c.dist, c.indx);
+    else if (c.n <= 4 * 1024) hipLaunchKernelGGL(fgt_kcenter_kernel<4>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, start_ptr, c.K, c.dist, c.indx, c.picked);
+    else if (c.n <= 16 * 1024) hipLaunchKernelGGL(fgt_kcenter_kernel<16>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, start_ptr, c.K, c.dist, c.indx, c.picked);
+    else hipLaunchKernelGGL(fgt_kcenter_kernel<0>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, start_ptr, c.K, c.dist, c.indx, c.picked);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // member lists (stable counting sort on the labels, see fgt_lists_pass_kernel)

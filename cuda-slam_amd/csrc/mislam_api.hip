@@ -229,6 +229,7 @@ static int ctx_create_common(int device, mi_ctx** out)
         c->tune.nn_chunks = env_i("MISLAM_NN_CHUNKS", 0);
         c->tune.cpd_mfma = env_i("MISLAM_CPD_MFMA", 1);
         c->tune.fgt_resume = env_i("MISLAM_FGT_RESUME", 1);
+        c->tune.fgt_replay = env_i("MISLAM_FGT_REPLAY", 1);
         if (const char* ppc = getenv("MISLAM_GRID_PPC")) { const float f = (float)atof(ppc); if (f >= 0.25f && f <= 64.f) c->tune.grid_points_per_cell = f; }
         if (env_i("MISLAM_PRELOAD", 0) == 1) MI_TRY(mi_ctx_preload(c));       // =1: mi_ctx_preload as part of every context creation
         // pinned upload staging: a ring of 16 pieces of 1 MB, pinned here, once per context (pinning costs ~0.25 ms per MB on this

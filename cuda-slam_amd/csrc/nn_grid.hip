@@ -783,6 +783,9 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
 // any subset of a wave), the others wait masked off.
 // waves per SIMD the register allocation must leave room for: a launch lasts as long as its waves hold their slots (the walking
 // waves hold a third of them for most of it), so slots count for more than registers here
+#ifndef MISLAM_GRID_XCD_RUN
+#define MISLAM_GRID_XCD_RUN (TREE_XCD_CHUNKS * (256 / GRID_BLOCK))
+#endif
 #ifndef MISLAM_GRID_MIN_WAVES
 #define MISLAM_GRID_MIN_WAVES 7
 #endif
@@ -802,7 +805,7 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
 #else
 #define MI_TL_STAMP(var, dep) do { } while (0)
 #endif
-    unsigned int chunk = xcd_chunk(blockIdx.x, gridDim.x, TREE_XCD_CHUNKS * (256 / GRID_BLOCK));
+    unsigned int chunk = xcd_chunk(blockIdx.x, gridDim.x, MISLAM_GRID_XCD_RUN);
     if (FUSED) chunk = (unsigned int)a.order[chunk];          // walking chunks first (IcpSchedule): speed only
     const int i = (int)(chunk * GRID_BLOCK) + tid;
     const bool valid = i < a.n;
@@ -906,7 +909,8 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
             tl[8] = tl_p1; tl[9] = tl_p2; tl[10] = tl_p3;
             tl[0] = tl_start; tl[1] = tl_scan; tl[2] = wall_clock64();
             tl[3] = (unsigned long long)(v0 + v1) | (nh << 16) | ((unsigned long long)(walk_only ? 1 : 0) << 32) | ((unsigned long long)chunk << 40);
-            tl[4] = dev_tl[0]; tl[5] = dev_tl[1]; tl[6] = dev_tl[2]; tl[7] = 0;
+            tl[4] = dev_tl[0]; tl[5] = dev_tl[1]; tl[6] = dev_tl[2];
+            tl[7] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);   // HW_ID, XCC_ID
         }
 #endif
         if (tid == 0) {                                         // one set of atomics per wave

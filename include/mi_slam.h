@@ -321,6 +321,14 @@ int mi_cpd_estep_fgt(mi_ctx* ctx, const float* y_xyz, int m, const float* x_xyz,
  * cell means.  Labels are bit-identical to the reference's (same arithmetic, same tie rules).  n >= 2, 1 <= K <= 65535. */
 int mi_fgt_kcenter(mi_ctx* ctx, const float* cloud_xyz, int n, int K, float* centers_xyz, int* cluster);
 
+/* The same clustering with a GUESS of the sweep's choices: guess[0 .. n_guess) = the points expected as centres 0, 1, ... (what an
+ * earlier sweep of the same cloud under another similarity transform chose -- how rigid CPD's E-steps cluster the moving cloud: the
+ * guess is replayed and checked for all points in parallel, and only what it does not cover, or gets wrong, is swept step by step).
+ * The result is mi_fgt_kcenter's, bit for bit, whatever the guess.  picked[K] (may be NULL) receives the sweep's choices, *verified
+ * (may be NULL) the number of leading entries of the guess that were the sweep's own (-1: no replay ran, n_guess < 2). */
+int mi_fgt_kcenter_guided(mi_ctx* ctx, const float* cloud_xyz, int n, int K, const int* guess, int n_guess, float* centers_xyz,
+                          int* cluster, int* picked, int* verified);
+
 /* Host-only (no device needed): the monomial tables of truncation order p the FGT kernels use, pd = C(p+2,3) entries each in
  * the reference's graded monomial order (fgt.cpp:124-137): exponents packed a | b<<8 | c<<16, the constants 2^|alpha|/alpha!
  * of ComputeC_k (fgt.cpp:214-244), and each monomial's slot in the Horner traversal.  Any output may be NULL. */

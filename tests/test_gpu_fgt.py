@@ -56,6 +56,96 @@ def test_kcenter_ties_and_duplicates(ctx, oracle):
     assert np.array_equal(np.nan_to_num(xc, nan=7.0), np.nan_to_num(xc_o, nan=7.0))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the sweep replayed from a guess (round 4): whatever the guess, the result is the step-by-step sweep's -- bit for bit
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed,n,K", [(2, 300, 50), (3, 4096, 117), (5, 14904, 150), (7, 16385, 33), (8, 50000, 70), (11, 65537, 37),
+                                      (12, 300000, 51)])
+def test_guided_kcenter_is_the_sweep_whatever_the_guess(ctx, oracle, seed, n, K):
+    c = cloud(seed, n)
+    xc_o, lab_o = oracle.fgt_kcenter(c, K)
+    xc0, lab0, picked0, v0 = ctx.fgt_kcenter_guided(c, K, np.zeros(0, np.int32))          # no guess: the plain sweep, and its choices
+    assert v0 == -1 and np.array_equal(lab0, lab_o) and np.array_equal(xc0, xc_o)
+    assert picked0[0] == 1 and len(set(picked0.tolist())) == K and np.array_equal(lab0[picked0], np.arange(K))   # centre k is a point of cell k
+    rng = np.random.default_rng(seed)
+    wrong_at = int(rng.integers(1, K - 1))
+    bad = picked0.copy()
+    bad[wrong_at] = (bad[wrong_at] + 1) % n
+    shifted = picked0.copy()
+    shifted[0] = 0                                                                        # centre 0 is point 1, always
+    cases = [(picked0, K),                                                                # the whole sweep guessed right
+             (picked0[: K // 2], K // 2),                                                 # half of it: the rest is swept
+             (np.concatenate([picked0, picked0]), K),                                     # longer than K: the surplus is ignored
+             (bad, wrong_at),                                                             # right up to wrong_at, then anything
+             (shifted, 0),
+             (rng.integers(0, n, K).astype(np.int32), None)]                              # noise
+    for guess, want_verified in cases:
+        xc, lab, picked, verified = ctx.fgt_kcenter_guided(c, K, guess)
+        assert np.array_equal(lab, lab_o) and np.array_equal(xc, xc_o) and np.array_equal(picked, picked0)
+        if len(guess) < 2:
+            assert verified == -1
+        elif want_verified is not None:
+            assert verified == want_verified, (verified, want_verified)
+        else:
+            assert 0 <= verified <= K
+
+
+def test_guided_kcenter_on_ties_and_under_similarity_transforms(ctx, oracle):
+    # a lattice with duplicates: equal distances everywhere, the FIRST maximum must win in the replay as in the sweep
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    c = np.concatenate([g, g])[np.random.default_rng(0).permutation(1024)]
+    for K in (9, 64, 200):
+        xc_o, lab_o = oracle.fgt_kcenter(c, K)
+        _, _, picked0, _ = ctx.fgt_kcenter_guided(c, K, np.zeros(0, np.int32))
+        xc, lab, picked, verified = ctx.fgt_kcenter_guided(c, K, picked0)
+        assert verified == K and np.array_equal(lab, lab_o) and np.array_equal(xc, xc_o) and np.array_equal(picked, picked0)
+    # the use CPD makes of it: the same cloud rotated, scaled and shifted, guessed from the untransformed cloud's sweep.  On a lattice the
+    # ties break differently once rounding enters (the guess fails early), on a scan-like cloud they hardly ever do -- either way the
+    # labels are the oracle's for the TRANSFORMED cloud
+    ang = 0.3
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+    for base, K in ((c, 64), (cloud(21, 9000), 120)):
+        _, _, picked0, _ = ctx.fgt_kcenter_guided(base, K, np.zeros(0, np.int32))
+        moved = (np.float32(1.1) * (base @ R.T) + np.array([0.4, -0.2, 0.1], np.float32)).astype(np.float32)
+        xc_o, lab_o = oracle.fgt_kcenter(moved, K)
+        xc, lab, picked, verified = ctx.fgt_kcenter_guided(moved, K, picked0)
+        assert np.array_equal(lab, lab_o) and np.array_equal(np.nan_to_num(xc, nan=7.0), np.nan_to_num(xc_o, nan=7.0))
+        assert 0 <= verified <= K
+        first_diff = next((i for i in range(K) if picked[i] != picked0[i]), K)
+        assert verified == first_diff                                                     # exactly the steps the two sweeps share
+
+
+def test_guided_kcenter_rejects_bad_guesses(ctx, capi):
+    c = cloud(0, 100)
+    with pytest.raises(capi.MiSlamError):
+        ctx.fgt_kcenter_guided(c, 10, np.array([1, 100], np.int32))                       # not a point of the cloud
+    with pytest.raises(capi.MiSlamError):
+        ctx.fgt_kcenter_guided(c, 10, np.array([1, -1], np.int32))
+
+
+def test_replayed_clustering_changes_nothing(ctx, capi, golden, bunny, monkeypatch):
+    # every E-step but the first replays the moving cloud's previous sweep instead of sweeping step by step; switched off
+    # (MISLAM_FGT_REPLAY=0, read at context creation) the runs must give the same bits
+    monkeypatch.setenv("MISLAM_FGT_REPLAY", "0")
+    with capi.Context(0) as plain:
+        before, after = bunny
+        g = golden.json("bunny_fgt.json")
+        for approx, cap in ((capi.CPD_APPROX_HYBRID, 50), (capi.CPD_APPROX_FULL, 24)):
+            p = capi.cpd_params(max_iterations=cap, sigma2_init=g["sigma2_init"], approximation=approx)
+            a = ctx.cpd_register(before, after, p)
+            b = plain.cpd_register(before, after, p)
+            assert a[3] == b[3] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[4] == b[4]
+        # a lattice against its rotated copy: guesses that fail early, every E-step
+        lat = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(12), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+        ang = 0.2
+        R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+        moved = (lat @ R.T + np.float32(0.3)).astype(np.float32)
+        p = capi.cpd_params(max_iterations=12, tolerance=0.0, approximation=capi.CPD_APPROX_FULL)
+        a = ctx.cpd_register(lat, moved, p)
+        b = plain.cpd_register(lat, moved, p)
+        assert a[3] == b[3] == 12 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[4] == b[4]
+
+
 def test_bunny_kcenter_golden(ctx, golden, bunny):
     _, after = bunny
     e = golden.npz("bunny_fgt_estep.npz")

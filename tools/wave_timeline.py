@@ -56,6 +56,24 @@ with capi.Context(0) as ctx:
             per_step = (end - scan)[w] / np.maximum(steps[w], 1)
             print("  walk: steps mean %.1f p99 %d max %d; us per step mean %.2f (p10 %.2f p90 %.2f); far lanes per walking wave mean %.1f"
                   % (steps[w].mean(), np.percentile(steps[w], 99), steps[w].max(), per_step.mean(), np.percentile(per_step, 10), np.percentile(per_step, 90), far_lanes[w].mean()))
+        # where the waves ran: XCD (XCC_ID), and the slot (SE, CU, SIMD, wave) inside it -- per XCD the end of its last wave, and per slot the
+        # gaps between one wave's end and the next one's start
+        hw, xcc = tl[:, 7] & 0xffffffff, (tl[:, 7] >> 32) & 0xf
+        slot = (xcc << 32) | (hw & 0xffff)
+        print("  per XCD: waves / walkers / last start / last end: " + "  ".join("%d: %d/%d/%.0f/%.0f" % (x, (xcc == x).sum(), (walked & (xcc == x)).sum(), start[xcc == x].max(), end[xcc == x].max()) for x in sorted(set(xcc.tolist()))))
+        b = np.arange(len(tl))
+        print("  XCC_ID of workgroup b is a function of b %% 8: %s; walkers by b %% 8: %s; walkers among the first / second / later thirds of the launch order: %d / %d / %d"
+              % (all(len(set(xcc[b % 8 == k].tolist())) == 1 for k in range(8)), [int((walked & (b % 8 == k)).sum()) for k in range(8)],
+                 walked[: len(tl) // 3].sum(), walked[len(tl) // 3: 2 * len(tl) // 3].sum(), walked[2 * len(tl) // 3:].sum()))
+        wpos = np.where(walked)[0]
+        print("  launch position of the walkers: p50 %d p90 %d p99 %d max %d; steps by XCD: %s" % (np.percentile(wpos, 50), np.percentile(wpos, 90), np.percentile(wpos, 99), wpos.max(),
+              [int(steps[walked & (xcc == x)].sum()) for x in sorted(set(xcc.tolist()))]))
+        order = np.lexsort((start, slot))
+        same = slot[order][1:] == slot[order][:-1]
+        gaps = (start[order][1:] - end[order][:-1])[same]
+        print("  slots used %d; waves per slot mean %.1f; gap between a slot's waves: mean %.2f us p50 %.2f p90 %.2f p99 %.2f (negative: HW_ID wave ids reused) ; sum of gaps / (slots x span) = %.3f"
+              % (len(set(slot.tolist())), len(tl) / max(len(set(slot.tolist())), 1), gaps.mean(), np.percentile(gaps, 50), np.percentile(gaps, 90), np.percentile(gaps, 99),
+                 gaps[gaps > 0].sum() / (len(set(slot.tolist())) * span)))
         # waves resident over time (10 us bins)
         edges = np.arange(0, span + 10, 10)
         res = [(int(((start <= t) & (end > t)).sum()), int(((start <= t) & (end > t) & walked).sum())) for t in edges]
