@@ -339,44 +339,75 @@ __global__ __launch_bounds__(256) void fgt_replay_check_kernel(const unsigned lo
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int FGT_LIST_LDS_LABELS = 8192;   // up to this many labels a chunk's cursors live in LDS (32 KB per wave)
 
-template <bool SCATTER>
-__global__ __launch_bounds__(64) void fgt_lists_pass_kernel(const int* __restrict__ indx, int n, int K, int chunk, int* __restrict__ H,
-                                                            const int* __restrict__ off, int* __restrict__ memb)
+// lanes of the wave that hold the same label as this one (valid lanes only): one ballot per label BIT instead of one round per
+// distinct label -- a chunk's 64 labels are mostly distinct, and the rounds were 64 dependent readlane / ballot / atomic steps
+__device__ __forceinline__ unsigned long long same_label_lanes(int lab, bool valid, int label_bits)
 {
-    extern __shared__ int cur[];                                 // SCATTER with K <= FGT_LIST_LDS_LABELS: this chunk's cursor per label
+    unsigned long long same = __builtin_amdgcn_ballot_w64(valid);
+    for (int b = 0; b < label_bits; b++) {
+        const bool bit = ((lab >> b) & 1) != 0;
+        const unsigned long long with = __builtin_amdgcn_ballot_w64(bit);
+        same &= bit ? with : ~with;
+    }
+    return same;
+}
+
+// SCATTER == false: H[g][k] = how many points of chunk g carry label k.  SCATTER == true: H[g][k] holds the number of label-k points in the
+// chunks before g (fgt_lists_columns_kernel); every point goes to memb[off[k] + that + its rank among the chunk's label-k points].
+// K <= FGT_LIST_LDS_LABELS: the chunk's row lives in LDS (count: zeroed there and written out whole, no memset, no global atomics).
+// SCAN_OFF (K <= FGT_LIST_SCAN_LABELS): off[] is not read but computed here, from tot[] (an exclusive prefix sum per wave, K / 64 steps)
+// into LDS -- workgroup 0 also writes it out for the kernels that follow; saves the one-workgroup offsets launch in between.
+constexpr int FGT_LIST_SCAN_LABELS = 1024;
+template <bool SCATTER, bool SCAN_OFF>
+__global__ __launch_bounds__(64) void fgt_lists_pass_kernel(const int* __restrict__ indx, int n, int K, int chunk, int label_bits, int* __restrict__ H,
+                                                            const int* __restrict__ tot, int* __restrict__ off, int* __restrict__ memb)
+{
+    extern __shared__ int cur[];                                 // K <= FGT_LIST_LDS_LABELS: this chunk's counter / cursor per label [+ K + 1 offsets]
     const int lane = threadIdx.x;
     const int lo = blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
     int* __restrict__ row = H + (size_t)blockIdx.x * K;
-    const bool lds = SCATTER && K <= FGT_LIST_LDS_LABELS;
+    const bool lds = K <= FGT_LIST_LDS_LABELS;
+    int* s_off = cur + K;
     if (lds)
-        for (int k = lane; k < K; k += 64) cur[k] = row[k];       // one wave: LDS operations of a wave complete in order
+        for (int k = lane; k < K; k += 64) cur[k] = SCATTER ? row[k] : 0;      // one wave: LDS operations of a wave complete in order
+    if (SCATTER && SCAN_OFF) {
+        int carry = 0;
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const int k = k0 + lane;
+            const int c = k < K ? tot[k] : 0;
+            int incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (k < K) { s_off[k] = carry + incl - c; if (blockIdx.x == 0) off[k] = carry + incl - c; }
+            carry += __shfl(incl, 63, 64);
+        }
+        if (blockIdx.x == 0 && lane == 0) off[K] = carry;
+    }
     for (int i0 = lo; i0 < hi; i0 += 64) {
         const int i = i0 + lane;
         const bool valid = i < hi;
         const int lab = valid ? indx[i] : -1;
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
-        while (todo != 0ull) {
-            const int leader = __builtin_ctzll(todo);
-            const int first = __builtin_amdgcn_readlane(lab, leader);
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(valid && lab == first);
-            todo &= ~m;
-            const int cnt = (int)__builtin_popcountll(m);
-            if (!SCATTER) {
-                if (lane == leader) atomicAdd(&row[first], cnt);  // result unused: fire and forget
-            } else {
-                int before = 0;
-                if (lane == leader) {
-                    if (lds) { before = cur[first]; cur[first] = before + cnt; }
-                    else before = atomicAdd(&row[first], cnt);    // very many labels: the wave's own cursor in memory (uncontended, L2-coherent)
-                }
-                before = __builtin_amdgcn_readlane(before, leader);
-                if (valid && lab == first) {
-                    const int rank = (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-                    memb[off[first] + before + rank] = i;
-                }
+        const unsigned long long same = same_label_lanes(lab, valid, label_bits);
+        const int cnt = (int)__builtin_popcountll(same);
+        const int rank = (int)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+        const bool leader = valid && rank == 0;                  // (the leaders of a step hold distinct labels)
+        if (!SCATTER) {
+            if (leader) { if (lds) cur[lab] += cnt; else atomicAdd(&row[lab], cnt); }
+        } else {
+            int before = 0;
+            if (leader) {
+                if (lds) { before = cur[lab]; cur[lab] = before + cnt; }
+                else before = atomicAdd(&row[lab], cnt);         // very many labels: the wave's own cursor in memory (uncontended, L2-coherent)
             }
+            before = __shfl(before, valid ? __builtin_ctzll(same) : lane, 64);
+            if (valid) memb[(SCAN_OFF ? s_off[lab] : off[lab]) + before + rank] = i;
         }
     }
+    if (!SCATTER && lds)
+        for (int k = lane; k < K; k += 64) row[k] = cur[k];
 }
 
 // per label: H[g][k] <- sum of the counts of the chunks before g; tot[k] <- the label's total.  One wave per label, 64 chunks per
@@ -708,13 +739,21 @@ hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_b
     if (sort_temp_bytes < sizeof(int) * ((size_t)G * c.K + c.K + 1)) return hipErrorInvalidValue;
     int* H = reinterpret_cast<int*>(sort_temp);
     int* tot = H + (size_t)G * c.K;
-    e = hipMemsetAsync(H, 0, sizeof(int) * (size_t)G * c.K, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fgt_lists_pass_kernel<false>, dim3(G), dim3(64), 0, s, c.indx, c.n, c.K, chunk, H, nullptr, nullptr);
+    int label_bits = 1;
+    while ((1 << label_bits) < c.K) label_bits++;
+    const bool lds = c.K <= FGT_LIST_LDS_LABELS, scan_off = c.K <= FGT_LIST_SCAN_LABELS;
+    if (!lds) {
+        e = hipMemsetAsync(H, 0, sizeof(int) * (size_t)G * c.K, s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((fgt_lists_pass_kernel<false, false>), dim3(G), dim3(64), lds ? sizeof(int) * (size_t)c.K : 0, s, c.indx, c.n, c.K, chunk, label_bits, H, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(fgt_lists_columns_kernel, dim3((c.K + 3) / 4), dim3(256), 0, s, H, G, c.K, tot);
-    hipLaunchKernelGGL(fgt_lists_offsets_kernel, dim3(1), dim3(1024), 0, s, tot, c.K, c.off);
-    const size_t cursors_lds = c.K <= FGT_LIST_LDS_LABELS ? sizeof(int) * (size_t)c.K : 0;
-    hipLaunchKernelGGL(fgt_lists_pass_kernel<true>, dim3(G), dim3(64), cursors_lds, s, c.indx, c.n, c.K, chunk, H, c.off, c.memb);
+    if (scan_off)
+        hipLaunchKernelGGL((fgt_lists_pass_kernel<true, true>), dim3(G), dim3(64), sizeof(int) * (2 * (size_t)c.K + 1), s, c.indx, c.n, c.K, chunk, label_bits, H, tot, c.off, c.memb);
+    else {
+        hipLaunchKernelGGL(fgt_lists_offsets_kernel, dim3(1), dim3(1024), 0, s, tot, c.K, c.off);
+        hipLaunchKernelGGL((fgt_lists_pass_kernel<true, false>), dim3(G), dim3(64), lds ? sizeof(int) * (size_t)c.K : 0, s, c.indx, c.n, c.K, chunk, label_bits, H, tot, c.off, c.memb);
+    }
     hipLaunchKernelGGL(fgt_centers_kernel, dim3(c.K), dim3(FGT_TILE), 0, s, c.x, c.y, c.z, c.memb, c.off, c.K, c.xc);
     return hipGetLastError();
 }

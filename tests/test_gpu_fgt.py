@@ -30,7 +30,7 @@ def rel(a, b):
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("seed,n,K", [(0, 2, 1), (1, 2, 2), (2, 300, 50), (3, 4096, 117), (4, 4097, 64), (5, 14904, 117),
                                       (6, 16384, 51), (7, 16385, 33), (8, 50000, 70), (9, 1000, 1000), (10, 65536, 20), (11, 65537, 37),
-                                      (12, 300000, 51)])
+                                      (12, 300000, 51), (13, 5000, 3000), (14, 20000, 9000)])     # (the last two: member lists beyond 1 024 / 8 192 cells)
 def test_kcenter_matches_oracle_bit_for_bit(ctx, oracle, seed, n, K):
     c = cloud(seed, n)
     xc_o, lab_o = oracle.fgt_kcenter(c, K)
