@@ -112,6 +112,7 @@ struct mi_ctx {
         float grid_points_per_cell = mislam::GRID_POINTS_PER_CELL;   // MISLAM_GRID_PPC
         int cpd_mfma = 1;                                // MISLAM_CPD_MFMA=0: VALU contraction instead of MFMA
         int fgt_resume = 1;                              // MISLAM_FGT_RESUME=0: re-cluster the fixed cloud from scratch every E-step
+        int grid_deal_rows = -1;                         // MISLAM_GRID_DEAL_ROWS=0 / 1: K1g's leftover rows never / always dealt out one per lane (default: by size)
         int fgt_replay = 1;                              // MISLAM_FGT_REPLAY=0: sweep the moving cloud step by step every E-step (no guess replayed)
     } tune;
 

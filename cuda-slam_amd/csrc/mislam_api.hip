@@ -230,6 +230,7 @@ static int ctx_create_common(int device, mi_ctx** out)
         c->tune.cpd_mfma = env_i("MISLAM_CPD_MFMA", 1);
         c->tune.fgt_resume = env_i("MISLAM_FGT_RESUME", 1);
         c->tune.fgt_replay = env_i("MISLAM_FGT_REPLAY", 1);
+        c->tune.grid_deal_rows = env_i("MISLAM_GRID_DEAL_ROWS", -1);
         if (const char* ppc = getenv("MISLAM_GRID_PPC")) { const float f = (float)atof(ppc); if (f >= 0.25f && f <= 64.f) c->tune.grid_points_per_cell = f; }
         if (env_i("MISLAM_PRELOAD", 0) == 1) MI_TRY(mi_ctx_preload(c));       // =1: mi_ctx_preload as part of every context creation
         // pinned upload staging: a ring of 16 pieces of 1 MB, pinned here, once per context (pinning costs ~0.25 ms per MB on this
@@ -798,6 +799,7 @@ int launch_nn(mi_ctx* c, const float* sx, const float* sy, const float* sz, int 
             GridSearchArgs a{};
             a.sx = sx; a.sy = sy; a.sz = sz; a.done_flag = done_flag; a.n = n; a.keys = c->keys.p;
             a.stats = c->nn_stats_on ? c->nn_stats.p : nullptr;
+            a.deal_rows = c->tune.grid_deal_rows < 0 ? (n >= GRID_DEAL_ROWS_MIN_POINTS ? 1 : 0) : c->tune.grid_deal_rows;
             MI_HIP(nn_grid_query(c->grid, c->tree, a, fma, c->stream));
         } else {
             MI_HIP(nn_tree_query(c->tree, sx, sy, sz, n, c->keys.p, done_flag, fma, c->stream));
@@ -1149,6 +1151,7 @@ static int icp_enqueue_iteration(mi_ctx* c)
         a.filter_pairs = c->icp.filter_pairs; a.max_distance_squared = c->icp.max_distance_squared;
         a.rows = c->rows.p;
         a.order = c->sched_order.p; a.far = c->sched_far.p;
+        a.deal_rows = c->tune.grid_deal_rows < 0 ? (c->n >= GRID_DEAL_ROWS_MIN_POINTS ? 1 : 0) : c->tune.grid_deal_rows;
         hipEvent_t e0 = nullptr, e1 = nullptr;           // timed, if at all, by events attached to the launch itself (nn_grid_query)
         MI_TRY(c->prof_span(MI_KERNEL_NN, &e0, &e1));
         MI_HIP(nn_grid_query(c->grid, c->tree, a, v.fma, c->stream, e0, e1));

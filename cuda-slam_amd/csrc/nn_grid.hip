@@ -556,6 +556,10 @@ __device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, uns
 // prefix sums, the row as the n-th set bit of the record's mask, and tests it for its OWNER: the owner's query, radius, cell range
 // and own row come from LDS, the result goes back through an LDS minimum, exactly as for dealt trips.  Every row is tested with the
 // radius the owner had when the rows were dealt (grid_batch re-reads it between batches): a superset, never a miss.
+// Fewer instructions, more dependent steps (two barriers, a binary search over LDS): +2 % iterations/s at 1e6 points, +5 % at 3e6, where
+// the launch is several times what the chip holds and instruction issue is what it waits for -- and -6 % at 7e5, -12 % at 1e5 and 1e4,
+// where (nearly) every wave is resident from the start and the launch lasts as long as ONE wave's chain of dependent steps
+// (profiles/r04_search_experiments.log).  Hence GridSearchArgs::deal_rows: by size, GRID_DEAL_ROWS_MIN_POINTS.
 #ifndef MISLAM_GRID_ROWS_DEALT
 #define MISLAM_GRID_ROWS_DEALT 1
 #endif
@@ -688,7 +692,7 @@ __device__ __forceinline__ void grid_rows_dealt(const NnGridView& g, GridLane& s
 // `reach_word` = row_occ of the query's cell: 0 says no cell the scan could visit holds a point, a clear bit that its row holds none.  `lane_on`: the lane has a point.
 template <bool FMA, bool STATS>
 __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3], bool lane_on, unsigned int reach_word, float& best, unsigned int& bidx,
-                                            unsigned int& bslot, unsigned int& n_cand, unsigned int& n_rows
+                                            unsigned int& bslot, unsigned int& n_cand, unsigned int& n_rows, bool deal_rows
 #ifdef MISLAM_DEV_WAVE_TIMELINE
                                             , unsigned long long (&dev_tl)[3]
 #endif
@@ -751,7 +755,7 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
     // first dealt the ROWS out, one per lane, before there was a way to deal trips: git show eefc579:cuda-slam_amd/csrc/nn_grid.hip; with the
     // trips dealt the two are as fast, at 1e5, 1e6 and 1e7 points, and this is the shorter code.)
 #if MISLAM_GRID_ROWS_DEALT
-    if (__builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) {
+    if (deal_rows && __builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) {
         const int x0 = (int)fmaxf(fx0, 0.f), x1 = (int)fminf(fx1, (float)(g.nx - 1));
         grid_rows_dealt<FMA, STATS>(g, s, mask, x0, x1, r2);
         mask = 0u;
@@ -869,9 +873,9 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
     const bool walk_only = FUSED && (unsigned int)__builtin_amdgcn_readfirstlane((int)far_class) >= 2u;
     if (walk_only) hard = valid;
 #ifdef MISLAM_DEV_WAVE_TIMELINE
-    else hard = grid_search<FMA, STATS>(g, q, valid, near_word, best, bidx, bslot, n_cand, n_rows, dev_tl) && valid;
+    else hard = grid_search<FMA, STATS>(g, q, valid, near_word, best, bidx, bslot, n_cand, n_rows, a.deal_rows != 0, dev_tl) && valid;
 #else
-    else hard = grid_search<FMA, STATS>(g, q, valid, near_word, best, bidx, bslot, n_cand, n_rows) && valid;   // (all lanes: the loops run in step)
+    else hard = grid_search<FMA, STATS>(g, q, valid, near_word, best, bidx, bslot, n_cand, n_rows, a.deal_rows != 0) && valid;   // (all lanes: the loops run in step)
 #endif
     const bool walked = __builtin_amdgcn_ballot_w64(hard) != 0ull;
     // the first iterations of a registration move the cloud by many cells: the starting candidates (previous matches) are STALE, and a walk

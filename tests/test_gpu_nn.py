@@ -90,11 +90,13 @@ def test_tree_equals_bruteforce_on_clustered_and_degenerate_clouds(ctx, capi, mo
 
 @pytest.mark.parametrize("ppc", ["0.25", "1", "2", "3", "8", "16", "64"])   # 2-3: around the most trips one deal takes; 16: lanes with 32 trips (lockstep)
 @pytest.mark.parametrize("mode", [0, 1])
-def test_grid_is_exact_at_every_cell_size(capi, oracle, monkeypatch, ppc, mode):
+@pytest.mark.parametrize("deal", ["0", "1"])                                  # leftover rows in batches of four per lane / dealt out one per lane
+def test_grid_is_exact_at_every_cell_size(capi, oracle, monkeypatch, ppc, mode, deal):
     # the grid's cell size is a speed knob (MISLAM_GRID_PPC = mean points per cell, read at context creation): from cells far
     # smaller than the point spacing (most rows empty, radii of many cells -> hierarchy fallback for the far queries) to cells so
     # crowded that the candidate budget sends lanes to the hierarchy mid-scan -- the answer must not change by a bit
     monkeypatch.setenv("MISLAM_GRID_PPC", ppc)
+    monkeypatch.setenv("MISLAM_GRID_DEAL_ROWS", deal)
     rng = np.random.default_rng(31)
     base = rng.uniform(-5, 5, (6000, 3)).astype(np.float32)
     tgt = np.concatenate([base, base[:2000]])                       # duplicates: ties
@@ -104,6 +106,24 @@ def test_grid_is_exact_at_every_cell_size(capi, oracle, monkeypatch, ppc, mode):
     with capi.Context(0) as c2:
         idx, d2 = c2.nn_search(src, tgt, mode, capi.NN_GRID)
     assert np.array_equal(idx, ridx) and np.array_equal(d2.view(np.uint32), rd2.view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [30000, 1000000])
+def test_leftover_rows_dealt_or_in_batches_same_bits(capi, monkeypatch, n):
+    # K1g takes a wave's leftover cell rows four per lane and batch below 900 000 moving points and deals them out one per lane above
+    # (MISLAM_GRID_DEAL_ROWS=0 / 1 forces either, read at context creation): the plain search and a fused ICP run must not change by a bit
+    from conftest import synth_cloud
+    before, after = synth_cloud(n, seed=5)[:2]
+    out = []
+    for deal in ("0", "1"):
+        monkeypatch.setenv("MISLAM_GRID_DEAL_ROWS", deal)
+        with capi.Context(0) as c2:
+            idx, d2 = c2.nn_search(before, after, 0, capi.NN_GRID)
+            reg = c2.icp_register(before, after, capi.icp_params(eps=0.0, max_iterations=6))
+            out.append((idx, d2.view(np.uint32), reg))
+    (i0, d0, r0), (i1, d1, r1) = out
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    assert r0[2] == r1[2] == 6 and np.array_equal(r0[0], r1[0]) and np.array_equal(r0[1], r1[1]) and r0[3] == r1[3]
 
 
 @pytest.mark.parametrize("mode", [0, 1])

@@ -12,8 +12,20 @@ from nn_soak import cloud  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["auto", "dealt"])
+def soak_ctx(request, ctx, capi, monkeypatch):
+    # "dealt": K1g's leftover rows dealt out one per lane at every size (the default does so from 900 000 moving points on)
+    if request.param == "auto":
+        yield ctx
+        return
+    monkeypatch.setenv("MISLAM_GRID_DEAL_ROWS", "1")
+    with capi.Context(0) as c2:
+        yield c2
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
-def test_tree_equals_every_pair_on_random_problems(ctx, capi, seed):
+def test_tree_equals_every_pair_on_random_problems(soak_ctx, capi, seed):
+    ctx = soak_ctx
     rng = np.random.default_rng(seed)
     for _ in range(10):
         n = int(10 ** rng.uniform(0, 5.48))
