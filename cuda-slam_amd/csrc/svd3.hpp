@@ -43,10 +43,14 @@ struct SvdMath {
 #if MISLAM_SVD_REFINE
             r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.f), r, r);           // r <- r + r (1 - b r)
             const float q = a * r;
-            return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);          // q <- q + r (a - b q): the quotient to the last bit but for rare ties
+            const float v = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);  // q <- q + r (a - b q): the quotient to the last bit but for rare ties
 #else
-            return a * r;
+            const float v = a * r;
 #endif
+            // a quotient that overflows (a planar cloud: a 2 x 2 block symmetrised to rounding residue) turns the residual steps into
+            // inf - inf; IEEE gives +-inf there and the rotation that follows is the identity -- so does this
+            if (fabsf(v) <= FLT_MAX) return v;
+            return a / b;
         }
 #endif
         return a / b;
@@ -59,7 +63,8 @@ struct SvdMath {
 #if MISLAM_SVD_REFINE
             y = __builtin_fmaf(0.5f * y, __builtin_fmaf(-x * y, y, 1.f), y);  // y <- y + (y / 2) (1 - x y^2)
 #endif
-            return y;
+            if (fabsf(y) <= FLT_MAX) return y;                               // (x = inf: 0 * inf in the residual; x = 0: inf -- IEEE's answers below)
+            return 1.f / sqrtf(x);
         }
 #endif
         return 1.f / sqrtf(x);
@@ -69,12 +74,14 @@ struct SvdMath {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (FAST) {
 #if MISLAM_SVD_REFINE
-            const float y = __builtin_amdgcn_rsqf(x);                        // (x >= 1 at every call site: no 0 * inf)
+            const float y = __builtin_amdgcn_rsqf(x);                        // (x >= 1 at every call site: no 0 * inf -- but x = inf is inf * 0)
             const float r = x * y;
-            return __builtin_fmaf(__builtin_fmaf(-r, r, x), 0.5f * y, r);    // r <- r + (x - r^2) / (2 r)
+            const float v = __builtin_fmaf(__builtin_fmaf(-r, r, x), 0.5f * y, r);    // r <- r + (x - r^2) / (2 r)
 #else
-            return __builtin_amdgcn_sqrtf(x);
+            const float v = __builtin_amdgcn_sqrtf(x);
 #endif
+            if (fabsf(v) <= FLT_MAX) return v;
+            return sqrtf(x);
         }
 #endif
         return sqrtf(x);

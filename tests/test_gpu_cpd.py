@@ -234,3 +234,23 @@ def test_sigma_squared_cpu_sequential_zero_head_and_exact_ties(ctx, capi, oracle
     a = np.zeros((len(xs), 3), np.float32)
     a[:, 0] = np.asarray(xs, np.float32)
     assert np.float32(ctx.cpd_sigma_squared(b, a, capi.SIGMA2_CPU_SEQUENTIAL)) == np.float32(oracle.cpd_sigma_squared(b, a))
+
+
+@pytest.mark.parametrize("axis", [0, 2])
+def test_planar_clouds_stay_finite_and_match_the_oracle(ctx, capi, oracle, axis):
+    # the M-step's Kabsch on a rank-2 cross-covariance (a planar moving cloud: one exactly zero column) -- the case the fast reciprocal /
+    # root forms of the 3 x 3 SVD answered with inf - inf before round 4's guard (test_gpu_icp.py has the ICP side)
+    rng = np.random.default_rng(17 + axis)
+    b = rng.uniform(-2, 2, (300, 3)).astype(np.float32)
+    b[:, axis] = np.float32(0.25)
+    ang = 0.15
+    c, s = np.cos(ang), np.sin(ang)
+    i, j = [k for k in range(3) if k != axis]
+    R0 = np.eye(3)
+    R0[i, i], R0[i, j], R0[j, i], R0[j, j] = c, -s, s, c                      # a rotation inside the plane
+    a = (b[rng.permutation(300)] @ R0.T + np.float32([0.1, -0.05, 0.02]) + rng.normal(scale=0.01, size=(300, 3))).astype(np.float32)
+    s2 = oracle.cpd_sigma_squared(b, a)
+    Ro, to, ito, eo = oracle.cpd(b, a, eps=0.0, max_iterations=10, tolerance=0.0)[:4]
+    sR, t, scale, it, err = ctx.cpd_register(b, a, capi.cpd_params(eps=0.0, max_iterations=10, tolerance=0.0, sigma2_init=s2))
+    assert np.isfinite(sR).all() and np.isfinite(t).all() and np.isfinite(err) and it == ito == 10
+    assert frob(sR, t, Ro, to) < 1e-3, frob(sR, t, Ro, to)                   # (10 EM iterations of fp32 sums in different orders on an ill-conditioned problem)
