@@ -343,6 +343,7 @@ def main():
     # MISLAM_BENCH_FORCE_DIST=1 takes the multi-process path (gloo bootstrap, RCCL communicator) even with one rank:
     # the rehearsal a single-GPU box allows
     use_dist = world > 1 or os.environ.get("MISLAM_BENCH_FORCE_DIST") == "1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between processes on this driver); before anything loads the HIP runtime
     quiet_host_pools()           # (before numpy / torch are imported)
     dist = None
     if use_dist:
