@@ -71,6 +71,8 @@ with capi.Context(0) as ctx:
         order = np.lexsort((start, slot))
         same = slot[order][1:] == slot[order][:-1]
         gaps = (start[order][1:] - end[order][:-1])[same]
+        if len(gaps) == 0:
+            gaps = np.zeros(1)                # (every wave had a slot of its own)
         print("  slots used %d; waves per slot mean %.1f; gap between a slot's waves: mean %.2f us p50 %.2f p90 %.2f p99 %.2f (negative: HW_ID wave ids reused) ; sum of gaps / (slots x span) = %.3f"
               % (len(set(slot.tolist())), len(tl) / max(len(set(slot.tolist())), 1), gaps.mean(), np.percentile(gaps, 50), np.percentile(gaps, 90), np.percentile(gaps, 99),
                  gaps[gaps > 0].sum() / (len(set(slot.tolist())) * span)))
