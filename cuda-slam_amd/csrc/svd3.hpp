@@ -47,10 +47,7 @@ struct SvdMath {
 #else
             const float v = a * r;
 #endif
-            // a quotient that overflows (a planar cloud: a 2 x 2 block symmetrised to rounding residue) turns the residual steps into
-            // inf - inf; IEEE gives +-inf there and the rotation that follows is the identity -- so does this
-            if (fabsf(v) <= FLT_MAX) return v;
-            return a / b;
+            return v;                // (NaN where the quotient overflows: see kabsch_rotation)
         }
 #endif
         return a / b;
@@ -63,8 +60,7 @@ struct SvdMath {
 #if MISLAM_SVD_REFINE
             y = __builtin_fmaf(0.5f * y, __builtin_fmaf(-x * y, y, 1.f), y);  // y <- y + (y / 2) (1 - x y^2)
 #endif
-            if (fabsf(y) <= FLT_MAX) return y;                               // (x = inf: 0 * inf in the residual; x = 0: inf -- IEEE's answers below)
-            return 1.f / sqrtf(x);
+            return y;                // (x = inf: 0 * inf in the residual -> NaN, see kabsch_rotation)
         }
 #endif
         return 1.f / sqrtf(x);
@@ -80,8 +76,7 @@ struct SvdMath {
 #else
             const float v = __builtin_amdgcn_sqrtf(x);
 #endif
-            if (fabsf(v) <= FLT_MAX) return v;
-            return sqrtf(x);
+            return v;
         }
 #endif
         return sqrtf(x);
@@ -251,10 +246,27 @@ struct Kabsch3 {
     float det;
 };
 
+// Where the fast forms break down: a quotient or a square that OVERFLOWS (a planar moving cloud gives a cross-covariance with a zero
+// column; a 2 x 2 block of the sweep is then symmetrised to rounding residue and tau = (x - z) / 2|y| leaves the fp32 range).  IEEE
+// arithmetic carries the infinity through (1 / inf = 0: the identity rotation); the residual steps of the fast forms turn it into
+// inf - inf.  Every such case ends in NaN, and NaN spreads to U and V -- so ONE test at the end, and the decomposition again in IEEE
+// arithmetic, out of line (guards inside the forms cost the solve kernel's one-lane chain 1.2 us; 7 of 400 random small problems need this).
+#if defined(__HIP_DEVICE_COMPILE__)
+static __attribute__((noinline, unused)) __device__ Svd3 svd3_ieee_out_of_line(const Mat3& A) { return svd3<false>(A); }
+#endif
+
 template <bool FAST = false>
 __host__ __device__ inline Kabsch3 kabsch_rotation(const Mat3& H)
 {
-    const Svd3 s = svd3<FAST>(H);
+    Svd3 s = svd3<FAST>(H);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (FAST) {
+        float chk = 0.f;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) chk += fabsf(s.U.a[r][c]) + fabsf(s.V.a[r][c]);
+        if (__builtin_expect(!(chk <= FLT_MAX), 0)) s = svd3_ieee_out_of_line(H);
+    }
+#endif
     Kabsch3 k;
     k.det = det3(mul_abt(s.U, s.V));
     Mat3 Ud = s.U;
