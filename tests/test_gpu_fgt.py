@@ -115,6 +115,16 @@ def test_guided_kcenter_on_ties_and_under_similarity_transforms(ctx, oracle):
         assert verified == first_diff                                                     # exactly the steps the two sweeps share
 
 
+def test_guided_kcenter_beyond_the_replay_limit(ctx, oracle):
+    # a replay stages at most 4 000 centres in LDS (FGT_REPLAY_MAX_CENTRES): a longer guess is replayed up to there, the rest is swept
+    c = cloud(31, 12000)
+    K = 4500
+    xc_o, lab_o = oracle.fgt_kcenter(c, K)
+    _, _, picked0, _ = ctx.fgt_kcenter_guided(c, K, np.zeros(0, np.int32))
+    xc, lab, picked, verified = ctx.fgt_kcenter_guided(c, K, picked0)
+    assert verified == 4000 and np.array_equal(lab, lab_o) and np.array_equal(xc, xc_o) and np.array_equal(picked, picked0)
+
+
 def test_guided_kcenter_rejects_bad_guesses(ctx, capi):
     c = cloud(0, 100)
     with pytest.raises(capi.MiSlamError):
