@@ -113,6 +113,7 @@ struct mi_ctx {
         int cpd_mfma = 1;                                // MISLAM_CPD_MFMA=0: VALU contraction instead of MFMA
         int fgt_resume = 1;                              // MISLAM_FGT_RESUME=0: re-cluster the fixed cloud from scratch every E-step
         int grid_deal_rows = -1;                         // MISLAM_GRID_DEAL_ROWS=0 / 1: K1g's leftover rows never / always dealt out one per lane (default: by size)
+        int icp_pipeline = 1;                            // MISLAM_ICP_PIPELINE=0: every host check of mi_icp_run settles the pending iteration and drains the stream
         int fgt_replay = 1;                              // MISLAM_FGT_REPLAY=0: sweep the moving cloud step by step every E-step (no guess replayed)
     } tune;
 
@@ -156,6 +157,7 @@ struct mi_ctx {
     mislam::DevBuf<unsigned char> keep_tmp;
     mislam::IcpState* d_state = nullptr;
     mislam::IcpState* h_state = nullptr;                 // pinned
+    hipEvent_t peek_event = nullptr;                     // behind the state copy of an intermediate host check (mi_icp_run)
 
     // ---- exact-NN indexes over the fixed-cloud shard (built lazily, valid until the shard is replaced)
     mislam::DevBuf<unsigned int> tcodes_in, tcodes_out;  // Morton sort scratch (also used for the moving cloud's ordering)

@@ -219,6 +219,7 @@ static int ctx_create_common(int device, mi_ctx** out)
         for (hipEvent_t& e : c->aux_event) MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         MI_HIP(hipMalloc((void**)&c->d_state, sizeof(IcpState)));
         MI_HIP(hipHostMalloc((void**)&c->h_state, sizeof(IcpState), hipHostMallocDefault));
+        MI_HIP(hipEventCreateWithFlags(&c->peek_event, hipEventDisableTiming));
         memset(c->h_state, 0, sizeof(IcpState));
         // developer switches: read here, once -- nothing on the per-iteration path looks at the environment
         auto env_i = [](const char* name, int dflt) { const char* v = getenv(name); return (v && *v) ? atoi(v) : dflt; };
@@ -231,6 +232,7 @@ static int ctx_create_common(int device, mi_ctx** out)
         c->tune.fgt_resume = env_i("MISLAM_FGT_RESUME", 1);
         c->tune.fgt_replay = env_i("MISLAM_FGT_REPLAY", 1);
         c->tune.grid_deal_rows = env_i("MISLAM_GRID_DEAL_ROWS", -1);
+        c->tune.icp_pipeline = env_i("MISLAM_ICP_PIPELINE", 1);
         if (const char* ppc = getenv("MISLAM_GRID_PPC")) { const float f = (float)atof(ppc); if (f >= 0.25f && f <= 64.f) c->tune.grid_points_per_cell = f; }
         if (env_i("MISLAM_PRELOAD", 0) == 1) MI_TRY(mi_ctx_preload(c));       // =1: mi_ctx_preload as part of every context creation
         // pinned upload staging: a ring of 16 pieces of 1 MB, pinned here, once per context (pinning costs ~0.25 ms per MB on this
@@ -429,6 +431,7 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->h_state) (void)hipHostFree(c->h_state);
+    if (c->peek_event) (void)hipEventDestroy(c->peek_event);
     for (hipEvent_t e : c->aux_event) if (e) (void)hipEventDestroy(e);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->aux2) (void)hipStreamDestroy(c->aux2);
@@ -1224,7 +1227,34 @@ extern "C" int mi_icp_run(mi_ctx* c, int max_new_iterations, int* iterations_don
     }
     if (c->icp.verbose) batch = 1;       // one "loop_nr" line per iteration, like basicicp.cpp:50 / icpcuda.cu:39
     int enqueued = 0;
-    while (!c->h_state->done && (max_new_iterations < 0 || enqueued < max_new_iterations)) {
+    // Batches of more than one iteration are PIPELINED (round 4): an intermediate host check used to settle the pending iteration (two
+    // launches over the moving cloud, ~23 us at 1e6 points), copy the state and drain the stream -- ~50 us in which the device waits for the
+    // host to read one flag and enqueue the next batch.  Now a check only PEEKS: the state block is copied behind the batch, ONE iteration
+    // of the next batch goes onto the stream behind the copy, and the host waits for the copy alone; the device is never idle, and the
+    // deferred stop rule makes the peek sound (a stop shows up one iteration late and that iteration applies nothing -- exactly as inside
+    // a batch; an iteration enqueued behind a stop returns at once).  The pending iteration is settled once, when the loop ends.
+    const bool pipelined = batch > 1 && !c->profile && g_stall_ms <= 0 && c->peek_event != nullptr && c->tune.icp_pipeline != 0;
+    bool ahead = false;                  // one iteration of the next batch is on the stream already
+    while (pipelined && !c->h_state->done && (max_new_iterations < 0 || enqueued < max_new_iterations)) {
+        int todo = batch;
+        if (max_new_iterations >= 0) todo = std::min(todo, max_new_iterations - enqueued + (ahead ? 1 : 0));
+        if (c->icp.max_iterations >= 0) todo = std::max(1, std::min(todo, c->icp.max_iterations - c->h_state->iterations));
+        for (int b = ahead ? 1 : 0; b < todo; b++) { MI_TRY(icp_enqueue_iteration(c)); enqueued++; }
+        const bool last = (max_new_iterations >= 0 && enqueued >= max_new_iterations) ||
+                          (c->icp.max_iterations >= 0 && c->h_state->iterations + todo >= c->icp.max_iterations);
+        if (last) { ahead = false; break; }                           // (the budget is spent: nothing to decide, settle below)
+        MI_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
+        MI_HIP(hipEventRecord(c->peek_event, c->stream));
+        MI_TRY(icp_enqueue_iteration(c));                             // the next batch's first iteration, behind the copy
+        enqueued++;
+        ahead = true;
+        MI_HIP(hipEventSynchronize(c->peek_event));
+    }
+    if (pipelined) {
+        MI_TRY(icp_flush_pending(c));
+        MI_TRY(icp_fetch_state(c));
+    }
+    while (!pipelined && !c->h_state->done && (max_new_iterations < 0 || enqueued < max_new_iterations)) {
         int todo = batch;
         if (max_new_iterations >= 0) todo = std::min(todo, max_new_iterations - enqueued);
         // a run capped at max_iterations is not enqueued past the cap (the device would turn the surplus into launches that return at once:

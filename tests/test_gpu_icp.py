@@ -108,6 +108,33 @@ def test_result_independent_of_host_check_interval(ctx, capi, bunny, sync_every)
 
 
 @pytest.mark.parametrize("cuda_rules", [False, True])
+def test_pipelined_host_checks_change_nothing(ctx, capi, bunny, monkeypatch, cuda_rules):
+    # Round 4: with batches of more than one iteration an intermediate host check only peeks at the state (copied behind the batch, one
+    # iteration of the next batch already behind the copy) instead of settling the pending iteration and draining the stream
+    # (MISLAM_ICP_PIPELINE=0, read at context creation: the old way).  Converged and capped runs, every batch size, and budgets handed to
+    # mi_icp_run piece by piece must give the same iterations, transform and error bit for bit -- and never run more than they were asked to.
+    before, after = bunny
+    monkeypatch.setenv("MISLAM_ICP_PIPELINE", "0")
+    with capi.Context(0) as plain:
+        for cap in (50, 7, 1):
+            want = plain.icp_register(before, after, capi.icp_params(cuda_slam=cuda_rules, max_iterations=cap, max_distance_squared=400.0, sync_every=1))
+            for sync in (0, 2, 3, 5, 16, 64):
+                for c2 in (ctx, plain):
+                    got = c2.icp_register(before, after, capi.icp_params(cuda_slam=cuda_rules, max_iterations=cap, max_distance_squared=400.0, sync_every=sync))
+                    assert got[2] == want[2] and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[3] == want[3], (cap, sync)
+        p = capi.icp_params(cuda_slam=cuda_rules, eps=0.0, max_iterations=-1, max_distance_squared=400.0, sync_every=4)
+        for c2 in (ctx, plain):
+            c2.icp_load(before, after, p)
+        ran = 0
+        for budget in (1, 2, 3, 4, 5, 9, 11):
+            a, b = ctx.icp_run(budget), plain.icp_run(budget)
+            ran += budget
+            ra, rb = ctx.icp_result(), plain.icp_result()
+            assert a == b == budget and ra[2] == rb[2] == ran and np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]) and ra[3] == rb[3], budget
+        ctx.icp_reset()
+
+
+@pytest.mark.parametrize("cuda_rules", [False, True])
 def test_search_strategy_does_not_change_the_registration(ctx, capi, bunny, cuda_rules):
     # every pair, the box hierarchy and the cell grid return the same keys, and every path -- the grid's fused iteration
     # included -- adds an iteration's sums in the same per-64-point rows: the whole run is bitwise identical
