@@ -26,10 +26,11 @@ struct FgtSide {
     DevBuf<unsigned long long> replay_partial;
     int swept_K = 0;            // the fixed cloud only: centres of the sweep dist/indx currently hold (0 = none); see fgt_kcenter_kernel
     int guess_K = 0;            // the moving cloud only: leading entries of `picked` the last E-step's sweep left -- the next one's guess
+    int prelaunched = 0;        // > 0: a replay of that guess (this many centres) is on the stream already, behind the last transform
     void release()
     {
         dist.release(); xc.release(); indx.release(); memb.release(); off.release(); sweep.release(); picked.release(); replay_state.release();
-        replay_partial.release(); swept_K = 0; guess_K = 0;
+        replay_partial.release(); swept_K = 0; guess_K = 0; prelaunched = 0;
     }
 };
 
@@ -111,6 +112,7 @@ static int cpd_load(mi_ctx* c, CpdWorkspace* w, const float* before_xyz, int m, 
     c->icp_loaded = false;   // the moving-cloud buffers are shared with the ICP driver
     w->fgt.a.swept_K = 0;    // a new fixed cloud: its clustering starts over
     w->fgt.y.guess_K = 0;    // a new moving cloud: nothing to guess its sweep from
+    w->fgt.y.prelaunched = 0;
     w->m = m; w->n = n; w->n_total = n;
     w->m_pad = round_up_i(m, NN_SRC_PAD);
     w->n_pad = round_up_i(n, NN_SRC_PAD);
@@ -313,6 +315,23 @@ static int fgt_arm_replay(mi_ctx* c, FgtSide* sd, FgtClusters* cl, int guess)
     return MI_OK;
 }
 
+// Behind the transform that ends an EM iteration, before the host has sigma^2 (hence K) of the next one: the moving cloud's sweep replayed
+// from this iteration's choices.  The replay needs the transformed cloud and the guess, not K; K only grows while the FGT is in use, so the
+// next E-step finds exactly the replay it would have launched -- 20 us of work inside the ~25 us the device used to wait for the host.
+static int cpd_fgt_prelaunch(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
+{
+    FgtWork* f = &w->fgt;
+    f->y.prelaunched = 0;
+    if (c->tune.fgt_replay == 0 || f->y.guess_K < 2) return MI_OK;
+    FgtClusters cy{};
+    MI_TRY(fgt_side(c, f, &f->y, v.yx, v.yy, v.yz, w->m, f->y.guess_K, &cy));
+    if (f->y.guess_K < 2) return MI_OK;                 // (fgt_side dropped the guess with a reallocated buffer)
+    MI_TRY(fgt_arm_replay(c, &f->y, &cy, f->y.guess_K));
+    MI_HIP(fgt_replay_prelaunch(cy, c->stream));
+    f->y.prelaunched = fgt_replay_limit(cy.guess, cy.K);
+    return MI_OK;
+}
+
 // K of the transform: cpdutils.cpp:36
 static int fgt_cluster_count(int m, int n, float sigma2, float sigma2_init)
 {
@@ -349,6 +368,9 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
     // Kt1 = K^T 1: sources = moving cloud, unit weights, queried at the fixed cloud   (cpdutils.cpp:42-43)
     // (the moving cloud's sweep: last E-step's choices replayed and checked in parallel, MISLAM_FGT_REPLAY=0: swept step by step every time)
     MI_TRY(fgt_arm_replay(c, &f->y, &cy, c->tune.fgt_replay != 0 ? f->y.guess_K : 0));
+    // (prelaunched: the same replay went onto the stream behind the last transform, cpd_fgt_prelaunch below -- K has not shrunk below the guess)
+    cy.replay_done = f->y.prelaunched > 0 && f->y.prelaunched == fgt_replay_limit(cy.guess, cy.K) ? 1 : 0;
+    f->y.prelaunched = 0;
     MI_HIP(fgt_cluster(cy, f->sort_temp.p, temp, c->stream));
     f->y.guess_K = K;
     MI_HIP(fgt_model(cy, nullptr, hsigma, t, f->By.p, c->stream));
@@ -442,8 +464,12 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
         batch = std::max(1, std::min(8, (int)(1.2e-3 / est_s)));
     }
     if (params->approximation != MI_CPD_APPROX_NONE) batch = 1;   // the E-step's shape depends on sigma^2: host-stepped
+    // exact P in batches: a host check only peeks (state copy behind the batch, ONE iteration of the next batch behind the copy, the host
+    // waits for the copy alone) -- the device does not idle for the ~26 us a drained stream and a fresh enqueue cost (mi_icp_run does the same)
+    const bool pipelined = batch > 1 && c->peek_event != nullptr && c->tune.icp_pipeline != 0 && !c->profile;
+    bool ahead = false;
     while (!w->h_state->done) {
-        for (int b = 0; b < batch; b++) {
+        for (int b = ahead ? 1 : 0; b < batch; b++) {
             if (params->approximation == MI_CPD_APPROX_NONE) {
                 MI_TRY(cpd_estep_enqueue(c, w, v));
             } else {
@@ -472,7 +498,22 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
             MI_TRY(cpd_mstep_enqueue(c, w, v, rules, 1));
             MI_HIP(cpd_transform(v, w->m_pad, c->stream));
         }
-        MI_TRY(cpd_fetch(c, w));
+        if (params->approximation != MI_CPD_APPROX_NONE && c->peek_event != nullptr) {
+            // the state copy first, the replay BEHIND it: the host has sigma^2 while the device replays
+            MI_HIP(hipMemcpyAsync(w->h_state, w->d_state, sizeof(CpdState), hipMemcpyDeviceToHost, c->stream));
+            MI_HIP(hipEventRecord(c->peek_event, c->stream));
+            MI_TRY(cpd_fgt_prelaunch(c, w, v));
+            MI_HIP(hipEventSynchronize(c->peek_event));
+        } else if (pipelined) {
+            MI_HIP(hipMemcpyAsync(w->h_state, w->d_state, sizeof(CpdState), hipMemcpyDeviceToHost, c->stream));
+            MI_HIP(hipEventRecord(c->peek_event, c->stream));
+            MI_TRY(cpd_estep_enqueue(c, w, v));                    // (returns at once on the device if the state copied above says "done")
+            MI_TRY(cpd_mstep_enqueue(c, w, v, rules, 1));
+            MI_HIP(cpd_transform(v, w->m_pad, c->stream));
+            ahead = true;
+            MI_HIP(hipEventSynchronize(c->peek_event));
+        } else
+            MI_TRY(cpd_fetch(c, w));
         if (params->verbose) printf("loop_nr %d, error: %f\n", w->h_state->iterations, w->h_state->error);
     }
     const CpdState* s = w->h_state;

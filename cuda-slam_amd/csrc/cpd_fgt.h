@@ -39,10 +39,14 @@ struct FgtClusters {
     int guess;
     unsigned long long* replay_partial;   // [fgt_replay_limit(guess, K)][fgt_replay_waves(n)]
     int* replay_state;                    // [1]  -> the number of leading steps of the guess that were verified
+    int replay_done;                      // the replay of this guess is on the stream already (fgt_replay_prelaunch): fgt_cluster only resumes from its verdict
 };
 constexpr int FGT_REPLAY_MAX_CENTRES = 4000;       // centres a replay stages in LDS (16 bytes each)
 int fgt_replay_waves(int n);
 int fgt_replay_limit(int guess, int K);
+// the replay + check of c.guess alone (what fgt_cluster starts with): lets a caller put it on the stream before it knows K -- rigid CPD does,
+// behind the transform of the moving cloud, while the host still waits for sigma^2 (K never shrinks below the guess there)
+hipError_t fgt_replay_prelaunch(const FgtClusters& c, hipStream_t s);
 
 size_t fgt_sort_temp_bytes(int n);     // scratch fgt_cluster needs for its member-list sort
 // K-centre clustering + member lists + cluster means; everything a model build needs

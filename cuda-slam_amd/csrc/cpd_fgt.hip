@@ -694,6 +694,20 @@ static void launch_replay(const FgtClusters& c, int lim, const int* limit_ptr, i
 #undef MI_REPLAY
 }
 
+static hipError_t launch_replay_and_check(const FgtClusters& c, int lim, hipStream_t s)
+{
+    launch_replay<true>(c, lim, nullptr, 0, s);
+    hipLaunchKernelGGL(fgt_replay_check_kernel, dim3(std::max(1, (lim - 1 + 3) / 4)), dim3(256), 0, s, c.replay_partial, fgt_replay_waves(c.n), c.picked, lim, c.replay_state);
+    launch_replay<false>(c, lim, c.replay_state, lim, s);
+    return hipGetLastError();
+}
+
+hipError_t fgt_replay_prelaunch(const FgtClusters& c, hipStream_t s)
+{
+    const int lim = c.replay_partial != nullptr && c.replay_state != nullptr ? fgt_replay_limit(c.guess, c.K) : 0;
+    return lim > 0 ? launch_replay_and_check(c, lim, s) : hipErrorInvalidValue;
+}
+
 hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_bytes, hipStream_t s)
 {
     int start = c.k_done > 0 && c.k_done < c.K ? c.k_done : 0;
@@ -701,10 +715,7 @@ hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_b
     const int lim = start == 0 && c.replay_partial != nullptr && c.replay_state != nullptr ? fgt_replay_limit(c.guess, c.K) : 0;
     if (lim > 0) {
         // the guess replayed and checked (fgt_replay_kernel); what it leaves: dist / indx after state[0] verified steps
-        launch_replay<true>(c, lim, nullptr, 0, s);
-        hipLaunchKernelGGL(fgt_replay_check_kernel, dim3(std::max(1, (lim - 1 + 3) / 4)), dim3(256), 0, s, c.replay_partial, fgt_replay_waves(c.n), c.picked, lim, c.replay_state);
-        launch_replay<false>(c, lim, c.replay_state, lim, s);
-        hipError_t e = hipGetLastError();
+        hipError_t e = c.replay_done ? hipSuccess : launch_replay_and_check(c, lim, s);
         if (e != hipSuccess) return e;
         start_ptr = c.replay_state;
         if (c.n > FGT_GRID_SWEEP_MIN_POINTS) {                        // the grid-wide sweep is driven from the host: it needs the number
