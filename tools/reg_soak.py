@@ -36,7 +36,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     capi = load_package().capi
     ctx = capi.Context(0)
-    worst = {"icp": 0.0, "cpd": 0.0}
+    worst = {"icp": 0.0, "cpd": 0.0, "hyb": 0.0}
     flagged = 0
     for k in range(cases):
         degenerate = k % 3 == 2              # tiny, collinear or coincident clouds: the rotation is not determined -- only "finite or not" is compared
@@ -72,7 +72,22 @@ def main():
                 if bad:
                     flagged += 1
                     print("CPD case %d n=%d m=%d kinds %d %d: it %d/%d finite %s/%s diff %.3g" % (k, n, m, ks, kt, it, ito, fin, fin_o, d), flush=True)
-    print("registration soak: %d cases, %d flagged, worst relative difference icp %.3g cpd %.3g" % (cases, flagged, worst["icp"], worst["cpd"]))
+        # the reference's default approximation (hybrid: FGT E-steps, K-centre sweeps replayed from one E-step to the next), well-posed cases only
+        if not degenerate and 60 <= n <= 1500 and 60 <= m <= 1500 and k % 2 == 0:
+            s2 = oracle.cpd_sigma_squared(src, tgt)
+            if np.isfinite(s2) and s2 > 0:
+                Ro, to, ito, eo = oracle.cpd_approx(src, tgt, oracle.APPROX_HYBRID, eps=0.0, max_iterations=6, tolerance=0.0)[:4]
+                sR, t, sc, it, err = ctx.cpd_register(src, tgt, capi.cpd_params(eps=0.0, max_iterations=6, tolerance=0.0, sigma2_init=s2,
+                                                                               approximation=capi.CPD_APPROX_HYBRID))
+                fin_o = np.isfinite(Ro).all() and np.isfinite(to).all()
+                fin = np.isfinite(sR).all() and np.isfinite(t).all()
+                d = frob(sR, t, Ro, to) if fin and fin_o else float("nan")
+                scale = max(1.0, float(np.abs(to).max()) if fin_o else 1.0)
+                if fin and fin_o: worst["hyb"] = max(worst["hyb"], d / scale)
+                if (fin != fin_o) or (fin and fin_o and d > 2e-3 * scale) or it != ito:
+                    flagged += 1
+                    print("HYBRID case %d n=%d m=%d kinds %d %d: it %d/%d finite %s/%s diff %.3g" % (k, n, m, ks, kt, it, ito, fin, fin_o, d), flush=True)
+    print("registration soak: %d cases, %d flagged, worst relative difference icp %.3g cpd %.3g hybrid %.3g" % (cases, flagged, worst["icp"], worst["cpd"], worst["hyb"]))
 
 
 if __name__ == "__main__":
