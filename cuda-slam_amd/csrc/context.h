@@ -113,6 +113,7 @@ struct mi_ctx {
         int cpd_mfma = 1;                                // MISLAM_CPD_MFMA=0: VALU contraction instead of MFMA
         int fgt_resume = 1;                              // MISLAM_FGT_RESUME=0: re-cluster the fixed cloud from scratch every E-step
         int grid_deal_rows = -1;                         // MISLAM_GRID_DEAL_ROWS=0 / 1: K1g's leftover rows never / always dealt out one per lane (default: by size)
+        int icp_fused_solve = 1;                         // MISLAM_ICP_FUSED_SOLVE=0: rows reduce and solve as two launches at every size
         int icp_pipeline = 1;                            // MISLAM_ICP_PIPELINE=0: every host check of mi_icp_run settles the pending iteration and drains the stream
         int fgt_replay = 1;                              // MISLAM_FGT_REPLAY=0: sweep the moving cloud step by step every E-step (no guess replayed)
     } tune;

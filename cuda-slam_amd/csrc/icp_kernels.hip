@@ -525,6 +525,60 @@ hipError_t icp_rows_to_state(IcpState* state, const double* part, int count, int
     return hipGetLastError();
 }
 
+// Small clouds (round 4): rows reduce AND deferred solve in ONE workgroup -- below ~10^5 points an ICP step is three launches of which the
+// search is 60 %, and what the two others cost is mostly being launches.  Thread (b, k) walks what workgroup b's column k of
+// icp_rows_reduce_kernel adds up -- the same strips, the same order, so the same 64 (or fewer) rows to the last bit -- into LDS, and the first
+// wave goes on exactly as icp_solve_deferred_kernel does.  No work order is dealt: every wave of such a search is resident from the start.
+__global__ __launch_bounds__(ROWS_REDUCE_THREADS) void icp_reduce_solve_kernel(IcpState* __restrict__ state, const double* __restrict__ rows, int nrows,
+                                                                              int rows_per_block, int count, int compose_mode, IcpRules rules, int mark_pending)
+{
+    if (state->done != 0) return;
+    constexpr int STRIPS = ROWS_REDUCE_THREADS / ICP_ROW;
+    __shared__ double part[ICP_REDUCED_ROWS * ICP_ROW];
+    __shared__ double sums[ICP_ROW];
+    // (a slice here has at most FUSED_SLICE <= STRIPS rows, i.e. every strip of the two-launch form holds at most one row: its sum is
+    // 0.0 + that row, and the strips are added in order -- the loads first, all in flight together, then the chain of additions)
+    constexpr int FUSED_SLICE = ICP_FUSED_SOLVE_MAX_ROWS / ICP_REDUCED_ROWS;
+    static_assert(FUSED_SLICE <= STRIPS, "one row per strip");
+    for (int item = (int)threadIdx.x; item < count * ICP_ROW; item += ROWS_REDUCE_THREADS) {
+        const int b = item / ICP_ROW, k = item - b * ICP_ROW;
+        const int lo = b * rows_per_block;
+        const int hi = lo + rows_per_block < nrows ? lo + rows_per_block : nrows;
+        double val[FUSED_SLICE];
+#pragma unroll
+        for (int j = 0; j < FUSED_SLICE; j++) val[j] = rows[(size_t)min(lo + j, nrows - 1) * ICP_ROW + k];     // (unconditional: all in flight at once)
+#pragma unroll
+        for (int j = 0; j < FUSED_SLICE; j++) val[j] = lo + j < hi ? val[j] : 0.0;
+        double tot = 0.0 + val[0];
+#pragma unroll
+        for (int j = 1; j < FUSED_SLICE; j++) tot = tot + (0.0 + val[j]);       // (an empty strip adds its 0.0, as it does there)
+        if (FUSED_SLICE < STRIPS) tot = tot + 0.0;
+        part[item] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;                   // the first wave goes on alone (the barrier inside reduce_rows_wave then counts one wave)
+    reduce_rows_wave(part, count, sums);
+    if (threadIdx.x != 0) return;
+    if (state->err_pending) {
+        state->err_pending = 0;
+        state->err[0] = sums[ICP_MOMENTS];
+        state->err[1] = sums[ICP_MOMENTS + 1];
+        finalize_iteration(state, sums[ICP_MOMENTS], sums[ICP_MOMENTS + 1], rules);
+        if (state->done != 0) return;
+    }
+    double mom[ICP_MOMENTS];
+    for (int i = 0; i < ICP_MOMENTS; i++) { mom[i] = sums[i]; state->mom[i] = sums[i]; }
+    apply_solve(state, mom, compose_mode, rules.seq_sums);
+    if (mark_pending && state->done == 0) state->err_pending = 1;
+}
+hipError_t icp_reduce_solve(IcpState* state, const double* rows, int nrows, int compose_mode, const IcpRules& rules, int mark_pending, hipStream_t s)
+{
+    const int g = icp_reduced_count(nrows);
+    const int per = (nrows + g - 1) / g;
+    hipLaunchKernelGGL(icp_reduce_solve_kernel, dim3(1), dim3(ROWS_REDUCE_THREADS), 0, s, state, rows, nrows, per, g, compose_mode, rules, mark_pending);
+    return hipGetLastError();
+}
+
 hipError_t icp_solve_deferred(IcpState* state, const double* part, int count, int compose_mode, const IcpRules& rules, int mark_pending, hipStream_t s,
                               int* sched_counters)
 {

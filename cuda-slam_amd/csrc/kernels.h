@@ -121,6 +121,8 @@ struct IcpSchedule {
 };
 hipError_t icp_schedule_reset(const IcpSchedule& sched, int nrows, hipStream_t s);             // identity order, no flags
 hipError_t icp_rows_reduce(const double* rows, int nrows, double* part, hipStream_t s, const IcpSchedule* sched = nullptr, bool all_rows = false);   // -> part[icp_reduced_count(nrows)][18]
+constexpr int ICP_FUSED_SOLVE_MAX_ROWS = 2048;      // up to this many rows (131 072 moving points) rows reduce + solve are one launch of one workgroup
+hipError_t icp_reduce_solve(IcpState* state, const double* rows, int nrows, int compose_mode, const IcpRules& rules, int mark_pending, hipStream_t s);
 // reduced rows -> state->mom / state->err (which: 1 moments, 2 error sums, 3 both); the multi-GPU paths all-reduce them there
 hipError_t icp_rows_to_state(IcpState* state, const double* part, int count, int which, hipStream_t s);
 // K3 + K6, deferred: settles the PREVIOUS iteration's stop rule from the error sums (if state->err_pending), then -- unless it

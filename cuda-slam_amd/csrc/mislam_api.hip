@@ -233,6 +233,7 @@ static int ctx_create_common(int device, mi_ctx** out)
         c->tune.fgt_replay = env_i("MISLAM_FGT_REPLAY", 1);
         c->tune.grid_deal_rows = env_i("MISLAM_GRID_DEAL_ROWS", -1);
         c->tune.icp_pipeline = env_i("MISLAM_ICP_PIPELINE", 1);
+        c->tune.icp_fused_solve = env_i("MISLAM_ICP_FUSED_SOLVE", 1);
         if (const char* ppc = getenv("MISLAM_GRID_PPC")) { const float f = (float)atof(ppc); if (f >= 0.25f && f <= 64.f) c->tune.grid_points_per_cell = f; }
         if (env_i("MISLAM_PRELOAD", 0) == 1) MI_TRY(mi_ctx_preload(c));       // =1: mi_ctx_preload as part of every context creation
         // pinned upload staging: a ring of 16 pieces of 1 MB, pinned here, once per context (pinning costs ~0.25 ms per MB on this
@@ -1179,6 +1180,10 @@ static int icp_enqueue_iteration(mi_ctx* c)
             { ProfScope ps(c, MI_KERNEL_ALLREDUCE); MI_TRY(allreduce_doubles(c, c->rows_reduced.p, ICP_REDUCED_ROWS * (ICP_MOMENTS + ICP_ERRSUMS))); }
             ProfScope ps(c, MI_KERNEL_SOLVE);
             MI_HIP(icp_solve_deferred(c->d_state, c->rows_reduced.p, ICP_REDUCED_ROWS, c->icp.compose_mode, rules, 1, c->stream, cursors));
+        } else if (nrows <= ICP_FUSED_SOLVE_MAX_ROWS && c->tune.icp_fused_solve != 0) {
+            // small clouds: one launch of one workgroup for both (and no work order: every wave of such a search is resident from the start)
+            ProfScope ps(c, MI_KERNEL_SOLVE);
+            MI_HIP(icp_reduce_solve(c->d_state, c->rows.p, nrows, c->icp.compose_mode, rules, 1, c->stream));
         } else {
             ProfScope ps(c, MI_KERNEL_SOLVE);
             MI_HIP(icp_rows_reduce(c->rows.p, nrows, c->rows_reduced.p, c->stream, c->fused ? &sched : nullptr));

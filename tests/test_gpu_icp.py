@@ -107,6 +107,19 @@ def test_result_independent_of_host_check_interval(ctx, capi, bunny, sync_every)
     assert base[2] == other[2] and np.array_equal(base[0], other[0]) and np.array_equal(base[1], other[1]) and base[3] == other[3]
 
 
+@pytest.mark.parametrize("n", [3, 64, 65, 2000, 14904, 100000, 131072])
+def test_one_launch_reduce_and_solve_is_the_two_launch_one(ctx, capi, monkeypatch, n):
+    # up to 131 072 moving points (2 048 rows) the rows reduce and the deferred solve are ONE launch of one workgroup (round 4) that adds
+    # the rows up in the two-launch form's order: same bits (MISLAM_ICP_FUSED_SOLVE=0, read at context creation, keeps two launches)
+    before, after = synth_cloud(n, seed=n)[:2]
+    monkeypatch.setenv("MISLAM_ICP_FUSED_SOLVE", "0")
+    with capi.Context(0) as two:
+        for nn in ((capi.NN_GRID, capi.NN_BRUTEFORCE) if n <= 20000 else (capi.NN_GRID,)):
+            p = capi.icp_params(eps=0.0, max_iterations=7, nn_mode=nn)
+            a, b = ctx.icp_register(before, after, p), two.icp_register(before, after, p)
+            assert a[2] == b[2] == 7 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[3] == b[3], (n, nn)
+
+
 @pytest.mark.parametrize("cuda_rules", [False, True])
 def test_pipelined_host_checks_change_nothing(ctx, capi, bunny, monkeypatch, cuda_rules):
     # Round 4: with batches of more than one iteration an intermediate host check only peeks at the state (copied behind the batch, one
