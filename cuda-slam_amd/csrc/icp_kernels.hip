@@ -509,7 +509,7 @@ hipError_t icp_rows_reduce(const double* rows, int nrows, double* part, hipStrea
 __global__ __launch_bounds__(256) void icp_schedule_reset_kernel(IcpSchedule sched, int nrows)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r < nrows) { sched.order[r] = r; sched.far[r] = 0; }
+    if (r < nrows) { sched.order[r] = r; sched.far[r] = 0; if (sched.lanes != nullptr) sched.lanes[r] = 0ull; }
     if (r < 2) sched.counters[r] = 0;
 }
 

@@ -117,6 +117,7 @@ hipError_t icp_transform_error_rows(const IcpView& v, double* rows, int rearm, h
 struct IcpSchedule {
     int* order;                            // nrows entries, always a permutation of the chunks
     unsigned char* far;                    // nrows flags
+    unsigned long long* lanes;             // nrows lane masks (GridSearchArgs::far_lanes)
     int* counters;                         // 2 cursors, zeroed by the solve kernel
 };
 hipError_t icp_schedule_reset(const IcpSchedule& sched, int nrows, hipStream_t s);             // identity order, no flags

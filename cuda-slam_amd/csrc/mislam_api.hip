@@ -232,6 +232,7 @@ static int ctx_create_common(int device, mi_ctx** out)
         c->tune.fgt_resume = env_i("MISLAM_FGT_RESUME", 1);
         c->tune.fgt_replay = env_i("MISLAM_FGT_REPLAY", 1);
         c->tune.grid_deal_rows = env_i("MISLAM_GRID_DEAL_ROWS", -1);
+        c->tune.grid_split_walks = env_i("MISLAM_GRID_SPLIT_WALKS", -1);
         c->tune.icp_pipeline = env_i("MISLAM_ICP_PIPELINE", 1);
         c->tune.icp_fused_solve = env_i("MISLAM_ICP_FUSED_SOLVE", 1);
         if (const char* ppc = getenv("MISLAM_GRID_PPC")) { const float f = (float)atof(ppc); if (f >= 0.25f && f <= 64.f) c->tune.grid_points_per_cell = f; }
@@ -426,7 +427,7 @@ extern "C" void mi_ctx_destroy(mi_ctx* c)
     c->tbbox.release(); c->tsort_temp.release(); c->tpts.release(); c->tboxes.release(); c->sorder.release(); c->sinv.release(); c->resid.release();
     c->tleaf.release(); c->tidx.release(); c->tboxes6.release(); c->nn_stats.release();
     c->gpts.release(); c->gstart.release(); c->gfill.release(); c->gscan.release(); c->rows.release(); c->rows_reduced.release();
-    c->sched_order.release(); c->sched_far.release(); c->sched_counters.release(); c->gslot_of.release(); c->match_slot.release();
+    c->sched_order.release(); c->sched_far.release(); c->sched_lanes.release(); c->sched_counters.release(); c->gslot_of.release(); c->match_slot.release();
     c->grow_occ.release(); c->gnear_tmp.release();
     for (auto& s : c->spans) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
@@ -870,6 +871,7 @@ static int reserve_rows(mi_ctx* c)
     MI_HIP(hipMemsetAsync(c->rows_reduced.p, 0, sizeof(double) * ICP_REDUCED_ROWS * (ICP_MOMENTS + ICP_ERRSUMS), c->stream));   // (rows past a rank's count: zero)
     MI_TRY(c->sched_order.reserve((size_t)icp_row_count(c->n_pad)));
     MI_TRY(c->sched_far.reserve((size_t)icp_row_count(c->n_pad)));
+    MI_TRY(c->sched_lanes.reserve((size_t)icp_row_count(c->n_pad)));
     MI_TRY(c->sched_counters.reserve(2));
     return MI_OK;
 }
@@ -877,7 +879,7 @@ static int reserve_rows(mi_ctx* c)
 static IcpSchedule make_schedule(mi_ctx* c)
 {
     IcpSchedule s{};
-    s.order = c->sched_order.p; s.far = c->sched_far.p; s.counters = c->sched_counters.p;
+    s.order = c->sched_order.p; s.far = c->sched_far.p; s.counters = c->sched_counters.p; s.lanes = c->sched_lanes.p;
     return s;
 }
 
@@ -1154,8 +1156,9 @@ static int icp_enqueue_iteration(mi_ctx* c)
         a.match_slot = c->match_slot.p; a.shard_lo = c->shard_lo; a.shard_hi = c->shard_hi;
         a.filter_pairs = c->icp.filter_pairs; a.max_distance_squared = c->icp.max_distance_squared;
         a.rows = c->rows.p;
-        a.order = c->sched_order.p; a.far = c->sched_far.p;
+        a.order = c->sched_order.p; a.far = c->sched_far.p; a.far_lanes = c->sched_lanes.p;
         a.deal_rows = c->tune.grid_deal_rows < 0 ? (c->n >= GRID_DEAL_ROWS_MIN_POINTS ? 1 : 0) : c->tune.grid_deal_rows;
+        a.split_walks = c->tune.grid_split_walks < 0 ? (c->n <= GRID_SPLIT_WALKS_MAX_POINTS ? 1 : 0) : c->tune.grid_split_walks;
         hipEvent_t e0 = nullptr, e1 = nullptr;           // timed, if at all, by events attached to the launch itself (nn_grid_query)
         MI_TRY(c->prof_span(MI_KERNEL_NN, &e0, &e1));
         MI_HIP(nn_grid_query(c->grid, c->tree, a, v.fma, c->stream, e0, e1));

@@ -21,6 +21,7 @@ constexpr int GRID_STATS_ROWS = 1024;         // mi_profile_search_stats: the co
 #endif
 constexpr float GRID_FAR_FACTOR = MISLAM_GRID_FAR_FACTOR;    // a starting candidate farther than this many times GRID_DU_MAX cells: straight to the hierarchy
 constexpr int GRID_DEAL_ROWS_MIN_POINTS = 900000;   // from this many moving points on, a wave's leftover rows are dealt out one per lane (nn_grid.hip; measured: -6 % at 7e5, +2 % at 1e6, +5 % at 3e6)
+constexpr int GRID_SPLIT_WALKS_MAX_POINTS = 350000;  // up to this many moving points a fused iteration runs a HELPER wave per workgroup (nn_grid.hip; measured: -27 % search time at 1e4, -20 % at 1e5, -5 % at 3e5, +7 % at 4.5e5)
 constexpr int GRID_CAND_BUDGET = 640;         // candidates a lane may test in the grid before it walks the hierarchy instead
 constexpr int GRID_BATCH = 4;                 // cell rows whose offsets a lane requests together, then scans as one flat run of candidates
 constexpr int GRID_PTS_PAD = 4;               // pts carries this many copies of its last entry: a lane fetches candidates four at a time
@@ -89,6 +90,8 @@ struct GridSearchArgs {
     double* rows;                          // [ceil(n / GRID_BLOCK)][ICP_ROW] partial sums (icp_rows.hpp)
     const int* order;                      // work order (IcpSchedule): workgroup at position p takes chunk order[p]; null = identity
     unsigned char* far;                    // out: far[chunk] = this chunk's wave walked the hierarchy
+    unsigned long long* far_lanes;         // in/out, may be null: per chunk, the lanes whose answer came from a walk (the helper wave's share next time)
+    int split_walks;                       // fused iterations of small clouds: a helper wave per workgroup takes half of every immediate walk (nn_grid.hip)
     int deal_rows;                         // set by nn_grid_query: leftover rows dealt out one per lane (launches of more waves than the chip holds)
 };
 hipError_t nn_grid_query(const NnGridView& g, const NnTreeView& t, const GridSearchArgs& a, int fma, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);

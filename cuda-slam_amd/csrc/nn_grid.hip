@@ -361,6 +361,14 @@ __device__ __forceinline__ GridWaveLds& grid_wave_lds()
     __shared__ GridWaveLds lds;
     return lds;
 }
+// The dealing arrays belong to ONE wave (a workgroup's second wave, where there is one, never touches them): what orders their traffic
+// is the wave's own program order -- LDS operations of a wave complete in issue order -- so the compiler must not move them across
+// these points, and no workgroup barrier is needed (a barrier here would also tie the scan to the helper wave's walk).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 // Returns false (nothing done) if dealing does not pay or does not fit; true: kbest / bslot hold the lane's results.
 // `owner_lane`: the lane the trips are tested FOR (the lane itself, or -- leftover rows dealt out -- the lane whose row it scans; then
 // `own_setup` is false: the owners' queries and keys are in LDS already).
@@ -408,7 +416,7 @@ __device__ __forceinline__ bool grid_deal_scan(const float4* __restrict__ pts, c
             deal_owner[first + k] = mine;
         }
     }
-    __syncthreads();                                            // (one wave per workgroup: orders the LDS traffic)
+    wave_lds_sync();                                            // (the arrays are one wave's own: orders its LDS traffic)
     for (unsigned int base = 0; base < total; base += 64u) {
         const unsigned int idx = base + (unsigned int)lane;
         const bool have = idx < total;
@@ -436,7 +444,7 @@ __device__ __forceinline__ bool grid_deal_scan(const float4* __restrict__ pts, c
         dev_passes += 1u;
 #endif
     }
-    __syncthreads();
+    wave_lds_sync();
     const unsigned long long kfin = deal_key[lane];
     if (kfin < kbest) { kbest = kfin; bslot = deal_slot[lane]; }
     return true;
@@ -601,7 +609,7 @@ __device__ __forceinline__ void grid_rows_dealt(const NnGridView& g, GridLane& s
     L.own_c[lane] = (unsigned int)s.cy | ((unsigned int)s.cz << 16);
     L.own_cand[lane] = 0u;
     if (mask != 0u) { L.rec_first[rank] = first | (lane << 16); L.rec_rows[rank] = mask; }
-    __syncthreads();                                            // (one wave per workgroup: orders the LDS traffic)
+    wave_lds_sync();                                            // (the arrays are one wave's own: orders its LDS traffic)
     for (unsigned int base = 0; base < total; base += 64u) {    // (wave-uniform; one round unless the wave has more than 64 rows left)
         const unsigned int c = base + lane;
         const bool have = c < total;
@@ -672,15 +680,15 @@ __device__ __forceinline__ void grid_rows_dealt(const NnGridView& g, GridLane& s
         if (won) atomicMin(&L.deal_key[owner], kb);
         // LDS operations of one wave complete in program order: every lane now reads the minimum, and whoever holds it says where
         if (won && L.deal_key[owner] == kb) L.deal_slot[owner] = slot;
-        __syncthreads();
+        wave_lds_sync();
     }
-    __syncthreads();
+    wave_lds_sync();
     const unsigned long long kfin = L.deal_key[lane];
     if (kfin < s.kbest) { s.kbest = kfin; s.bslot = L.deal_slot[lane]; }
     const int cand = (int)L.own_cand[lane];
     if (cand > s.budget) s.alive = false;
     s.budget -= min(cand, s.budget);
-    __syncthreads();                                            // (the records are read: the next use of the arrays may write)
+    wave_lds_sync();                                            // (the records are read: the next use of the arrays may write)
 }
 
 // Grid part of one lane's search.  Returns true if the lane gave up (it must then walk the hierarchy from (best, bidx)).
@@ -794,14 +802,25 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
 #define MISLAM_GRID_MIN_WAVES 7
 #endif
 #define MI_GRID_OCC __attribute__((amdgpu_waves_per_eu(MISLAM_GRID_MIN_WAVES, 8)))
-template <bool FMA, bool FUSED, bool STATS>
-__global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridView g, NnTreeView t, GridSearchArgs a)
+// WAVES == 2 (fused iterations of SMALL clouds, nn_grid_query): a HELPER wave per workgroup.  A launch of a small cloud fits the chip
+// several times over and lasts as long as its longest wave -- at 1e5 points a chunk that scans and THEN walks for the lanes the grid cannot
+// serve: 11 us + 14 us on average, 38 at most, where a scan-only wave takes 12 (profiles/r04_wave_timeline_1e5.log).  The helper takes the
+// walks: in a chunk that scans, the lanes that ended beyond the grid's reach last time (far_lanes; they will again) walk THERE, at once,
+// while the first wave scans for the others -- max(scan, walk) instead of scan + walk; in a chunk that walks at once (class 2) the two waves
+// take half the lanes each.  The helper hands its answers over through LDS and returns; a chunk with nothing to help with loses its helper
+// at once.  Everything after the walk is the first wave's, unchanged -- an exact walk and an exact scan find the same neighbour, so the
+// keys and the rows are the same to the last bit (tests/test_gpu_icp.py).  Search at 1e4 / 1e5 / 3e5 points: 0.0245 -> 0.0178 / 0.0370 ->
+// 0.0295 / 0.0478 -> 0.0452 ms; from 4.5e5 on the helpers cost more slots than they save time (GRID_SPLIT_WALKS_MAX_POINTS).
+template <bool FMA, bool FUSED, bool STATS, int WAVES = 1>
+__global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel(NnGridView g, NnTreeView t, GridSearchArgs a)
 {
     static_assert(GRID_BLOCK == 64 && ICP_ROW_POINTS == 64, "one wave = one workgroup = one row of partial sums");
+    static_assert(WAVES == 1 || (WAVES == 2 && FUSED && !STATS), "the helper wave exists for fused iterations only");
     if (FUSED) {
         if (a.state->done != 0) return;
     } else if (a.done_flag != nullptr && *a.done_flag != 0) return;
-    const int tid = (int)threadIdx.x;
+    const int tid = (int)threadIdx.x & 63;
+    const int helper = WAVES == 2 ? (int)threadIdx.x >> 6 : 0;         // 1: the second wave of the workgroup
 #ifdef MISLAM_DEV_WAVE_TIMELINE        // developer build: per wave { start, end of scan, end } in 100 MHz ticks + walk steps (tools/wave_timeline.py)
     const unsigned long long tl_start = wall_clock64();
     unsigned long long tl_scan = 0, dev_tl[3] = {0, 0, 0}, tl_p1 = 0, tl_p2 = 0, tl_p3 = 0;
@@ -871,13 +890,24 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
     // all its lanes walk, each from its own starting candidate -- the walk is exact by itself, the few lanes the scan would have
     // served add little to the union the wave visits anyway, and the wave's critical path loses the scan (speed only).
     const bool walk_only = FUSED && (unsigned int)__builtin_amdgcn_readfirstlane((int)far_class) >= 2u;
-    if (walk_only) hard = valid;
+    // the lanes of this chunk whose answer came from a walk last time (they will walk again: the flags move slowly).  With a helper wave
+    // they walk THERE, at once, while the first wave scans for the others -- a chunk's chain is max(scan, walk) instead of scan + walk
+    unsigned long long predicted = 0ull;
+    if (WAVES == 2 && !walk_only) {
+        const unsigned long long w = a.far_lanes[chunk];
+        predicted = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(w >> 32)) << 32) |
+                    (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)w);
+    }
+    const bool mine_to_walk = WAVES == 2 && ((predicted >> tid) & 1ull) != 0ull;   // (of a scanning chunk: this lane is the helper's)
+    if (WAVES == 2 && helper != 0 && !walk_only && predicted == 0ull) return;   // (nothing to help with: the first wave scans alone, as ever)
+    if (walk_only) hard = valid && (WAVES == 1 || (tid >> 5) == helper);
+    else if (WAVES == 2 && helper != 0) hard = valid && mine_to_walk;
 #ifdef MISLAM_DEV_WAVE_TIMELINE
-    else hard = grid_search<FMA, STATS>(g, q, valid, near_word, best, bidx, bslot, n_cand, n_rows, a.deal_rows != 0, dev_tl) && valid;
+    else hard = grid_search<FMA, STATS>(g, q, valid && !mine_to_walk, near_word, best, bidx, bslot, n_cand, n_rows, a.deal_rows != 0, dev_tl) && valid && !mine_to_walk;
 #else
-    else hard = grid_search<FMA, STATS>(g, q, valid, near_word, best, bidx, bslot, n_cand, n_rows, a.deal_rows != 0) && valid;   // (all lanes: the loops run in step)
+    else hard = grid_search<FMA, STATS>(g, q, valid && !mine_to_walk, near_word, best, bidx, bslot, n_cand, n_rows, a.deal_rows != 0) && valid && !mine_to_walk;   // (all lanes: the loops run in step)
 #endif
-    const bool walked = __builtin_amdgcn_ballot_w64(hard) != 0ull;
+    bool walked = __builtin_amdgcn_ballot_w64(hard) != 0ull;
     // the first iterations of a registration move the cloud by many cells: the starting candidates (previous matches) are STALE, and a walk
     // that enters the children in index order meets the true neighbourhood late; there the nearest child goes first (a lane vote per step)
 #ifndef MISLAM_GRID_COLD_PASSES
@@ -888,6 +918,16 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
     tl_scan = wall_clock64();
 #endif
     if (hard) tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves, cold);
+    if (WAVES == 2 && (walk_only || predicted != 0ull)) {               // (workgroup-uniform: both waves are here)
+        __shared__ float x_best[64];
+        __shared__ unsigned int x_bidx[64];
+        const bool helpers = walk_only ? tid >= 32 : mine_to_walk;      // the lanes whose walk the helper wave took
+        if (helper != 0 && helpers) { x_best[tid] = best; x_bidx[tid] = bidx; }
+        __syncthreads();
+        if (helper != 0) return;
+        if (helpers) { best = x_best[tid]; bidx = x_bidx[tid]; hard = valid; }   // (their answers come from a walk)
+        walked = __builtin_amdgcn_ballot_w64(hard) != 0ull;
+    }
     // the point's index again, from the chunk number (a scalar) as far as the compiler can tell a different one: kept from the prologue it
     // would sit in two vector registers through the whole search, which is short of them
     unsigned int chunk_again = chunk;
@@ -954,6 +994,10 @@ __global__ __launch_bounds__(GRID_BLOCK) MI_GRID_OCC void nn_grid_kernel(NnGridV
             const float cap2 = cap * cap * (1.f - 1e-5f);
             const int beyond = (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && !(best <= cap2)));
             if (tid == 0) a.far[chunk] = beyond >= GRID_WALK_ONLY_MIN ? 2 : (walked ? 1 : 0);
+            // (the helper wave's share next time: the lanes the scan cannot serve -- NOT "the lanes that walked", which would keep every lane
+            // that ever walked walking for good)
+            const unsigned long long out_of_reach = __builtin_amdgcn_ballot_w64(valid && !(best <= cap2));
+            if (tid == 0 && a.far_lanes != nullptr) a.far_lanes[chunk] = out_of_reach;
         }
     }
 }
@@ -968,6 +1012,7 @@ hipError_t nn_grid_query(const NnGridView& g, const NnTreeView& t, const GridSea
     if (a.n <= 0) return hipSuccess;
     const dim3 grid((a.n + GRID_BLOCK - 1) / GRID_BLOCK), block(GRID_BLOCK);
     const bool fused = a.state != nullptr;
+    const bool helped = fused && a.stats == nullptr && a.split_walks != 0 && a.far_lanes != nullptr;   // two waves per workgroup (nn_grid_kernel<.., 2>)
     if (fused && (a.order == nullptr || a.far == nullptr || a.rows == nullptr || a.match_slot == nullptr)) return hipErrorInvalidValue;   // (the fused kernel does not test for them)
     const bool timed = e0 != nullptr && e1 != nullptr;
 #define MI_GRID_LAUNCH(F, U, S) do { if (timed) hipExtLaunchKernelGGL((nn_grid_kernel<F, U, S>), grid, block, 0, s, e0, e1, 0, g, t, a); \
@@ -975,6 +1020,12 @@ hipError_t nn_grid_query(const NnGridView& g, const NnTreeView& t, const GridSea
     if (a.stats != nullptr) {          // counting build of the same kernel (mi_profile_search_stats)
         if (fused) { if (fma) MI_GRID_LAUNCH(true, true, true); else MI_GRID_LAUNCH(false, true, true); }
         else { if (fma) MI_GRID_LAUNCH(true, false, true); else MI_GRID_LAUNCH(false, false, true); }
+    } else if (helped) {
+        const dim3 block2(2 * GRID_BLOCK);
+#define MI_GRID_LAUNCH2(F) do { if (timed) hipExtLaunchKernelGGL((nn_grid_kernel<F, true, false, 2>), grid, block2, 0, s, e0, e1, 0, g, t, a); \
+                                else hipLaunchKernelGGL((nn_grid_kernel<F, true, false, 2>), grid, block2, 0, s, g, t, a); } while (0)
+        if (fma) MI_GRID_LAUNCH2(true); else MI_GRID_LAUNCH2(false);
+#undef MI_GRID_LAUNCH2
     } else {
         if (fused) { if (fma) MI_GRID_LAUNCH(true, true, false); else MI_GRID_LAUNCH(false, true, false); }
         else { if (fma) MI_GRID_LAUNCH(true, false, false); else MI_GRID_LAUNCH(false, false, false); }

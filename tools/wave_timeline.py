@@ -42,6 +42,11 @@ with capi.Context(0) as ctx:
                   % (name, np.percentile(start[m], 50), np.percentile(start[m], 99), start[m].max(), (scan - start)[m].mean(),
                      np.percentile((scan - start)[m], 99), (end - scan)[m].mean(), np.percentile((end - scan)[m], 99), (end - scan)[m].max(),
                      np.percentile(end[m], 50), np.percentile(end[m], 99), end[m].max()))
+        for name, mm in (("walk-only waves", walk_only == 1), ("scan-then-walk waves", walked & (walk_only == 0))):
+            if mm.sum():
+                print("  %-20s %5d: steps mean %.1f p99 %d max %d | start->end mean %.1f p99 %.1f max %.1f | end p50 %.1f p99 %.1f max %.1f"
+                      % (name, mm.sum(), steps[mm].mean(), np.percentile(steps[mm], 99), steps[mm].max(), (end - start)[mm].mean(),
+                         np.percentile((end - start)[mm], 99), (end - start)[mm].max(), np.percentile(end[mm], 50), np.percentile(end[mm], 99), end[mm].max()))
         m = ~walked
         t_in, t_blk = (tl[:, 4] - t0) * 0.01, (tl[:, 5] - t0) * 0.01
         trips_b, trips_r, batches_r = tl[:, 6] & 0xffff, (tl[:, 6] >> 16) & 0xffff, (tl[:, 6] >> 32) & 0xffff
