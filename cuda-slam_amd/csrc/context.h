@@ -112,7 +112,7 @@ struct mi_ctx {
         float grid_points_per_cell = mislam::GRID_POINTS_PER_CELL;   // MISLAM_GRID_PPC
         int cpd_mfma = 1;                                // MISLAM_CPD_MFMA=0: VALU contraction instead of MFMA
         int fgt_resume = 1;                              // MISLAM_FGT_RESUME=0: re-cluster the fixed cloud from scratch every E-step
-        int grid_split_walks = -1;                       // MISLAM_GRID_SPLIT_WALKS=0 / 1: immediate walks of the fused search never / always split over two waves (default: by size)
+        int grid_split_walks = -1;                       // MISLAM_GRID_SPLIT_WALKS=0 / 1 / 2: the fused search's helper waves: none / for every walk / only beside a scan (default: by size)
         int grid_deal_rows = -1;                         // MISLAM_GRID_DEAL_ROWS=0 / 1: K1g's leftover rows never / always dealt out one per lane (default: by size)
         int icp_fused_solve = 1;                         // MISLAM_ICP_FUSED_SOLVE=0: rows reduce and solve as two launches at every size
         int icp_pipeline = 1;                            // MISLAM_ICP_PIPELINE=0: every host check of mi_icp_run settles the pending iteration and drains the stream

@@ -1158,7 +1158,7 @@ static int icp_enqueue_iteration(mi_ctx* c)
         a.rows = c->rows.p;
         a.order = c->sched_order.p; a.far = c->sched_far.p; a.far_lanes = c->sched_lanes.p;
         a.deal_rows = c->tune.grid_deal_rows < 0 ? (c->n >= GRID_DEAL_ROWS_MIN_POINTS ? 1 : 0) : c->tune.grid_deal_rows;
-        a.split_walks = c->tune.grid_split_walks < 0 ? (c->n <= GRID_SPLIT_WALKS_MAX_POINTS ? 1 : 0) : c->tune.grid_split_walks;
+        a.split_walks = c->tune.grid_split_walks < 0 ? (c->n <= GRID_HELPER_FULL_MAX_POINTS ? 1 : (c->n <= GRID_HELPER_MAX_POINTS ? 2 : 0)) : c->tune.grid_split_walks;
         hipEvent_t e0 = nullptr, e1 = nullptr;           // timed, if at all, by events attached to the launch itself (nn_grid_query)
         MI_TRY(c->prof_span(MI_KERNEL_NN, &e0, &e1));
         MI_HIP(nn_grid_query(c->grid, c->tree, a, v.fma, c->stream, e0, e1));

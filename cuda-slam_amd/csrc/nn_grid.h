@@ -21,7 +21,11 @@ constexpr int GRID_STATS_ROWS = 1024;         // mi_profile_search_stats: the co
 #endif
 constexpr float GRID_FAR_FACTOR = MISLAM_GRID_FAR_FACTOR;    // a starting candidate farther than this many times GRID_DU_MAX cells: straight to the hierarchy
 constexpr int GRID_DEAL_ROWS_MIN_POINTS = 900000;   // from this many moving points on, a wave's leftover rows are dealt out one per lane (nn_grid.hip; measured: -6 % at 7e5, +2 % at 1e6, +5 % at 3e6)
-constexpr int GRID_SPLIT_WALKS_MAX_POINTS = 350000;  // up to this many moving points a fused iteration runs a HELPER wave per workgroup (nn_grid.hip; measured: -27 % search time at 1e4, -20 % at 1e5, -5 % at 3e5, +7 % at 4.5e5)
+// helper waves of the fused search (nn_grid.hip) by the number of moving points: up to GRID_HELPER_FULL_MAX_POINTS for every walk (mode 1),
+// up to GRID_HELPER_MAX_POINTS only beside a scan (mode 2: chunks that walk at once keep to one wave), none beyond.  Measured search time,
+// modes 0 / 1 / 2: 1e5 0.0370 / 0.0281 / 0.0301 ms, 3e5 0.0487 / 0.0440 / 0.0425, 4.5e5 0.0545 / 0.0581 / 0.0536, 7e5 0.0649 / 0.0828 / 0.0755
+constexpr int GRID_HELPER_FULL_MAX_POINTS = 200000;
+constexpr int GRID_HELPER_MAX_POINTS = 450000;
 constexpr int GRID_CAND_BUDGET = 640;         // candidates a lane may test in the grid before it walks the hierarchy instead
 constexpr int GRID_BATCH = 4;                 // cell rows whose offsets a lane requests together, then scans as one flat run of candidates
 constexpr int GRID_PTS_PAD = 4;               // pts carries this many copies of its last entry: a lane fetches candidates four at a time

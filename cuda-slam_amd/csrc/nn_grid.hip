@@ -810,7 +810,7 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
 // take half the lanes each.  The helper hands its answers over through LDS and returns; a chunk with nothing to help with loses its helper
 // at once.  Everything after the walk is the first wave's, unchanged -- an exact walk and an exact scan find the same neighbour, so the
 // keys and the rows are the same to the last bit (tests/test_gpu_icp.py).  Search at 1e4 / 1e5 / 3e5 points: 0.0245 -> 0.0178 / 0.0370 ->
-// 0.0295 / 0.0478 -> 0.0452 ms; from 4.5e5 on the helpers cost more slots than they save time (GRID_SPLIT_WALKS_MAX_POINTS).
+// 0.0281 / 0.0487 -> 0.0425 ms; beyond 4.5e5 points the helpers cost more slots than they save time (nn_grid.h: modes by size).
 template <bool FMA, bool FUSED, bool STATS, int WAVES = 1>
 __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel(NnGridView g, NnTreeView t, GridSearchArgs a)
 {
@@ -830,6 +830,12 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
 #endif
     unsigned int chunk = xcd_chunk(blockIdx.x, gridDim.x, MISLAM_GRID_XCD_RUN);
     if (FUSED) chunk = (unsigned int)a.order[chunk];          // walking chunks first (IcpSchedule): speed only
+    if (WAVES == 2 && helper != 0) {
+        // a helper with nothing to help with leaves before it has loaded anything else (three chunks in four, late in a registration)
+        const unsigned int fc = a.far[chunk];
+        const unsigned long long fl = a.far_lanes[chunk];
+        if (fc < 2u ? fl == 0ull : a.split_walks == 2) return;   // (split_walks == 2: chunks that walk at once are left to their first wave)
+    }
     const int i = (int)(chunk * GRID_BLOCK) + tid;
     const bool valid = i < a.n;
     MI_TL_STAMP(tl_p1, i);
@@ -900,7 +906,8 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
     }
     const bool mine_to_walk = WAVES == 2 && ((predicted >> tid) & 1ull) != 0ull;   // (of a scanning chunk: this lane is the helper's)
     if (WAVES == 2 && helper != 0 && !walk_only && predicted == 0ull) return;   // (nothing to help with: the first wave scans alone, as ever)
-    if (walk_only) hard = valid && (WAVES == 1 || (tid >> 5) == helper);
+    const bool halves = WAVES == 2 && a.split_walks != 2;                  // a chunk that walks at once: half the lanes per wave
+    if (walk_only) hard = valid && (!halves || (tid >> 5) == helper);
     else if (WAVES == 2 && helper != 0) hard = valid && mine_to_walk;
 #ifdef MISLAM_DEV_WAVE_TIMELINE
     else hard = grid_search<FMA, STATS>(g, q, valid && !mine_to_walk, near_word, best, bidx, bslot, n_cand, n_rows, a.deal_rows != 0, dev_tl) && valid && !mine_to_walk;
@@ -918,7 +925,7 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
     tl_scan = wall_clock64();
 #endif
     if (hard) tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves, cold);
-    if (WAVES == 2 && (walk_only || predicted != 0ull)) {               // (workgroup-uniform: both waves are here)
+    if (WAVES == 2 && (walk_only ? halves : predicted != 0ull)) {       // (workgroup-uniform: both waves are here)
         __shared__ float x_best[64];
         __shared__ unsigned int x_bidx[64];
         const bool helpers = walk_only ? tid >= 32 : mine_to_walk;      // the lanes whose walk the helper wave took

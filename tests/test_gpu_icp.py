@@ -122,19 +122,20 @@ def test_one_launch_reduce_and_solve_is_the_two_launch_one(ctx, capi, monkeypatc
 
 @pytest.mark.parametrize("n", [100, 5000, 14904, 100000, 300000])
 def test_walks_split_over_two_waves_change_nothing(capi, monkeypatch, n):
-    # fused iterations of small clouds (up to 350 000 moving points) run a helper wave per workgroup that takes the walks -- of the lanes
+    # fused iterations of small clouds (up to 450 000 moving points) run a helper wave per workgroup that takes the walks -- of the lanes
     # beyond the grid's reach while the first wave scans for the others, or of half the lanes of a chunk that walks at once -- and hands its
     # answers to the first wave (round 4).  MISLAM_GRID_SPLIT_WALKS=0 / 1 (read at context creation) forces one / two waves at any size:
     # ten iterations from a start far enough out that most chunks walk, then converging -- the same bits
     before, after = synth_cloud(n, seed=n + 1)[:2]
     out = []
-    for split in ("0", "1"):
+    for split in ("0", "1", "2"):                                      # 2: helpers only beside a scan (the default between 200 000 and 450 000 points)
         monkeypatch.setenv("MISLAM_GRID_SPLIT_WALKS", split)
         with capi.Context(0) as c2:
-            out.append(c2.icp_register(before, after, capi.icp_params(eps=0.0, max_iterations=10)))
-            out.append(c2.icp_register(before, after, capi.icp_params(cuda_slam=True, eps=0.0, max_iterations=3, dist_mode=1)))
-    for a, b in ((out[0], out[2]), (out[1], out[3])):
-        assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[3] == b[3]
+            out.append((c2.icp_register(before, after, capi.icp_params(eps=0.0, max_iterations=10)),
+                        c2.icp_register(before, after, capi.icp_params(cuda_slam=True, eps=0.0, max_iterations=3, dist_mode=1))))
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[3] == b[3]
 
 
 @pytest.mark.parametrize("cuda_rules", [False, True])
