@@ -12,7 +12,8 @@
 namespace mislam {
 
 constexpr int RADIX_BITS = 10, RADIX_BUCKETS = 1 << RADIX_BITS;
-constexpr int RADIX_MAX_CHUNKS = 4096;                     // G * 1024 counters <= 2^22
+constexpr int RADIX_MAX_CHUNKS = 4096;                     // G * 1024 counters <= 2^22 (what the scratch is sized for)
+constexpr int RADIX_TARGET_CHUNKS = 1024;                  // chunks per pass: one wave each, ~1 000 elements at 1e6 -- the counter matrix stays at 4 MB
 
 template <bool SCATTER>
 __global__ __launch_bounds__(64) void radix_pass_kernel(const unsigned int* __restrict__ keys, const int* __restrict__ vals, int n, int shift,
@@ -29,23 +30,26 @@ __global__ __launch_bounds__(64) void radix_pass_kernel(const unsigned int* __re
         const bool valid = i < hi;
         const unsigned int key = valid ? keys[i] : 0u;
         const int val = valid ? vals[i] : 0;
-        const int dig = valid ? (int)((key >> shift) & (RADIX_BUCKETS - 1)) : -1;
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
-        while (todo != 0ull) {
-            const int leader = __builtin_ctzll(todo);
-            const int first = __builtin_amdgcn_readlane(dig, leader);
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(valid && dig == first);
-            todo &= ~m;
-            const int cnt = (int)__builtin_popcountll(m);
-            int before = 0;
-            if (lane == leader) { before = cur[first]; cur[first] = before + cnt; }
-            if (SCATTER) {
-                before = __builtin_amdgcn_readlane(before, leader);
-                if (valid && dig == first) {
-                    const int pos = before + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-                    keys_out[pos] = key;
-                    vals_out[pos] = val;
-                }
+        const int dig = (int)((key >> shift) & (RADIX_BUCKETS - 1));
+        // the lanes holding the same digit: one ballot per digit BIT (ten) -- not one round per distinct digit, of which a step's 64
+        // elements have ~60 (round 4; the member lists of cpd_fgt.hip learnt it first)
+        unsigned long long same = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; b++) {
+            const bool bit = ((dig >> b) & 1) != 0;
+            const unsigned long long with = __builtin_amdgcn_ballot_w64(bit);
+            same &= bit ? with : ~with;
+        }
+        const int cnt = (int)__builtin_popcountll(same);
+        const int rank = (int)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+        int before = 0;
+        if (valid && rank == 0) { before = cur[dig]; cur[dig] = before + cnt; }     // (the leaders of a step hold distinct digits)
+        if (SCATTER) {
+            before = __shfl(before, valid ? __builtin_ctzll(same) : lane, 64);
+            if (valid) {
+                const int pos = before + rank;
+                keys_out[pos] = key;
+                vals_out[pos] = val;
             }
         }
     }
@@ -99,7 +103,7 @@ hipError_t radix_sort_pairs_u32(void* temp, unsigned int* keys_in, unsigned int*
 {
     if (n <= 0) return hipSuccess;
     int chunk = 64, G = (n + chunk - 1) / chunk;
-    while (G > RADIX_MAX_CHUNKS) { chunk += 64; G = (n + chunk - 1) / chunk; }
+    while (G > RADIX_TARGET_CHUNKS) { chunk += 64; G = (n + chunk - 1) / chunk; }   // (G x 1 024 counters cross memory three times per pass)
     int* H = reinterpret_cast<int*>(temp);
     int* tot = H + (size_t)G * RADIX_BUCKETS;
     int* off = tot + RADIX_BUCKETS;
