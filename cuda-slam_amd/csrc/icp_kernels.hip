@@ -575,6 +575,7 @@ hipError_t icp_reduce_solve(IcpState* state, const double* rows, int nrows, int 
 {
     const int g = icp_reduced_count(nrows);
     const int per = (nrows + g - 1) / g;
+    if (nrows > ICP_FUSED_SOLVE_MAX_ROWS || per > ICP_FUSED_SOLVE_MAX_ROWS / ICP_REDUCED_ROWS) return hipErrorInvalidValue;   // (a slice must fit the kernel's registers)
     hipLaunchKernelGGL(icp_reduce_solve_kernel, dim3(1), dim3(ROWS_REDUCE_THREADS), 0, s, state, rows, nrows, per, g, compose_mode, rules, mark_pending);
     return hipGetLastError();
 }
