@@ -56,6 +56,18 @@ def test_oracle_cpd_matches_cpu_slam_on_the_sweep_clouds(oracle, cpd_sizes, n):
     assert abs(err - f["error"]) <= 1e-4 * f["error"] + 2e-5
 
 
+@pytest.mark.parametrize("n", [200, 500, 700, 1000])
+def test_oracle_hybrid_cpd_matches_cpu_slam_on_the_sweep_clouds(oracle, cpd_sizes, n):
+    # the parser's default approximation (FGT E-steps) on the same clouds, from the reference build (round 4)
+    g, z = cpd_sizes
+    f, p = g["cases"][str(n)]["hybrid"], g["params"]
+    b, a = z["before_%d" % n], z["after_%d" % n]
+    sR, t, it, err = oracle.cpd_approx(b, a, oracle.APPROX_HYBRID, eps=p["eps"], weight=p["weight"], const_scale=p["const_scale"],
+                                       max_iterations=p["max_iterations"], tolerance=p["tolerance"])[:4]
+    assert it == f["iterations"]
+    assert frob(sR, t, f["sR"], f["t"]) < 1e-4 and abs(err - f["error"]) <= 1e-4 * f["error"]
+
+
 # ---------------------------------------------------------------------------------------------------------------- GPU: the HIP path
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", [1, 3, 10])
@@ -99,3 +111,18 @@ def test_hip_cpd_matches_cpu_slam_on_the_sweep_clouds(ctx, capi, cpd_sizes, n):
         assert abs(err - f["error"]) <= 1e-4 * f["error"]
     else:
         assert 0.0 <= err <= 3e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [200, 500, 700, 1000])
+def test_hip_hybrid_cpd_matches_cpu_slam_on_the_sweep_clouds(ctx, capi, cpd_sizes, n):
+    # hybrid CPD (K9: K-centre sweeps -- replayed from the second E-step on --, member lists, model, predict) against cpu-slam's own run
+    g, z = cpd_sizes
+    f, pr = g["cases"][str(n)]["hybrid"], g["params"]
+    b, a = z["before_%d" % n], z["after_%d" % n]
+    p = capi.cpd_params(max_iterations=pr["max_iterations"], weight=pr["weight"], const_scale=0, eps=pr["eps"], tolerance=pr["tolerance"],
+                        sigma2_mode=capi.SIGMA2_CPU_SEQUENTIAL, approximation=capi.CPD_APPROX_HYBRID)
+    sR, t, scale, it, err = ctx.cpd_register(b, a, p)
+    d = frob(sR, t, f["sR"], f["t"])
+    print("HIP hybrid CPD vs cpu-slam, %d points: %d iterations, |d(sR|t)|_F = %.3e, sigma^2 %.6g vs %.6g" % (n, it, d, err, f["error"]))
+    assert it == f["iterations"] and d < 1e-4 and abs(err - f["error"]) <= 1e-4 * f["error"]
