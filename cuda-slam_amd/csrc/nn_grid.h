@@ -10,7 +10,7 @@ namespace mislam {
 
 constexpr int GRID_BLOCK = 64;             // moving points per workgroup: one wave = one row of ICP partial sums (icp_rows.hpp)
 constexpr int GRID_MAX_DIM = 1024;         // cells per axis: keeps the rounding of a cell coordinate (2^-23 * 1024) far below the 1e-3 slack
-constexpr float GRID_POINTS_PER_CELL = 1.5f;        // measured with the round-3 scan (profiles/r03_scan_forms.log): 2: 0.098, 1.5: 0.094, 1: 0.095, 0.75: 0.101 ms per search
+constexpr float GRID_POINTS_PER_CELL = 1.25f;       // round 3's scan liked 1.5 (profiles/r03_scan_forms.log); with row_occ and the dealt rows: 1e6 points 0.0824 ms per search at 1.25 against 0.0845 at 1.5 (five interleaved runs each), 1e7 0.796 against 0.814, 1e5 the same; 1.0: as 1.25; 0.75 and 2: worse (profiles/r04_search_experiments.log)
 #ifndef MISLAM_GRID_DU_MAX
 #define MISLAM_GRID_DU_MAX 2.0f
 #endif

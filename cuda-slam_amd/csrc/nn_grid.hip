@@ -278,7 +278,7 @@ __device__ __forceinline__ float gap_cells(float u, int i)
 //   * rows are named by a per-lane BIT MASK over the (2R+1)^2 rows around the query's own (R = GRID_REACH_CELLS): building it is
 //     arithmetic (two ranges, one multiply), and the wave steps through set bits only -- a row no lane needs costs nothing;
 //   * FIRST the 2 x 2 x 2 block of cells nearest to the query (its own cell and, on each axis, the neighbour on the side the query
-//     leans to): with 1.5 points per cell the neighbour is in there nine times out of ten, so the radius is tight before anything
+//     leans to): with 1.25 - 1.5 points per cell the neighbour is in there nine times out of ten, so the radius is tight before anything
 //     else is looked at -- whatever the starting candidate was worth; THEN the rows the shrunken radius still reaches, minus what
 //     the block covered;
 //   * GRID_BATCH rows at a time: their offsets are requested together (one round trip) and their points are ONE flat sequence of
