@@ -159,6 +159,66 @@ def cpu_baseline(np, before, after, target_seconds=15.0):
             "pairs_per_s": rows * m / dt}
 
 
+def cpu_baseline_direct(np, before, after):
+    """"time N = 10^4 and 10^5 directly" -- ONE whole correspondence search of the reference's cpu-slam (all source rows, all
+    targets: 1e8 / 1e10 pairs, ~0.01 / ~1 s on this box's pair rate), twice, the better one."""
+    from oracle import refbind, oraclebind
+    cores = os.cpu_count() or 1
+    if refbind.available():
+        kind, search = "reference", lambda: refbind.corresponding_points(before, after, 1000.0, True)
+    else:
+        kind, search = "port", lambda: oraclebind.nn_search(before, after, threads=0)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        search()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    n, m = len(before), len(after)
+    return {"value": 1.0 / best, "unit": "iterations/s", "cores": cores, "host_cpu_quota": host_cpu_budget(), "kind": kind,
+            "sample": "GetCorrespondingPoints (common.cpp:441-507, %d threads) on ALL %d source rows x %d targets, timed directly: %.4f s "
+                      "(the search is >99%% of a cpu-slam iteration)" % (cores, n, m, best),
+            "pairs_per_s": n * float(m) / best}
+
+
+def cpu_baseline_cpd(np, before, after, sigma2, weight=0.3):
+    """One EM iteration of the reference's cpu-slam CPD on the same clouds: ComputePMatrix (coherentpointdrift.cpp:168-221, one thread --
+    the reference's E-step is sequential) + MStep (:223-277)."""
+    from oracle import refbind, oraclebind
+    m, n = len(before), len(after)
+    c = oraclebind.cpd_constant(sigma2, weight, m, n)
+    kind, mod = ("reference", refbind) if refbind.available() else ("port", oraclebind)
+    t0 = time.perf_counter()
+    p1, pt1, px, L = mod.cpd_estep(before, after, c, sigma2)
+    t1 = time.perf_counter()
+    mod.cpd_mstep(before, after, p1, pt1, px, False)
+    t2 = time.perf_counter()
+    return {"value": 1.0 / (t2 - t0), "unit": "EM iterations/s", "cores": 1, "host_cpu_quota": host_cpu_budget(), "kind": kind,
+            "sample": "one ComputePMatrix (%d x %d affinities, %.2f s) + one MStep (%.4f s) of cpu-slam on the same clouds, single thread as the reference runs them"
+                      % (m, n, t1 - t0, t2 - t1),
+            "ms_per_em_iteration": (t2 - t0) * 1e3}
+
+
+def cpd_published_size(np, capi, ctx, n=49000, iterations=8):
+    """The size the reference publishes CPD times for (N = 49 000: doc/plots/ms-cpd-3.png, BASELINE.md section 1 -- exact P ~15 500 ms per
+    iteration on its GPU build, hybrid ~3 000 ms), on the synthetic recipe of the headline: `iterations` EM iterations each (no stop rule),
+    exact sigma^2_0, time per iteration as a caller sees it."""
+    before, after = synth_cloud(np, n)
+    out = {"workload": "cpd_synthetic_uniform_n%d" % n, "points": n,
+           "published_reference_ms_per_iteration": {"exact_gpu_rtx2060s": 15500, "exact_cpu": 31000, "hybrid_gpu_rtx2060s": 3000, "hybrid_cpu": 2100,
+                                                    "source": "doc/plots/ms-cpd-3.png (read off a log plot, +-10 %), BASELINE.md section 1; other hardware, allocation included"}}
+    for label, approx in (("exact", capi.CPD_APPROX_NONE), ("hybrid", capi.CPD_APPROX_HYBRID)):
+        p = capi.cpd_params(max_iterations=iterations, eps=0.0, tolerance=0.0, approximation=approx)
+        ctx.cpd_register(before, after, p)
+        walls = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            sR, t, scale, it, err = ctx.cpd_register(before, after, p)
+            walls.append((time.perf_counter() - t0) * 1e3)
+        out[label] = {"iterations": it, "ms_total": min(walls), "ms_per_em_iteration": min(walls) / max(it, 1), "final_sigma2": err}
+    return out
+
+
 def whole_call(np, capi, ctx, n, repeats=3):
     """One registration as the reference times it (testrunner.cpp:54-56, doc/documentation.tex:397): mi_icp_register on HOST buffers,
     upload / index builds / 50 iterations / result included, GPU-reference driver rules and sweep settings (testset.cpp:82-117).
@@ -281,18 +341,61 @@ def cpd_bunny(np, capi, ctx, world):
     return out
 
 
+def loaded_runtimes():
+    """Every libamdhip64 / librccl object mapped into this process (/proc/self/maps): more than one of a kind means two ROCm runtimes."""
+    import re
+    found = {"hip": set(), "rccl": set()}
+    try:
+        for line in open("/proc/self/maps"):
+            m = re.search(r"(/\S*/(libamdhip64|librccl)[^/\s]*)", line)
+            if m:
+                found["hip" if m.group(2) == "libamdhip64" else "rccl"].add(os.path.realpath(m.group(1)))
+    except OSError:
+        pass
+    return {k: sorted(v) for k, v in found.items()}
+
+
+def runtime_report(capi):
+    """What the process actually resolved: the objects libmislam.so's HIP / RCCL calls bind to, their versions, and
+    every copy of those libraries that is mapped.  `conflict`: a reason to refuse to start, or None.
+
+    The decision: under a launcher the ranks import torch FIRST (gloo bootstrap); torch/lib carries libamdhip64.so and
+    librccl.so under the SONAMEs libmislam.so asks for (libamdhip64.so.7, librccl.so.1), so the dynamic loader hands libmislam.so those
+    already-mapped objects -- ONE runtime in the process, torch's.  That order is what the world-1 RCCL rehearsals ran.  What must never
+    happen is two different RCCL (or HIP) objects of different versions mapped at once: then libmislam.so's communicator and the other
+    copy each run their own runtime state on the same devices."""
+    import ctypes
+    info = capi.runtime_info()
+    maps = loaded_runtimes()
+    rep = {"libmislam_binds": info, "mapped": maps, "torch_imported_first": "torch" in sys.modules}
+    conflict = None
+    for kind, sym in (("rccl", "ncclGetVersion"), ("hip", "hipRuntimeGetVersion")):
+        if len(maps[kind]) > 1:
+            versions = {}
+            for path in maps[kind]:
+                try:
+                    v = ctypes.c_int(0)
+                    getattr(ctypes.CDLL(path), sym)(ctypes.byref(v))
+                    versions[path] = v.value
+                except Exception as e:      # noqa: BLE001
+                    versions[path] = "unreadable: %s" % e
+            rep[kind + "_versions"] = versions
+            if len(set(versions.values())) > 1:
+                conflict = "two different %s runtimes are mapped: %s" % (kind.upper(), versions)
+    rep["conflict"] = conflict
+    return rep
+
+
 def self_launch(n_ranks):
     """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks as a fresh child process tree -- `python -m
     torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`, the driver's own launch line -- relay rank 0's
     JSON line and return the child's exit code.  A child, not an exec; called before this process has imported the package or
     touched the GPU."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_ranks, "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher binds its own rendezvous to a free port (no pre-picked port another process could take between a probe
+    # and the launcher's bind -- ADVICE r04); --local-addr: the workers' MASTER_ADDR, an address that resolves everywhere
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node=%d" % n_ranks,
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
@@ -373,6 +476,11 @@ def main():
     import numpy as np
     from __graft_entry__ import load_package
     capi = load_package().capi
+    # which ROCm runtime(s) this process holds, BEFORE any device call: two different RCCL / HIP objects mapped at once = refuse to start
+    runtime = runtime_report(capi)
+    if use_dist and runtime["conflict"]:
+        sys.stderr.write("bench.py rank %d: %s -- refusing to start (see runtime_report in bench.py)\n" % (rank, runtime["conflict"]))
+        sys.exit(3)
 
     # Rehearsal of the N > 1 flow on a box with ONE GPU (tools/gpu_dist_rehearsal.sh): MISLAM_BENCH_DEVICE pins every rank to
     # that device and MISLAM_BENCH_TRANSPORT=gloo swaps RCCL (which refuses two ranks on one device) for the caller's-transport
@@ -552,6 +660,8 @@ def main():
             sizes[str(sn)] = {"iterations_per_s": 10 / s_el, "ms_per_step": s_el / 10 * 1e3, "steps": 10, "warmup": 5,
                               "nn_kernel": fig["kernel"], "nn_avg_launch_ms": fig["avg_launch_ms"], "hbm_achieved_GBs": fig["achieved"],
                               "hbm_frac": fig["frac"]}
+            if rank == 0 and world == 1 and not args.no_cpu_baseline and sn <= 100000:
+                sizes[str(sn)]["cpu_baseline"] = cpu_baseline_direct(np, sb, sa)      # 1e4 and 1e5 timed directly
             del sb, sa
 
     # Outside the timed region as well: the CPD leg of BASELINE.json's metric ("CPD E-step on bunny"), cfg 4 on the committed
@@ -560,11 +670,39 @@ def main():
     cpd = None
     if not args.no_cpd and (world == 1 or os.environ.get("MISLAM_BENCH_CPD") == "1"):
         cpd = cpd_bunny(np, capi, ctx, world)
+        if world == 1 and rank == 0 and not args.no_cpu_baseline:
+            z = np.load(os.path.join(ROOT, "tests", "golden", "bunny_clouds.npz"))
+            s2 = json.load(open(os.path.join(ROOT, "tests", "golden", "bunny_cpd.json")))["sigma2_init"]
+            cpd["cpu_baseline"] = cpu_baseline_cpd(np, z["before"], z["after"], s2)
+        if world == 1:
+            cpd["published_size"] = cpd_published_size(np, capi, ctx)
 
     # Outside the timed region too: whole registrations on host buffers, as the reference times a SlamFunc
     whole = None
     if world == 1 and not args.no_whole_call:
         whole = {str(wn): whole_call(np, capi, ctx, wn) for wn in (100000, 1000000)}
+
+    # The floor of the headline path's collective: the 64 x 18-double sum of one iteration through a ONE-rank RCCL communicator, event-timed
+    # (what ncclAllReduce costs on this stream before a single byte crosses xGMI).  N = 1 only, outside the timed region, never fatal.
+    allreduce_floor = None
+    if world == 1 and not use_dist and os.environ.get("MISLAM_BENCH_NO_RCCL_FLOOR") != "1":
+        try:
+            dctx = capi.Context(local_rank, 0, 1, capi.dist_unique_id())
+            fb, fa = synth_cloud(np, 100000)
+            dctx.icp_load(fb, fa, capi.icp_params(eps=0.0, max_iterations=-1, shard_mode=capi.SHARD_SOURCE, sync_every=8))
+            dctx.icp_run(4)
+            dctx.profile_enable(True)
+            dctx.profile_select([capi.KERNEL_ALLREDUCE])
+            dctx.profile_reset()
+            dctx.icp_run(16)
+            ar = dctx.profile_get(capi.KERNEL_ALLREDUCE)
+            dctx.profile_enable(False)
+            dctx.close()
+            allreduce_floor = {"ranks": 1, "launches": ar[1], "ms_per_launch": ar[0] / max(ar[1], 1), "payload_bytes": 8 * 18 * 64,
+                               "note": "ncclAllReduce(ncclDouble, ncclSum) of the 64 reduced rows on a one-rank communicator, HIP events around it: the latency floor of "
+                                       "the one collective an iteration of the headline path issues; every rank beyond one adds xGMI hops to it"}
+        except Exception as e:      # noqa: BLE001
+            allreduce_floor = {"error": str(e)}
 
     if rank == 0:
         workload = "icp_synthetic_uniform_n%d" % n
@@ -623,6 +761,21 @@ def main():
                                               "behind all of them: every batch ends in a flush (transform + error of the last iteration) and a 256-byte read-back"},
             "kernels_ms_per_step": breakdown,     # ms per launch, from the untimed follow-up iterations (every kernel event-timed)
         }
+        out["runtime"] = runtime
+        if allreduce_floor is not None:
+            out["allreduce_f64_sum_floor"] = allreduce_floor
+        if world > 1 or use_dist:
+            # what to expect BEFORE reading the first multi-GPU numbers: from the one-GPU emulation of a rank's share
+            # (tools/search_vs_queries.py, profiles/r04_search_vs_queries.log): the search of the indexed path shrinks with the rank's share of the
+            # moving cloud, the other ~0.02 ms of a step (rows reduce + solve + launch boundaries) and the all-reduce do not
+            emu = {1000000: {1: 0.0819 + 0.0187, 2: 0.0609 + 0.0230, 4: 0.0488 + 0.0221, 8: 0.0418 + 0.0214},
+                   10000000: {1: 0.8159 + 0.0898, 2: 0.4230 + 0.0638, 4: 0.2218 + 0.0296, 8: 0.1294 + 0.0282}}
+            out["expected_scaling"] = {
+                "source": "profiles/r04_search_vs_queries.log (one GPU running one rank's share; all-reduce latency NOT included)",
+                "speedup_upper_bound": {str(pts): {str(w): round(t[1] / t[w], 2) for w in t} for pts, t in emu.items()},
+                "note": "strong scaling of an indexed search at 1e6 points is latency-limited (<= 1.6x on 8 GPUs before the all-reduce is paid): a launch cannot be shorter "
+                        "than its longest wave; 1e7 points (sizes['10000000'] in this line, the same --gpus) is the size where a curve can show (~5.8x at 8); cfg 3 as "
+                        "BASELINE.json words it (target-sharded every-pair search: `target_sharded`) scales ~linearly but is two orders of magnitude slower than one GPU's grid"}
         if use_dist and rehearsal_transport == "gloo":
             out["rehearsal"] = "ranks share device %d over the gloo exchange context: flow check only, not a measurement" % local_rank
         if whole is not None:

@@ -32,7 +32,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int) 
 # every symbol include/mi_slam.h declares (tests check that the library exports each of them)
 EXPORTS = [
     "mi_abi_version", "mi_last_error", "mi_device_count", "mi_ctx_create", "mi_dist_unique_id", "mi_ctx_create_dist",
-    "mi_ctx_create_exchange", "mi_ctx_preload", "mi_ctx_rank", "mi_dist_info", "mi_shard_range", "mi_source_share", "mi_pack_key", "mi_unpack_key", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_icp_params_default", "mi_icp_params_cuda_slam",
+    "mi_ctx_create_exchange", "mi_runtime_info", "mi_ctx_preload", "mi_ctx_rank", "mi_dist_info", "mi_shard_range", "mi_source_share", "mi_pack_key", "mi_unpack_key", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_icp_params_default", "mi_icp_params_cuda_slam",
     "mi_icp_register", "mi_icp_load", "mi_icp_reset", "mi_icp_run", "mi_icp_auto_batch", "mi_icp_result", "mi_nn_search", "mi_nn_search_ex", "mi_cross_moments", "mi_kabsch",
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_sigma_squared_mode", "mi_cpd_estep",
     "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_kcenter_guided", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
@@ -194,6 +194,15 @@ def dist_unique_id():
     buf = C.create_string_buffer(UNIQUE_ID_BYTES)
     _check(lib().mi_dist_unique_id(buf))
     return buf.raw
+
+
+def runtime_info():
+    """{hip_path, rccl_path, hip_runtime_version, rccl_version}: the shared objects libmislam.so's HIP / RCCL calls bind to in this
+    process (mi_runtime_info; no device touched)."""
+    hip, rccl = C.create_string_buffer(1024), C.create_string_buffer(1024)
+    hv, rv = C.c_int(0), C.c_int(0)
+    _check(lib().mi_runtime_info(hip, rccl, 1024, C.byref(hv), C.byref(rv)))
+    return {"hip_path": hip.value.decode(), "rccl_path": rccl.value.decode(), "hip_runtime_version": hv.value, "rccl_version": rv.value}
 
 
 def _T_to_Rt(T):

@@ -111,9 +111,11 @@ struct mi_ctx {
         int nn_R = 2, nn_wgs = 0, nn_chunks = 0;         // MISLAM_NN_R / _WGS / _CHUNKS: K1 sources per lane, workgroup budget, target chunks
         float grid_points_per_cell = mislam::GRID_POINTS_PER_CELL;   // MISLAM_GRID_PPC
         int cpd_mfma = 1;                                // MISLAM_CPD_MFMA=0: VALU contraction instead of MFMA
+        int cpd_trunc_cull = 1;                          // MISLAM_CPD_TRUNC_CULL=0: the hybrid mode's truncated E-step over every pair (round 4's kernels) instead of K7t
         int fgt_resume = 1;                              // MISLAM_FGT_RESUME=0: re-cluster the fixed cloud from scratch every E-step
         int grid_split_walks = -1;                       // MISLAM_GRID_SPLIT_WALKS=0 / 1 / 2: the fused search's helper waves: none / for every walk / only beside a scan (default: by size)
         int grid_deal_rows = -1;                         // MISLAM_GRID_DEAL_ROWS=0 / 1: K1g's leftover rows never / always dealt out one per lane (default: by size)
+        int svd_ieee = 0;                                // MISLAM_SVD_IEEE=1: the 3 x 3 SVD of every solve in IEEE divisions and roots (svd3.hpp)
         int icp_fused_solve = 1;                         // MISLAM_ICP_FUSED_SOLVE=0: rows reduce and solve as two launches at every size
         int icp_pipeline = 1;                            // MISLAM_ICP_PIPELINE=0: every host check of mi_icp_run settles the pending iteration and drains the stream
         int fgt_replay = 1;                              // MISLAM_FGT_REPLAY=0: sweep the moving cloud step by step every E-step (no guess replayed)

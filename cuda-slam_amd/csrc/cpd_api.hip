@@ -58,12 +58,22 @@ struct CpdWorkspace {
     DevBuf<float4> xw4;
     DevBuf<double> part_x, part_k, part_init;
     DevBuf<unsigned char> sig_scratch;   // cpd_sigma2_sequential
+    // K7t (cpd_trunc.hip): both clouds along a space-filling curve -- the orders (once per load), the fixed cloud's sorted copy and boxes (once),
+    // the moving cloud's current positions in curve order and their boxes (every truncated E-step)
+    DevBuf<float> t_ax, t_ay, t_az, t_yx, t_yy, t_yz, t_abox, t_ybox, t_bbox;
+    DevBuf<int> t_aorder, t_border, t_order_tmp;
+    DevBuf<unsigned int> t_codes_in, t_codes_out;
+    DevBuf<unsigned char> t_sort;
+    DevBuf<float4> t_xw4;
+    bool trunc_ready = false;                 // the orders and the fixed cloud's sorted copy belong to the clouds now loaded
     CpdState* d_state = nullptr;
     CpdState* h_state = nullptr;
     int m = 0, n = 0, m_pad = 0, n_pad = 0;   // n = this rank's share of the fixed cloud
     int n_total = 0;                          // |after| over all ranks
+    int svd_ieee = 0;                         // the context's MISLAM_SVD_IEEE switch (set where the workspace is fetched)
     int k_chunks = 1, k_chunk_len = 0, x_chunks = 1, x_chunk_len = 0;
     bool sums_fresh = false;                  // the last exact E-step left the M-step's x-sums and k-sums in part_x / part_k
+    int sum_rows_x = 0, sum_rows_k = 0;       // ... in this many rows each
     bool replicated = false;                  // multi-rank context, but this registration runs whole on every rank (the FGT modes): no collective
     mi_cpd_params params{};
 };
@@ -75,6 +85,9 @@ void cpd_workspace_destroy(mi_ctx* c)
     w->ax.release(); w->ay.release(); w->az.release();
     w->den_part.release(); w->pt1.release(); w->p1_part.release(); w->px_part.release(); w->p1.release(); w->px.release();
     w->xw4.release(); w->part_x.release(); w->part_k.release(); w->part_init.release();
+    w->t_ax.release(); w->t_ay.release(); w->t_az.release(); w->t_yx.release(); w->t_yy.release(); w->t_yz.release();
+    w->t_abox.release(); w->t_ybox.release(); w->t_bbox.release(); w->t_aorder.release(); w->t_border.release(); w->t_order_tmp.release();
+    w->t_codes_in.release(); w->t_codes_out.release(); w->t_sort.release(); w->t_xw4.release();
     w->fgt.release();
     if (w->d_state) (void)hipFree(w->d_state);
     if (w->h_state) (void)hipHostFree(w->h_state);
@@ -92,6 +105,7 @@ static int cpd_workspace(mi_ctx* c, CpdWorkspace** out)
         MI_HIP(hipHostMalloc((void**)&c->cpd->h_state, sizeof(CpdState), hipHostMallocDefault));
         memset(c->cpd->h_state, 0, sizeof(CpdState));
     }
+    c->cpd->svd_ieee = c->tune.svd_ieee;
     *out = c->cpd;
     return MI_OK;
 }
@@ -114,6 +128,7 @@ static int cpd_load(mi_ctx* c, CpdWorkspace* w, const float* before_xyz, int m, 
     w->fgt.y.guess_K = 0;    // a new moving cloud: nothing to guess its sweep from
     w->fgt.y.prelaunched = 0;
     w->m = m; w->n = n; w->n_total = n;
+    w->trunc_ready = false;
     w->m_pad = round_up_i(m, NN_SRC_PAD);
     w->n_pad = round_up_i(n, NN_SRC_PAD);
     const size_t mp = (size_t)w->m_pad, np = (size_t)w->n_pad;
@@ -129,8 +144,8 @@ static int cpd_load(mi_ctx* c, CpdWorkspace* w, const float* before_xyz, int m, 
     MI_TRY(w->px_part.reserve((size_t)w->x_chunks * 3 * m));
     MI_TRY(w->p1.reserve(mp));
     MI_TRY(w->px.reserve(3 * mp));
-    MI_TRY(w->part_x.reserve((size_t)ICP_MAX_PARTIAL_BLOCKS * CPD_XSUMS));
-    MI_TRY(w->part_k.reserve((size_t)ICP_MAX_PARTIAL_BLOCKS * CPD_KSUMS));
+    MI_TRY(w->part_x.reserve((size_t)std::max(ICP_MAX_PARTIAL_BLOCKS, CPD_TRUNC_MAX_BLOCKS) * CPD_XSUMS));
+    MI_TRY(w->part_k.reserve((size_t)std::max(ICP_MAX_PARTIAL_BLOCKS, CPD_TRUNC_MAX_BLOCKS) * CPD_KSUMS));
     MI_TRY(w->part_init.reserve((size_t)ICP_MAX_PARTIAL_BLOCKS * CPD_INIT_SUMS));
     MI_TRY(upload_soa(c, before_xyz, m, w->m_pad, c->bx.p, c->by.p, c->bz.p, nullptr));
     MI_TRY(upload_soa(c, after_xyz, n, w->n_pad, w->ax.p, w->ay.p, w->az.p, nullptr));
@@ -169,6 +184,7 @@ static CpdRules cpd_rules(const CpdWorkspace* w, const mi_cpd_params* p)
     r.const_scale = p->const_scale;
     r.max_iterations = p->max_iterations;
     r.m = w->m; r.n = w->n_total;
+    r.svd_ieee = w->svd_ieee;
     return r;
 }
 
@@ -186,17 +202,75 @@ static int cpd_estep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
     { ProfScope ps(c, MI_KERNEL_CPD_CONTRACT); MI_HIP(cpd_contract(v, use_mfma_contraction(c), c->stream)); }
     MI_HIP(cpd_post_contract(v, c->stream, w->part_k.p, nkb));
     w->sums_fresh = true;
+    w->sum_rows_x = nxb; w->sum_rows_k = nkb;
+    return MI_OK;
+}
+
+// K7t: the hybrid mode's truncated E-step, culled (cpd_trunc.hip).  MISLAM_CPD_TRUNC_CULL=0: round 4's every-pair truncated kernels.
+static int cpd_trunc_tiles(int n) { return (n + CPD_TRUNC_TILE - 1) / CPD_TRUNC_TILE; }
+static int cpd_trunc_supers(int n) { return (cpd_trunc_tiles(n) + CPD_TRUNC_SUPER - 1) / CPD_TRUNC_SUPER; }
+
+static int cpd_trunc_prepare(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
+{
+    if (w->trunc_ready) return MI_OK;
+    const int big = std::max(w->m, w->n);
+    MI_TRY(w->t_bbox.reserve(256 * 6 + 6));
+    MI_TRY(w->t_codes_in.reserve(big)); MI_TRY(w->t_codes_out.reserve(big)); MI_TRY(w->t_order_tmp.reserve(big));
+    MI_TRY(w->t_sort.reserve(std::max<size_t>(tree_sort_temp_bytes(big), 16)));
+    MI_TRY(w->t_aorder.reserve(w->n)); MI_TRY(w->t_border.reserve(w->m));
+    const size_t na = (size_t)cpd_trunc_tiles(w->n) * CPD_TRUNC_TILE, ny = (size_t)cpd_trunc_tiles(w->m) * CPD_TRUNC_TILE;
+    MI_TRY(w->t_ax.reserve(na)); MI_TRY(w->t_ay.reserve(na)); MI_TRY(w->t_az.reserve(na)); MI_TRY(w->t_xw4.reserve(na));
+    MI_TRY(w->t_yx.reserve(ny)); MI_TRY(w->t_yy.reserve(ny)); MI_TRY(w->t_yz.reserve(ny));
+    MI_TRY(w->t_abox.reserve(6 * ((size_t)cpd_trunc_tiles(w->n) + cpd_trunc_supers(w->n))));
+    MI_TRY(w->t_ybox.reserve(6 * ((size_t)cpd_trunc_tiles(w->m) + cpd_trunc_supers(w->m))));
+    // the fixed cloud along its curve; the moving cloud along the curve of its ORIGINAL points (a similarity transform keeps neighbours together)
+    MortonArgs ma{};
+    ma.bbox_partials = w->t_bbox.p; ma.bbox = w->t_bbox.p + 256 * 6;
+    ma.codes_in = w->t_codes_in.p; ma.codes_out = w->t_codes_out.p; ma.order_in = w->t_order_tmp.p;
+    ma.sort_temp = w->t_sort.p; ma.sort_temp_bytes = w->t_sort.cap;
+    ma.x = v.ax; ma.y = v.ay; ma.z = v.az; ma.m = w->n; ma.order_out = w->t_aorder.p;
+    MI_HIP(morton_order(ma, c->stream));
+    ma.x = v.bx; ma.y = v.by; ma.z = v.bz; ma.m = w->m; ma.order_out = w->t_border.p;
+    MI_HIP(morton_order(ma, c->stream));
+    MI_HIP(cpd_trunc_gather(v.ax, v.ay, v.az, w->t_aorder.p, w->n, w->t_ax.p, w->t_ay.p, w->t_az.p, w->t_abox.p,
+                            w->t_abox.p + 6 * (size_t)cpd_trunc_tiles(w->n), nullptr, c->stream));
+    w->trunc_ready = true;
+    return MI_OK;
+}
+
+static int cpd_estep_trunc_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
+{
+    MI_TRY(cpd_trunc_prepare(c, w, v));
+    CpdTruncView t{};
+    t.state = v.state;
+    t.ax = w->t_ax.p; t.ay = w->t_ay.p; t.az = w->t_az.p;
+    t.abox = w->t_abox.p; t.asuper = w->t_abox.p + 6 * (size_t)cpd_trunc_tiles(w->n);
+    t.a_order = w->t_aorder.p; t.n = w->n;
+    t.yx = w->t_yx.p; t.yy = w->t_yy.p; t.yz = w->t_yz.p;
+    t.ybox = w->t_ybox.p; t.ysuper = w->t_ybox.p + 6 * (size_t)cpd_trunc_tiles(w->m);
+    t.b_order = w->t_border.p; t.m = w->m;
+    t.bx = v.bx; t.by = v.by; t.bz = v.bz;
+    t.xw4 = w->t_xw4.p; t.pt1 = v.pt1; t.p1 = v.p1; t.px = v.px;
+    t.trunc_log = v.trunc_log;
+    const int nxb = std::min(CPD_TRUNC_MAX_BLOCKS, cpd_trunc_tiles(w->n)), nkb = std::min(CPD_TRUNC_MAX_BLOCKS, cpd_trunc_tiles(w->m));
+    // the moving cloud's current positions in curve order + this E-step's boxes
+    MI_HIP(cpd_trunc_gather(v.yx, v.yy, v.yz, w->t_border.p, w->m, w->t_yx.p, w->t_yy.p, w->t_yz.p, w->t_ybox.p,
+                            w->t_ybox.p + 6 * (size_t)cpd_trunc_tiles(w->m), v.state, c->stream));
+    { ProfScope ps(c, MI_KERNEL_CPD_DENOM); MI_HIP(cpd_trunc_denominators(t, w->part_x.p, nxb, c->stream)); }
+    { ProfScope ps(c, MI_KERNEL_CPD_CONTRACT); MI_HIP(cpd_trunc_contract(t, w->part_k.p, nkb, c->stream)); }
+    w->sums_fresh = true;
+    w->sum_rows_x = nxb; w->sum_rows_k = nkb;
     return MI_OK;
 }
 
 static int cpd_mstep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const CpdRules& rules, int update_loop_state)
 {
-    const int nxb = cpd_sum_blocks(w->n), nkb = cpd_sum_blocks(w->m);
+    int nxb = cpd_sum_blocks(w->n), nkb = cpd_sum_blocks(w->m);
     ProfScope ps(c, MI_KERNEL_CPD_MSTEP);
     if (!w->sums_fresh) {
         MI_HIP(cpd_xsums(v, w->part_x.p, nxb, c->stream));
         MI_HIP(cpd_ksums(v, w->part_k.p, nkb, c->stream));
-    }
+    } else { nxb = w->sum_rows_x; nkb = w->sum_rows_k; }     // (the rows the E-step's own kernels left)
     w->sums_fresh = false;
     if (!c->distributed() || w->replicated) {
         MI_HIP(cpd_solve(w->d_state, w->part_x.p, nxb, w->part_k.p, nkb, rules, update_loop_state, c->stream));
@@ -492,7 +566,8 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
                     CpdView vt = v;
                     vt.truncate = 1;
                     vt.trunc_log = std::log(1e-3f);                // ComputePMatrix(..., true, 1e-3f), :166 / :182-183
-                    MI_TRY(cpd_estep_enqueue(c, w, vt));
+                    if (c->tune.cpd_trunc_cull != 0) MI_TRY(cpd_estep_trunc_enqueue(c, w, vt));
+                    else MI_TRY(cpd_estep_enqueue(c, w, vt));
                 }
             }
             MI_TRY(cpd_mstep_enqueue(c, w, v, rules, 1));
@@ -582,7 +657,8 @@ static int estep_primitive(mi_ctx* c, const float* y_xyz, int m, const float* x_
             v.truncate = 1;
             v.trunc_log = std::log(truncate);
         }
-        MI_TRY(cpd_estep_enqueue(c, w, v));
+        if (mode == 1 && c->tune.cpd_trunc_cull != 0) MI_TRY(cpd_estep_trunc_enqueue(c, w, v));
+        else MI_TRY(cpd_estep_enqueue(c, w, v));
     }
     w->sums_fresh = false;               // (a stand-alone E-step: nothing of it is carried into a later M-step call)
     const int nxb = cpd_sum_blocks(n);

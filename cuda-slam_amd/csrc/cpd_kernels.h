@@ -37,6 +37,7 @@ struct CpdRules {
     float eps, weight, tolerance;
     int const_scale, max_iterations;
     int m, n;
+    int svd_ieee;                    // developer switch MISLAM_SVD_IEEE=1 (svd3.hpp kabsch_rotation)
 };
 
 struct CpdView {
@@ -62,6 +63,33 @@ struct CpdView {
     int truncate;
     float trunc_log;
 };
+
+// K7t: the truncated E-step of the hybrid mode, culled by tile boxes along a space-filling curve (cpd_trunc.hip)
+constexpr int CPD_TRUNC_TILE = 64;        // points per tile = one wave
+constexpr int CPD_TRUNC_SUPER = 16;       // tiles per super-tile (one more level of boxes: 1 024 points skipped per test)
+constexpr int CPD_TRUNC_MAX_BLOCKS = 4096;   // workgroups (= rows of M-step partial sums) of its two kernels
+struct CpdTruncView {
+    CpdState* state;
+    // fixed cloud in curve order (padded to whole tiles), its tile / super-tile boxes, sorted slot -> caller's index
+    const float *ax, *ay, *az;
+    const float *abox, *asuper;
+    const int* a_order;
+    int n;
+    // moving cloud: CURRENT positions in the curve order of the original cloud (padded to whole tiles), boxes of this E-step, slot -> caller's index
+    const float *yx, *yy, *yz;
+    const float *ybox, *ysuper;
+    const int* b_order;
+    int m;
+    const float *bx, *by, *bz;            // the original moving cloud, caller's order (M-step k-sums)
+    float4* xw4;                          // [n] curve order: (w*ax, w*ay, w*az, w), w = 1/den_x
+    float *pt1, *p1, *px;                 // caller's order, as CpdView
+    float trunc_log;
+};
+// out = in[order] (padded to whole tiles with copies of the last point), tile and super-tile boxes; state != null: nothing once it says done
+hipError_t cpd_trunc_gather(const float* x, const float* y, const float* z, const int* order, int n, float* ox, float* oy, float* oz,
+                            float* tile_box, float* super_box, const CpdState* state, hipStream_t s);
+hipError_t cpd_trunc_denominators(const CpdTruncView& v, double* xpartials, int nblocks, hipStream_t s);   // den, Pt1, xw4 + the M-step's x-sums
+hipError_t cpd_trunc_contract(const CpdTruncView& v, double* kpartials, int nblocks, hipStream_t s);       // P1, PX + the M-step's k-sums
 
 hipError_t cpd_init_sums(const CpdView& v, double* partials, int nblocks, hipStream_t s);
 // sigma2_override > 0: use it; sigma2_from_state: use the value cpd_sigma2_sequential left in state->sigma2_init; else the exact

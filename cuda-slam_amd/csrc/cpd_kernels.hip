@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void cpd_solve_kernel(CpdState* __restrict__ s
     Mat3 A;   // (EigenBefore * px)^T - Np * centerAfter * centerBefore^T
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) A.a[r][c] = (float)ks[4 + 3 * c + r] - Np * (ca[r] * cb[c]);
-    const Kabsch3 kb = kabsch_rotation<true>(A);     // (svd3.hpp SvdMath: the one-lane chain, as in the ICP solve)
+    const Kabsch3 kb = kabsch_rotation<true>(A, rules.svd_ieee != 0);     // (svd3.hpp SvdMath: the one-lane chain, as in the ICP solve)
     const float scaleNumerator = (kb.S[0] + kb.S[1]) + kb.S[2] * kb.det;
     const float sigmaSubtrahend = (float)xs[4] - Np * ((ca[0] * ca[0] + ca[1] * ca[1]) + ca[2] * ca[2]);
     const float scaleDenominator = (float)ks[13] - Np * ((cb[0] * cb[0] + cb[1] * cb[1]) + cb[2] * cb[2]);

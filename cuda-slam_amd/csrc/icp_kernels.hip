@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64) void icp_rows_to_state_kernel(IcpState* __restr
 // seq_b / seq_a (MI_SUM_CPU_SEQUENTIAL, else null): cpu-slam's sequential fp32 running sums of the kept pairs; its centroids
 // are those sums divided by (float)count (common.cpp:283), and t inherits their rounding.  The cross-covariance keeps the
 // fp64 form: replacing the exact centroids by the rounded ones changes H by n*da*db^T, ~1e-9 relative.
-__device__ void solve_from_moments(const double* mom, const float* seq_b, const float* seq_a, float Ri[9], float ti[3])
+__device__ void solve_from_moments(const double* mom, const float* seq_b, const float* seq_a, float Ri[9], float ti[3], bool svd_ieee)
 {
     const double n = mom[0];
     const double inv_n = 1.0 / n;            // (n is a count: one fp64 division instead of six on the one-lane chain)
@@ -221,7 +221,7 @@ __device__ void solve_from_moments(const double* mom, const float* seq_b, const 
     Mat3 H;
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) H.a[r][c] = (float)(mom[7 + 3 * r + c] - n * ca[r] * cb[c]);
-    const Kabsch3 k = kabsch_rotation<true>(H);     // (svd3.hpp SvdMath: hardware reciprocals and roots for the rotation parameters)
+    const Kabsch3 k = kabsch_rotation<true>(H, svd_ieee);     // (svd3.hpp SvdMath: hardware reciprocals and roots for the rotation parameters)
     // column-major like glm::mat3 (ConvertRotationMatrix, common.cpp:335-346)
     for (int c = 0; c < 3; c++)
         for (int r = 0; r < 3; r++) Ri[3 * c + r] = k.R.a[r][c];
@@ -245,7 +245,7 @@ __device__ void mat3_mul_cm(const float a[9], const float b[9], float out[9])
 }
 
 // Kabsch solve of the moments + composition with the running transform (one lane)
-__device__ void apply_solve(IcpState* __restrict__ state, const double* mom, int compose_mode, int seq_sums)
+__device__ void apply_solve(IcpState* __restrict__ state, const double* mom, int compose_mode, int seq_sums, int svd_ieee)
 {
     state->pairs = (int)mom[0];
     if (mom[0] <= 0.0) {   // "if (correspondingPoints.size() == 0) break;"  basicicp.cpp:36
@@ -256,7 +256,7 @@ __device__ void apply_solve(IcpState* __restrict__ state, const double* mom, int
     float Ri[9], ti[3];
     float seq_b[3], seq_a[3];
     for (int d = 0; d < 3; d++) { seq_b[d] = state->seq_sum_b[d]; seq_a[d] = state->seq_sum_a[d]; }
-    solve_from_moments(mom, seq_sums ? seq_b : nullptr, seq_sums ? seq_a : nullptr, Ri, ti);
+    solve_from_moments(mom, seq_sums ? seq_b : nullptr, seq_sums ? seq_a : nullptr, Ri, ti, svd_ieee != 0);
     for (int i = 0; i < 9; i++) state->Ri[i] = Ri[i];
     for (int i = 0; i < 3; i++) state->ti[i] = ti[i];
     float R[9], t[3];
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64) void icp_solve_deferred_kernel(IcpState* __rest
     }
     double mom[ICP_MOMENTS];
     for (int i = 0; i < ICP_MOMENTS; i++) { mom[i] = sums[i]; state->mom[i] = sums[i]; }
-    apply_solve(state, mom, compose_mode, rules.seq_sums);
+    apply_solve(state, mom, compose_mode, rules.seq_sums, rules.svd_ieee);
     if (mark_pending && state->done == 0) state->err_pending = 1;
 }
 
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(ROWS_REDUCE_THREADS) void icp_reduce_solve_kernel(I
     }
     double mom[ICP_MOMENTS];
     for (int i = 0; i < ICP_MOMENTS; i++) { mom[i] = sums[i]; state->mom[i] = sums[i]; }
-    apply_solve(state, mom, compose_mode, rules.seq_sums);
+    apply_solve(state, mom, compose_mode, rules.seq_sums, rules.svd_ieee);
     if (mark_pending && state->done == 0) state->err_pending = 1;
 }
 hipError_t icp_reduce_solve(IcpState* state, const double* rows, int nrows, int compose_mode, const IcpRules& rules, int mark_pending, hipStream_t s)

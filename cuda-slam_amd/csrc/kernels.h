@@ -85,6 +85,7 @@ struct IcpRules {
     int abort_on_increase;
     int m_total;                     // |after| over all ranks
     int seq_sums;                    // MI_SUM_CPU_SEQUENTIAL: the error comes from state->seq_sum_err
+    int svd_ieee;                    // developer switch MISLAM_SVD_IEEE=1: K3 in IEEE divisions and roots instead of the refined hardware forms
 };
 
 constexpr int ICP_CHUNK_POINTS = 64;          // moving points per wave / per row of partial sums (icp_rows.hpp ICP_ROW_POINTS)

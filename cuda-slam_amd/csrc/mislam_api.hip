@@ -5,11 +5,13 @@
 // without a single host round trip; the host only reads the 256-byte state block back every `sync_every` iterations.
 #include <hip/hip_runtime.h>
 #include <sys/resource.h>
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -229,12 +231,14 @@ static int ctx_create_common(int device, mi_ctx** out)
         c->tune.nn_wgs = env_i("MISLAM_NN_WGS", 0);
         c->tune.nn_chunks = env_i("MISLAM_NN_CHUNKS", 0);
         c->tune.cpd_mfma = env_i("MISLAM_CPD_MFMA", 1);
+        c->tune.cpd_trunc_cull = env_i("MISLAM_CPD_TRUNC_CULL", 1);
         c->tune.fgt_resume = env_i("MISLAM_FGT_RESUME", 1);
         c->tune.fgt_replay = env_i("MISLAM_FGT_REPLAY", 1);
         c->tune.grid_deal_rows = env_i("MISLAM_GRID_DEAL_ROWS", -1);
         c->tune.grid_split_walks = env_i("MISLAM_GRID_SPLIT_WALKS", -1);
         c->tune.icp_pipeline = env_i("MISLAM_ICP_PIPELINE", 1);
         c->tune.icp_fused_solve = env_i("MISLAM_ICP_FUSED_SOLVE", 1);
+        c->tune.svd_ieee = env_i("MISLAM_SVD_IEEE", 0);
         if (const char* ppc = getenv("MISLAM_GRID_PPC")) { const float f = (float)atof(ppc); if (f >= 0.25f && f <= 64.f) c->tune.grid_points_per_cell = f; }
         if (env_i("MISLAM_PRELOAD", 0) == 1) MI_TRY(mi_ctx_preload(c));       // =1: mi_ctx_preload as part of every context creation
         // pinned upload staging: a ring of 16 pieces of 1 MB, pinned here, once per context (pinning costs ~0.25 ms per MB on this
@@ -360,6 +364,29 @@ extern "C" int mi_dist_info(mi_ctx* c, int* nranks, int* rank, unsigned long lon
         MI_HIP(hipMemcpyAsync(&all, c->rows_reduced.p, sizeof all, hipMemcpyDeviceToHost, c->stream));
         MI_HIP(hipStreamSynchronize(c->stream));
         *ranks_seen = (unsigned long long)all;
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_runtime_info(char* hip_path, char* rccl_path, int cap, int* hip_runtime_version, int* rccl_version)
+{
+    const auto object_of = [cap](const void* symbol, char* out) {
+        if (!out || cap <= 0) return;
+        Dl_info info;
+        const char* name = (dladdr(symbol, &info) != 0 && info.dli_fname) ? info.dli_fname : "";
+        snprintf(out, (size_t)cap, "%s", name);
+    };
+    object_of(reinterpret_cast<const void*>(&hipStreamSynchronize), hip_path);
+    object_of(reinterpret_cast<const void*>(&ncclAllReduce), rccl_path);
+    if (hip_runtime_version) {
+        int v = 0;
+        if (hipRuntimeGetVersion(&v) != hipSuccess) v = -1;      // (no device needed: the runtime's own build number)
+        *hip_runtime_version = v;
+    }
+    if (rccl_version) {
+        int v = 0;
+        if (ncclGetVersion(&v) != ncclSuccess) v = -1;
+        *rccl_version = v;
     }
     return MI_OK;
 }
@@ -1112,6 +1139,7 @@ static IcpRules icp_rules(const mi_ctx* c)
     rules.abort_on_increase = c->icp.abort_on_increase;
     rules.m_total = c->m_total;
     rules.seq_sums = c->icp.sum_mode == MI_SUM_CPU_SEQUENTIAL;
+    rules.svd_ieee = c->tune.svd_ieee;
     return rules;
 }
 

@@ -255,17 +255,35 @@ struct Kabsch3 {
 static __attribute__((noinline, unused)) __device__ Svd3 svd3_ieee_out_of_line(const Mat3& A) { return svd3<false>(A); }
 #endif
 
+// force_ieee (device code, FAST only): the IEEE decomposition whatever the fast one would have given -- the developer switch
+// MISLAM_SVD_IEEE=1 of a context (round 5: an A/B of the two on one device, tests/test_gpu_icp.py, and the way a soak's difference is
+// attributed to K3 or not).  The NaN test covers S as well: the CPD M-step reads the singular values.
 template <bool FAST = false>
-__host__ __device__ inline Kabsch3 kabsch_rotation(const Mat3& H)
+__host__ __device__ inline Kabsch3 kabsch_rotation(const Mat3& H, bool force_ieee = false)
 {
-    Svd3 s = svd3<FAST>(H);
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (FAST) {
-        float chk = 0.f;
-        for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 3; c++) chk += fabsf(s.U.a[r][c]) + fabsf(s.V.a[r][c]);
-        if (__builtin_expect(!(chk <= FLT_MAX), 0)) s = svd3_ieee_out_of_line(H);
+    Svd3 s;
+    if (FAST && force_ieee) s = svd3_ieee_out_of_line(H);
+    else {
+        s = svd3<FAST>(H);
+        if (FAST) {
+            float chk = (fabsf(s.S[0]) + fabsf(s.S[1])) + fabsf(s.S[2]);
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) chk += fabsf(s.U.a[r][c]) + fabsf(s.V.a[r][c]);
+            // Round 5 (tools/soak_rootcause.py): a RANK-DEFICIENT cross-covariance (clusters against a plane, a planar or
+            // collinear moving cloud: smallest singular value ~ 0).  The directions of the null space -- and with them the sign det(U V^T) that
+            // decides between a rotation and its mirror image in that direction -- are then whatever the LAST BITS of the sweep make them:
+            // Eigen's arithmetic (the oracle, cpu-slam) lands on one branch, reproducibly (the oracle against itself with the points reordered:
+            // 3e-6), the refined hardware forms on another (soak seed 1 case 174: singular values 1990 / 0.106 / 0, |d(R|t)|_F = 1.81 after three
+            // iterations; with the IEEE forms 4e-6).  The fast forms differ from IEEE by rounding, which is harmless exactly as long as R
+            // depends continuously on H: so when the decomposition says it does not -- S[2] below 1e-3 of S[0] -- the IEEE one decides.
+            const bool ill = s.S[2] < 1e-3f * s.S[0];
+            if (__builtin_expect(!(chk <= FLT_MAX) || ill, 0)) s = svd3_ieee_out_of_line(H);
+        }
     }
+#else
+    (void)force_ieee;
+    Svd3 s = svd3<FAST>(H);
 #endif
     Kabsch3 k;
     k.det = det3(mul_abt(s.U, s.V));

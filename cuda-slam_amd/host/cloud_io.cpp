@@ -129,9 +129,11 @@ CpuCloud LoadCloud(const std::string& path)
                 const long i = std::strtol(tok.c_str(), nullptr, 10);   // "v", "v/vt", "v//vn", "v/vt/vn"
                 ids.push_back(i > 0 ? i - 1 : (long)verts.size() + i);
             }
-            for (size_t k = 1; k + 1 < ids.size(); k++)
-                for (long id : {ids[0], ids[k], ids[k + 1]})
-                    if (id >= 0 && id < (long)verts.size()) corners.push_back(verts[(size_t)id]);
+            // one point per corner of the face AS WRITTEN: assimp's OBJ importer makes a vertex per face-vertex reference, its triangulation
+            // step only re-indexes them (a quad stays 4 points), and the reference's loader copies mesh->mVertices (loader.cpp:58-66):
+            // bird.obj, 8 752 quads, is the 35 008 points of testset.cpp:25-26
+            for (long id : ids)
+                if (id >= 0 && id < (long)verts.size()) corners.push_back(verts[(size_t)id]);
         }
     }
     return corners.empty() ? verts : corners;

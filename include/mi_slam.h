@@ -134,6 +134,13 @@ int mi_ctx_rank(const mi_ctx* ctx, int* rank, int* world);
  * stream -- bit r set = rank r took part.  Collective: every rank calls it.  Any output may be NULL. */
 int mi_dist_info(mi_ctx* ctx, int* nranks, int* rank, unsigned long long* ranks_seen);
 
+/* Which shared objects this library's HIP and RCCL calls actually bind to in THIS process, and their versions -- no device is touched
+ * (dladdr on hipStreamSynchronize / ncclAllReduce, ncclGetVersion, hipRuntimeGetVersion).  A launcher that has imported another copy of the ROCm
+ * runtime first (PyTorch bundles libamdhip64 / librccl under torch/lib with the same SONAMEs) decides what these resolve to: bench.py prints
+ * them in its N > 1 line and refuses to start when two different RCCL objects of different versions are mapped (round 5).
+ * Paths are copied into the caller's buffers (truncated to `cap` bytes, always NUL-terminated); any pointer may be NULL. */
+int mi_runtime_info(char* hip_path, char* rccl_path, int cap, int* hip_runtime_version, int* rccl_version);
+
 /* The same multi-GPU path over the CALLER's transport instead of RCCL (MPI between nodes, a test harness ...; no reference
  * counterpart either).  Wherever the RCCL context issues an all-reduce, this one drains its stream, copies the operand to
  * pinned host memory, calls `exchange` and copies the result back: `exchange` must combine host_buf[0 .. count) IN PLACE across

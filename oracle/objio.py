@@ -1,9 +1,10 @@
 """TEST INFRASTRUCTURE ONLY.  Minimal Wavefront-OBJ point reader used to feed the checkers.
 
 Semantics follow what the reference's loader yields (source/common/loader.cpp:30-67): assimp is run with
-aiProcess_Triangulate and WITHOUT aiProcess_JoinIdenticalVertices, so a mesh contributes one point per FACE CORNER, in
-face order (bunny.obj: 4 968 triangles -> 14 904 points, cf. source/common/testset.cpp:22).  Polygons with more than three
-corners are fan-triangulated (v0, v_i, v_i+1), which is what assimp's triangulation step produces for convex polygons.
+aiProcess_Triangulate and WITHOUT aiProcess_JoinIdenticalVertices, and the loader copies mesh->mVertices: the OBJ importer makes
+one vertex per face-vertex reference and the triangulation step only re-indexes them, so a mesh contributes one point per corner
+of every face AS WRITTEN, in face order (bunny.obj: 4 968 triangles -> 14 904 points; bird.obj: 8 752 quads -> 35 008 points,
+cf. source/common/testset.cpp:22-26 -- round 5: quads used to be fan-triangulated here into 6 points).
 A file without faces falls back to its bare vertex list.
 """
 import numpy as np
@@ -22,8 +23,7 @@ def load_obj_points(path):
                 for tok in line.split()[1:]:
                     i = int(tok.split("/")[0])
                     ids.append(i - 1 if i > 0 else len(verts) + i)
-                for k in range(1, len(ids) - 1):
-                    corners.extend((ids[0], ids[k], ids[k + 1]))
+                corners.extend(ids)
     v = np.asarray(verts, dtype=np.float32).reshape(-1, 3)
     if not corners:
         return v

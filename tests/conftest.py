@@ -138,3 +138,30 @@ def prepare_kwargs(opt, draws, side):
     if side == "a":
         kw.update(R=np.array(opt["R"], np.float32), t=np.array(opt["t"], np.float32))
     return kw
+
+
+# ---- the reference's CPD evaluation corpus (doc/noise/configs, oracle/make_golden_noise.py) ----
+def noise_corpus(golden):
+    """(fixture document, {file name: raw cloud}) -- the raw clouds are the meshes' face corners in face order (loader.cpp:58-66)."""
+    doc = golden.json("noise_configs.json")
+    z = golden.npz("noise_meshes.npz")
+    meshes = {}
+    for key in z.files:
+        if key.endswith("_v"):
+            name = key[:-2].replace("_", "-") + ".obj"
+            meshes[name] = (z[key], z[key[:-2] + "_f"].astype(np.int64))
+    return doc, meshes
+
+
+def write_noise_meshes(meshes, directory):
+    """The corpus' .obj files rebuilt from the fixture (vertices with nine significant digits: every fp32 value survives the round
+    trip; faces: the corner list cut into triangles -- a loader that yields one point per face corner reads the same cloud from any cut)."""
+    os.makedirs(os.path.join(directory, "data"), exist_ok=True)
+    for name, (v, f) in meshes.items():
+        with open(os.path.join(directory, "data", name), "w") as out:
+            for p in v:
+                out.write("v %.9g %.9g %.9g\n" % (float(p[0]), float(p[1]), float(p[2])))
+            cuts = list(range(0, len(f) - len(f) % 3, 3))
+            for k, c in enumerate(cuts):
+                end = len(f) if k == len(cuts) - 1 else c + 3
+                out.write("f " + " ".join(str(int(i) + 1) for i in f[c:end]) + "\n")

@@ -231,6 +231,60 @@ def test_bunny_truncated_estep_golden(ctx, golden, bunny):
     assert abs(L - t["L"]) < 1e-4 * abs(t["L"])              # sequential fp32 log sum there, fp64 here
 
 
+@pytest.fixture(scope="module")
+def every_pair_ctx(capi):
+    """A context whose truncated E-step is round 4's every-pair kernel (MISLAM_CPD_TRUNC_CULL=0; switches are read at context creation)."""
+    import os
+    os.environ["MISLAM_CPD_TRUNC_CULL"] = "0"
+    try:
+        c = capi.Context(0)
+    finally:
+        del os.environ["MISLAM_CPD_TRUNC_CULL"]
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("seed,m,n,s2", [(3, 1, 1, 1.0), (4, 1, 700, 0.3), (5, 65, 63, 0.05), (6, 64, 64, 5.0), (7, 1025, 1023, 0.01),
+                                         (8, 5000, 9000, 0.004), (9, 20000, 17000, 0.02), (10, 40000, 30000, 1e-4)])
+def test_culled_truncated_estep_equals_the_every_pair_one(ctx, every_pair_ctx, oracle, seed, m, n, s2):
+    # K7t (cpd_trunc.hip): tiles of 64 points along a space-filling curve, skipped when their boxes are farther apart than the truncation
+    # radius.  A skipped pair contributes exactly 0.0f in the reference (coherentpointdrift.cpp:193-196), so the culled sums hold the same
+    # non-zero terms as the every-pair kernel's, in another order: equal to fp32 summation rounding.  Ragged sizes (one point, one lane short of
+    # a tile, one past a super-tile), a radius that reaches everything (s2 = 5: nothing is skipped) and one that reaches almost nothing (1e-4)
+    y, x = pair(seed, m, n)
+    c = oracle.cpd_constant(4.0, 0.3, m, n)
+    a = ctx.cpd_estep_truncated(y, x, c, s2, 1e-3)
+    b = every_pair_ctx.cpd_estep_truncated(y, x, c, s2, 1e-3)
+    for g, w in zip(a[:3], b[:3]):
+        assert rel(g, w) < 2e-5, (m, n, s2, rel(g, w))
+    assert abs(a[3] - b[3]) < 1e-6 * abs(b[3]) + 1e-4
+    if m * n <= 2000000:
+        want = oracle.cpd_estep_truncated(y, x, c, s2, 1e-3)
+        for g, w in zip(a[:3], want[:3]):
+            assert rel(g, w) < 2e-4
+
+
+def test_culled_truncated_estep_with_nothing_in_reach(ctx, oracle):
+    # two clouds farther apart than the truncation radius: every affinity is cut -- den = c, Pt1 = 0, P1 = PX = 0, exactly
+    rng = np.random.default_rng(21)
+    y = rng.uniform(-1, 1, (900, 3)).astype(np.float32)
+    x = (rng.uniform(-1, 1, (1100, 3)) + 50.0).astype(np.float32)
+    c = oracle.cpd_constant(4.0, 0.3, 900, 1100)
+    p1, pt1, px, L = ctx.cpd_estep_truncated(y, x, c, 0.5, 1e-3)
+    o1, ot1, ox, oL = oracle.cpd_estep_truncated(y, x, c, 0.5, 1e-3)
+    assert not p1.any() and not px.any() and np.array_equal(pt1, ot1) and abs(L - oL) < 1e-5 * abs(oL)
+
+
+def test_hybrid_run_is_the_same_registration_with_and_without_culling(ctx, every_pair_ctx, capi, golden, bunny):
+    # the whole hybrid run (FGT E-steps, then truncated ones): same iteration count, s*R|t within E-step summation rounding of each other
+    before, after = bunny
+    g = golden.json("bunny_fgt.json")
+    p = capi.cpd_params(max_iterations=50, sigma2_init=g["sigma2_init"], approximation=capi.CPD_APPROX_HYBRID)
+    a, b = ctx.cpd_register(before, after, p), every_pair_ctx.cpd_register(before, after, p)
+    assert a[3] == b[3] == 23
+    assert frob(a[0], a[1], b[0], b[1]) < 2e-5
+
+
 def test_estep_primitives_reject_bad_arguments(ctx, capi):
     y, x = pair(0, 50, 60)
     with pytest.raises(capi.MiSlamError):

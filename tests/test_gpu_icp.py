@@ -207,6 +207,80 @@ def test_planar_and_duplicated_clouds_stay_finite_and_match_the_oracle(ctx, capi
         assert frob(R, t, Ro, to) < 2e-4 * max(1.0, float(np.abs(to).max())), (seed, nn, frob(R, t, Ro, to))
 
 
+@pytest.fixture(scope="module")
+def ieee_ctx(capi):
+    """A context whose 3 x 3 SVDs run in IEEE divisions and roots (MISLAM_SVD_IEEE=1; switches are read at context creation)."""
+    import os
+    os.environ["MISLAM_SVD_IEEE"] = "1"
+    try:
+        c = capi.Context(0)
+    finally:
+        del os.environ["MISLAM_SVD_IEEE"]
+    yield c
+    c.close()
+
+
+def soak_problem(seed, case):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from reg_soak import problems
+    for k, degenerate, n, m, ks, kt, src, tgt in problems(case + 1, seed):
+        if k == case:
+            return src, tgt
+    raise AssertionError("no such case")
+
+
+@pytest.mark.parametrize("seed,case,bar", [(1, 174, 2e-5), (1, 333, None), (3, 337, None)])
+def test_soak_cases_root_caused_in_round_5(ctx, ieee_ctx, capi, oracle, seed, case, bar):
+    # Round 4's registration soak filed its worst "well-posed" differences from the oracle (2.3e-3 ICP, 3.7e-3 CPD after 3 / 5 iterations) under
+    # "clustered against clustered".  Round 5 took them apart (tools/soak_rootcause.py, profiles/r05_soak_rootcause.log):
+    #  * seed 1 case 174 (two tight clusters against a plane; singular values of the cross-covariance 1990 / 0.106 / 0): a RANK-DEFICIENT H.  The
+    #    null direction's sign -- rotation or its mirror image -- is decided by the last bits of the Jacobi sweep; Eigen's arithmetic (the oracle,
+    #    reproducible to 3e-6 with the points reordered) takes one branch, K3's refined hardware forms took the other: |d(R|t)|_F = 1.81.  K3 now
+    #    hands a decomposition whose smallest singular value is below 1e-3 of the largest to the IEEE forms (svd3.hpp): 4e-6.
+    #  * seed 1 case 333, seed 3 case 337: differences of 5e-2 / 1.5 that the ORACLE shows against itself when the moving cloud is merely
+    #    reordered (cpu-slam's sequential fp32 centroid sums round differently): the problem's own conditioning, no kernel's error.  Asserted
+    #    as such: the device is no farther from the oracle than the oracle from itself (x 1.5).
+    src, tgt = soak_problem(seed, case)
+    Ro, to, ito, eo = oracle.icp(src, tgt, eps=0.0, max_iterations=3)[:4]
+    scale = max(1.0, float(np.abs(to).max()))
+    R, t, it, err = ctx.icp_register(src, tgt, capi.icp_params(eps=0.0, max_iterations=3))[:4]
+    d = frob(R, t, Ro, to) / scale
+    Ri, ti = ieee_ctx.icp_register(src, tgt, capi.icp_params(eps=0.0, max_iterations=3))[:2]
+    print("soak seed %d case %d: |d(R|t)|_F / scale vs oracle: default %.3e, IEEE K3 %.3e" % (seed, case, d, frob(Ri, ti, Ro, to) / scale))
+    assert it == ito == 3 and np.isfinite(R).all()
+    if bar is not None:
+        assert d < bar
+    else:
+        rng = np.random.default_rng(seed * 1000 + case)
+        own = max(frob(*oracle.icp(src[rng.permutation(len(src))], tgt, eps=0.0, max_iterations=3)[:2], Ro, to) for _ in range(3)) / scale
+        assert d <= 1.5 * own + 1e-5, (d, own)
+
+
+def test_fast_and_ieee_k3_agree_on_the_fixtures(ctx, ieee_ctx, capi, golden, bunny):
+    # ADVICE r04: the one change that moves results away from the reference's arithmetic is the FAST K3 (rcp / rsq refined by fmas instead of IEEE
+    # divisions and roots).  A/B on one device, same inputs: bunny ICP (39 iterations composed) and bunny CPD (27 EM iterations) -- same iteration
+    # counts, and each form as close to cpu-slam as the other (measured round 5: ICP 1.4e-5 fast / 1.2e-5 IEEE; the bar of the IEEE form, 1e-5 + what
+    # the forms differ by, is kept for both)
+    before, after = bunny
+    g = golden.json("bunny_icp.json")
+    p = g["params"]
+    prm = capi.icp_params(eps=p["eps"], max_iterations=p["max_iterations"], max_distance_squared=p["max_distance_squared"])
+    a, b = ctx.icp_register(before, after, prm), ieee_ctx.icp_register(before, after, prm)
+    assert a[2] == b[2] == g["iterations"]
+    d_ab = frob(a[0], a[1], b[0], b[1])
+    d_fast, d_ieee = frob(a[0], a[1], g["R"], g["t"]), frob(b[0], b[1], g["R"], g["t"])
+    print("bunny ICP vs cpu-slam: fast K3 %.3e, IEEE K3 %.3e, fast vs IEEE %.3e" % (d_fast, d_ieee, d_ab))
+    assert d_ab < 1e-5 and d_ieee < 1.5e-5 and d_fast < 2e-5
+    gc = golden.json("bunny_cpd.json")
+    pc = capi.cpd_params(max_iterations=50, const_scale=0, sigma2_init=gc["sigma2_init"])
+    a, b = ctx.cpd_register(before, after, pc), ieee_ctx.cpd_register(before, after, pc)
+    f = gc["final_scale_free"]
+    assert a[3] == b[3] == f["iterations"]
+    print("bunny CPD vs cpu-slam: fast K3 %.3e, IEEE K3 %.3e, fast vs IEEE %.3e" % (frob(a[0], a[1], f["sR"], f["t"]), frob(b[0], b[1], f["sR"], f["t"]), frob(a[0], a[1], b[0], b[1])))
+    assert frob(a[0], a[1], b[0], b[1]) < 2e-5
+
+
 def test_cuda_slam_driver_rules(ctx, capi, oracle, golden):
     # exact composition, no filter, error / |after|, abort + rollback, FMA distance (icpcuda.cu:8-58) vs the oracle in
     # the same modes ("parity unpinned" against a real CUDA run: none can be made here)

@@ -69,15 +69,17 @@ def test_parser_rejects_like_the_reference(tmp_path):
 
 
 def test_obj_face_corner_expansion_and_transform(tmp_path):
-    # 4 vertices, one triangle + one quad (fan-triangulated): 3 + 6 = 9 points, duplicates kept (loader.cpp:58-66)
+    # 4 vertices, one triangle + one quad: 3 + 4 = 7 points -- one per face corner AS WRITTEN, duplicates kept: the reference's loader copies
+    # mesh->mVertices (loader.cpp:58-66), and assimp's triangulation only re-indexes the quad's four vertices (bird.obj: 8 752 quads = the
+    # 35 008 points of testset.cpp:25-26; round 5: quads used to be fan-triangulated into 6 points here)
     verts = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)]
     write_obj(tmp_path / "a.obj", verts, [(1, 2, 3), (1, 2, 3, 4)])
     r = run(dict(BASE, **{"random-seed": 5}), tmp_path, dump=True)
     assert r.returncode == 0
     before, after = read_dump(tmp_path / "clouds.bin")
-    assert before.shape == (9, 3) and after.shape == (9, 3)
+    assert before.shape == (7, 3) and after.shape == (7, 3)
     v = np.array(verts, np.float32)
-    expect = np.concatenate([v[[0, 1, 2]], v[[0, 1, 2]], v[[0, 2, 3]]])
+    expect = np.concatenate([v[[0, 1, 2]], v[[0, 1, 2, 3]]])
     assert sorted(map(tuple, before)) == sorted(map(tuple, expect))
     R = np.array(BASE["rotation"], np.float32).reshape(3, 3)
     want = sorted(map(tuple, np.round(expect @ R.T + 1.0, 5)))

@@ -1,0 +1,51 @@
+"""CPU suite: the reference's CPD evaluation corpus (doc/noise/configs/config*.json, 25 of 39 runnable with the .obj files the reference
+ships) through the C++ host side's input stage -- configuration reader, OBJ reader, GetCloudsFromConfig mirror -- against the clouds the
+reference's own code prepared (tests/golden/noise_configs.json holds their sizes and sha256; oracle/make_golden_noise.py).  No GPU call:
+MISLAM_DUMP_ONLY stops mi-slam before the registration; the GPU suite (test_gpu_noise_corpus.py) runs the registrations."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import Golden, noise_corpus, write_noise_meshes
+from test_host_cpp import EXE, read_dump
+
+DOC, MESHES = noise_corpus(Golden())
+CONFIGS = {c["config"]: c for c in DOC["configs"]}
+
+
+@pytest.fixture(scope="module")
+def corpus_dir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("noise_corpus")
+    write_noise_meshes(MESHES, str(d))
+    return d
+
+
+def test_the_corpus_is_complete():
+    # 39 configurations; 14 name .obj files that are missing blobs of the reference checkout (.MISSING_LARGE_BLOBS)
+    assert len(CONFIGS) == 25 and len(DOC["skipped"]) == 14
+    assert sorted(CONFIGS) + sorted(s["config"] for s in DOC["skipped"]) != [] and set(CONFIGS) | {s["config"] for s in DOC["skipped"]} == set(range(1, 40))
+    assert all(c["options"]["method"] == "cpd" and c["options"]["approximation"] == "hybrid" for c in CONFIGS.values())
+    assert sum(1 for c in CONFIGS.values() if c["options"]["cpd_const_scale"]) == 19
+    # bird.obj: 8 752 quads = 35 008 points (testset.cpp:25-26): one point per face corner as written
+    assert len(MESHES["bird.obj"][1]) == 35008 and len(MESHES["bunny.obj"][1]) == 14904
+
+
+@pytest.mark.parametrize("number", sorted(CONFIGS))
+def test_host_input_stage_reproduces_the_reference_clouds(corpus_dir, number):
+    if not os.path.exists(EXE):
+        pytest.skip("mi-slam not built (run __graft_entry__.build())")
+    c = CONFIGS[number]
+    cfg = corpus_dir / ("config%d.json" % number)
+    cfg.write_text(json.dumps(c["config_json"]))           # the reference's file as it is: paths relative to the working directory
+    dump = corpus_dir / ("clouds%d.bin" % number)
+    r = subprocess.run([EXE, str(cfg), "--prepare", "host", "--dump-clouds", str(dump)], capture_output=True, text=True,
+                       env=dict(os.environ, MISLAM_DUMP_ONLY="1"), cwd=str(corpus_dir), timeout=120)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    before, after = read_dump(dump)
+    assert (len(before), len(after)) == (c["n_before"], c["n_after"])
+    assert hashlib.sha256(before.tobytes()).hexdigest() == c["sha256_before"]
+    assert hashlib.sha256(after.tobytes()).hexdigest() == c["sha256_after"]

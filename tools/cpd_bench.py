@@ -80,6 +80,37 @@ def main():
                               "ms_per_em_iteration": min(plain) / max(it, 1), "fgt_esteps": fgt_n,
                               "K9_fgt_estep_ms": fgt_ms / max(fgt_n, 1), "t": [float(x) for x in t], "sigma2": err}), flush=True)
     ctx.close()
+    # Round 5: the hybrid mode's truncated E-step alone (K7t, cpd_trunc.hip: culled by tile boxes) against round 4's every-pair truncated kernels
+    # (MISLAM_CPD_TRUNC_CULL=0), on the bunny clouds at the sigma^2 where the hybrid mode switches over and late in a run; and a hybrid
+    # registration at 1e5 points (--hybrid-1e5): the size where culling decides whether the mode is usable at all
+    for cull in ("1", "0"):
+        os.environ["MISLAM_CPD_TRUNC_CULL"] = cull
+        ctx = capi.Context(0)
+        name, before, after, s2 = cases[0]
+        for sigma2 in (0.05, 0.01, 0.001):
+            c = 1.0
+            ctx.cpd_estep_truncated(before, after, c, sigma2, 1e-3)
+            ctx.profile_enable(True)
+            ctx.profile_reset()
+            for _ in range(5):
+                ctx.cpd_estep_truncated(before, after, c, sigma2, 1e-3)
+            den, con = ctx.profile_get(capi.KERNEL_CPD_DENOM), ctx.profile_get(capi.KERNEL_CPD_CONTRACT)
+            ctx.profile_enable(False)
+            print(json.dumps({"case": name, "truncated_estep": "culled (K7t)" if cull == "1" else "every pair (round 4)", "sigma2": sigma2,
+                              "K7a_ms": den[0] / max(den[1], 1), "K7b_ms": con[0] / max(con[1], 1),
+                              "K7a_plus_K7b_ms": den[0] / max(den[1], 1) + con[0] / max(con[1], 1)}), flush=True)
+        if "--hybrid-1e5" in sys.argv:
+            from bench import synth_cloud
+            b5, a5 = synth_cloud(np, 100000)
+            p = capi.cpd_params(max_iterations=40, approximation=capi.CPD_APPROX_HYBRID)
+            ctx.cpd_register(b5, a5, p)
+            t0 = time.perf_counter()
+            sR, t, scale, it, err = ctx.cpd_register(b5, a5, p)
+            wall = (time.perf_counter() - t0) * 1e3
+            print(json.dumps({"case": "synthetic_100000", "approximation": "hybrid", "truncated_estep": "culled (K7t)" if cull == "1" else "every pair (round 4)",
+                              "iterations": it, "wall_ms_total": wall, "ms_per_em_iteration": wall / max(it, 1), "sigma2": err, "t": [float(x) for x in t]}), flush=True)
+        ctx.close()
+    os.environ.pop("MISLAM_CPD_TRUNC_CULL", None)
 
 
 if __name__ == "__main__":

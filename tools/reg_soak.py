@@ -27,17 +27,11 @@ def make(rng, n, kind):
     return cloud(rng, n, kind).astype(np.float32)
 
 
-def frob(R1, t1, R2, t2):
-    return float(np.sqrt(((np.asarray(R1, np.float64) - R2) ** 2).sum() + ((np.asarray(t1, np.float64) - t2) ** 2).sum()))
-
-
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    capi = load_package().capi
-    ctx = capi.Context(0)
-    worst = {"icp": 0.0, "cpd": 0.0, "hyb": 0.0}
-    flagged = 0
+def problems(cases, seed):
+    """reg_soak's problems, in order: (k, degenerate, n, m, kind of the moving cloud, kind of the fixed cloud, moving cloud, fixed cloud).  ONE
+    generator consumed case by case -- case k of a seed is only reached through the cases before it (tools/soak_rootcause.py and the pinned
+    cases of tests/test_gpu_icp.py replay it the same way)."""
+    rng = np.random.default_rng(seed)
     for k in range(cases):
         degenerate = k % 3 == 2              # tiny, collinear or coincident clouds: the rotation is not determined -- only "finite or not" is compared
         if degenerate:
@@ -46,7 +40,21 @@ def main():
         else:
             n = int(10 ** rng.uniform(1.7, 3.3)); m = int(10 ** rng.uniform(1.7, 3.3))
             ks, kt = int(rng.integers(0, 4)), int(rng.integers(0, 4))
-        src, tgt = make(rng, n, ks), make(rng, m, kt)
+        yield k, degenerate, n, m, ks, kt, make(rng, n, ks), make(rng, m, kt)
+
+
+def frob(R1, t1, R2, t2):
+    return float(np.sqrt(((np.asarray(R1, np.float64) - R2) ** 2).sum() + ((np.asarray(t1, np.float64) - t2) ** 2).sum()))
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    capi = load_package().capi
+    ctx = capi.Context(0)
+    worst = {"icp": 0.0, "cpd": 0.0, "hyb": 0.0}
+    flagged = 0
+    for k, degenerate, n, m, ks, kt, src, tgt in problems(cases, seed):
         Ro, to, ito, eo = oracle.icp(src, tgt, eps=0.0, max_iterations=3)[:4]
         R, t, it, err = ctx.icp_register(src, tgt, capi.icp_params(eps=0.0, max_iterations=3))[:4]
         fin_o = np.isfinite(Ro).all() and np.isfinite(to).all()
