@@ -188,8 +188,12 @@ static CpdRules cpd_rules(const CpdWorkspace* w, const mi_cpd_params* p)
     return r;
 }
 
-// workgroups of the M-step sums and of the E-step's post kernels (a quad of lanes per point there: 64 points per workgroup)
+// workgroups of the E-step's post kernels (a quad of lanes per point there: 64 points per workgroup) = rows of M-step partial sums they leave
 static int cpd_sum_blocks(int n) { return std::max(1, std::min(ICP_MAX_PARTIAL_BLOCKS, (n + 63) / 64)); }
+// ... and of the STAND-ALONE sums kernels (cpd_xsums / cpd_ksums: one lane per point, 256 per workgroup).  ADVICE r04: launched with
+// cpd_sum_blocks they left three quarters of their workgroups storing zeros below 32 768 points.  Their fp64 partials are grouped differently
+// from the fused ones' (256 against 64 points per row) -- the same sums to ~1e-16 relative, not the same bits.
+static int cpd_standalone_sum_blocks(int n) { return std::max(1, std::min(ICP_MAX_PARTIAL_BLOCKS, (n + 255) / 256)); }
 
 static int use_mfma_contraction(const mi_ctx* c) { return c->tune.cpd_mfma; }   // MISLAM_CPD_MFMA, read at context creation
 
@@ -208,7 +212,6 @@ static int cpd_estep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
 
 // K7t: the hybrid mode's truncated E-step, culled (cpd_trunc.hip).  MISLAM_CPD_TRUNC_CULL=0: round 4's every-pair truncated kernels.
 static int cpd_trunc_tiles(int n) { return (n + CPD_TRUNC_TILE - 1) / CPD_TRUNC_TILE; }
-static int cpd_trunc_supers(int n) { return (cpd_trunc_tiles(n) + CPD_TRUNC_SUPER - 1) / CPD_TRUNC_SUPER; }
 
 static int cpd_trunc_prepare(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
 {
@@ -221,8 +224,8 @@ static int cpd_trunc_prepare(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
     const size_t na = (size_t)cpd_trunc_tiles(w->n) * CPD_TRUNC_TILE, ny = (size_t)cpd_trunc_tiles(w->m) * CPD_TRUNC_TILE;
     MI_TRY(w->t_ax.reserve(na)); MI_TRY(w->t_ay.reserve(na)); MI_TRY(w->t_az.reserve(na)); MI_TRY(w->t_xw4.reserve(na));
     MI_TRY(w->t_yx.reserve(ny)); MI_TRY(w->t_yy.reserve(ny)); MI_TRY(w->t_yz.reserve(ny));
-    MI_TRY(w->t_abox.reserve(6 * ((size_t)cpd_trunc_tiles(w->n) + cpd_trunc_supers(w->n))));
-    MI_TRY(w->t_ybox.reserve(6 * ((size_t)cpd_trunc_tiles(w->m) + cpd_trunc_supers(w->m))));
+    MI_TRY(w->t_abox.reserve(6 * (size_t)cpd_trunc_tiles(w->n)));
+    MI_TRY(w->t_ybox.reserve(6 * (size_t)cpd_trunc_tiles(w->m)));
     // the fixed cloud along its curve; the moving cloud along the curve of its ORIGINAL points (a similarity transform keeps neighbours together)
     MortonArgs ma{};
     ma.bbox_partials = w->t_bbox.p; ma.bbox = w->t_bbox.p + 256 * 6;
@@ -232,8 +235,7 @@ static int cpd_trunc_prepare(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
     MI_HIP(morton_order(ma, c->stream));
     ma.x = v.bx; ma.y = v.by; ma.z = v.bz; ma.m = w->m; ma.order_out = w->t_border.p;
     MI_HIP(morton_order(ma, c->stream));
-    MI_HIP(cpd_trunc_gather(v.ax, v.ay, v.az, w->t_aorder.p, w->n, w->t_ax.p, w->t_ay.p, w->t_az.p, w->t_abox.p,
-                            w->t_abox.p + 6 * (size_t)cpd_trunc_tiles(w->n), nullptr, c->stream));
+    MI_HIP(cpd_trunc_gather(v.ax, v.ay, v.az, w->t_aorder.p, w->n, w->t_ax.p, w->t_ay.p, w->t_az.p, w->t_abox.p, nullptr, c->stream));
     w->trunc_ready = true;
     return MI_OK;
 }
@@ -244,18 +246,17 @@ static int cpd_estep_trunc_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
     CpdTruncView t{};
     t.state = v.state;
     t.ax = w->t_ax.p; t.ay = w->t_ay.p; t.az = w->t_az.p;
-    t.abox = w->t_abox.p; t.asuper = w->t_abox.p + 6 * (size_t)cpd_trunc_tiles(w->n);
+    t.abox = w->t_abox.p;
     t.a_order = w->t_aorder.p; t.n = w->n;
     t.yx = w->t_yx.p; t.yy = w->t_yy.p; t.yz = w->t_yz.p;
-    t.ybox = w->t_ybox.p; t.ysuper = w->t_ybox.p + 6 * (size_t)cpd_trunc_tiles(w->m);
+    t.ybox = w->t_ybox.p;
     t.b_order = w->t_border.p; t.m = w->m;
     t.bx = v.bx; t.by = v.by; t.bz = v.bz;
-    t.xw4 = w->t_xw4.p; t.pt1 = v.pt1; t.p1 = v.p1; t.px = v.px;
+    t.xw4 = w->t_xw4.p; t.xw4_caller = v.xw4; t.pt1 = v.pt1; t.p1 = v.p1; t.px = v.px;
     t.trunc_log = v.trunc_log;
     const int nxb = std::min(CPD_TRUNC_MAX_BLOCKS, cpd_trunc_tiles(w->n)), nkb = std::min(CPD_TRUNC_MAX_BLOCKS, cpd_trunc_tiles(w->m));
     // the moving cloud's current positions in curve order + this E-step's boxes
-    MI_HIP(cpd_trunc_gather(v.yx, v.yy, v.yz, w->t_border.p, w->m, w->t_yx.p, w->t_yy.p, w->t_yz.p, w->t_ybox.p,
-                            w->t_ybox.p + 6 * (size_t)cpd_trunc_tiles(w->m), v.state, c->stream));
+    MI_HIP(cpd_trunc_gather(v.yx, v.yy, v.yz, w->t_border.p, w->m, w->t_yx.p, w->t_yy.p, w->t_yz.p, w->t_ybox.p, v.state, c->stream));
     { ProfScope ps(c, MI_KERNEL_CPD_DENOM); MI_HIP(cpd_trunc_denominators(t, w->part_x.p, nxb, c->stream)); }
     { ProfScope ps(c, MI_KERNEL_CPD_CONTRACT); MI_HIP(cpd_trunc_contract(t, w->part_k.p, nkb, c->stream)); }
     w->sums_fresh = true;
@@ -265,7 +266,7 @@ static int cpd_estep_trunc_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
 
 static int cpd_mstep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const CpdRules& rules, int update_loop_state)
 {
-    int nxb = cpd_sum_blocks(w->n), nkb = cpd_sum_blocks(w->m);
+    int nxb = cpd_standalone_sum_blocks(w->n), nkb = cpd_standalone_sum_blocks(w->m);
     ProfScope ps(c, MI_KERNEL_CPD_MSTEP);
     if (!w->sums_fresh) {
         MI_HIP(cpd_xsums(v, w->part_x.p, nxb, c->stream));
@@ -591,6 +592,10 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
             MI_TRY(cpd_fetch(c, w));
         if (params->verbose) printf("loop_nr %d, error: %f\n", w->h_state->iterations, w->h_state->error);
     }
+    // The host checks above only PEEK: behind the state copy that said "done" the stream still holds the iteration enqueued ahead of it (kernels
+    // that return at once) or the prelaunched K-centre replay.  Drained here, so that the call's wall time brackets all of its device work
+    // (bench.py's timers around this call used to miss that tail) and the workspace is quiet when the caller gets it back.
+    MI_HIP(hipStreamSynchronize(c->stream));
     const CpdState* s = w->h_state;
     // return make_pair(scale * rotationMatrix, translationVector)   coherentpointdrift.cpp:123 / cpdcuda.cu:360
     for (int col = 0; col < 3; col++) {
@@ -661,7 +666,7 @@ static int estep_primitive(mi_ctx* c, const float* y_xyz, int m, const float* x_
         else MI_TRY(cpd_estep_enqueue(c, w, v));
     }
     w->sums_fresh = false;               // (a stand-alone E-step: nothing of it is carried into a later M-step call)
-    const int nxb = cpd_sum_blocks(n);
+    const int nxb = cpd_standalone_sum_blocks(n);
     MI_HIP(cpd_xsums(v, w->part_x.p, nxb, c->stream));
     MI_HIP(hipMemcpyAsync(p1, w->p1.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
     MI_HIP(hipMemcpyAsync(pt1, w->pt1.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));

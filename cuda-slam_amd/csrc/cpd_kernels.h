@@ -66,28 +66,28 @@ struct CpdView {
 
 // K7t: the truncated E-step of the hybrid mode, culled by tile boxes along a space-filling curve (cpd_trunc.hip)
 constexpr int CPD_TRUNC_TILE = 64;        // points per tile = one wave
-constexpr int CPD_TRUNC_SUPER = 16;       // tiles per super-tile (one more level of boxes: 1 024 points skipped per test)
 constexpr int CPD_TRUNC_MAX_BLOCKS = 4096;   // workgroups (= rows of M-step partial sums) of its two kernels
 struct CpdTruncView {
     CpdState* state;
-    // fixed cloud in curve order (padded to whole tiles), its tile / super-tile boxes, sorted slot -> caller's index
+    // fixed cloud in curve order (padded to whole tiles), its tile boxes (component-major: [6][tiles]), sorted slot -> caller's index
     const float *ax, *ay, *az;
-    const float *abox, *asuper;
+    const float* abox;
     const int* a_order;
     int n;
     // moving cloud: CURRENT positions in the curve order of the original cloud (padded to whole tiles), boxes of this E-step, slot -> caller's index
     const float *yx, *yy, *yz;
-    const float *ybox, *ysuper;
+    const float* ybox;
     const int* b_order;
     int m;
     const float *bx, *by, *bz;            // the original moving cloud, caller's order (M-step k-sums)
     float4* xw4;                          // [n] curve order: (w*ax, w*ay, w*az, w), w = 1/den_x
+    float4* xw4_caller;                   // the same records in the caller's order (CpdView::xw4)
     float *pt1, *p1, *px;                 // caller's order, as CpdView
     float trunc_log;
 };
-// out = in[order] (padded to whole tiles with copies of the last point), tile and super-tile boxes; state != null: nothing once it says done
+// out = in[order] (padded to whole tiles with copies of the last point) and the tiles' boxes; state != null: nothing once it says done
 hipError_t cpd_trunc_gather(const float* x, const float* y, const float* z, const int* order, int n, float* ox, float* oy, float* oz,
-                            float* tile_box, float* super_box, const CpdState* state, hipStream_t s);
+                            float* tile_box, const CpdState* state, hipStream_t s);
 hipError_t cpd_trunc_denominators(const CpdTruncView& v, double* xpartials, int nblocks, hipStream_t s);   // den, Pt1, xw4 + the M-step's x-sums
 hipError_t cpd_trunc_contract(const CpdTruncView& v, double* kpartials, int nblocks, hipStream_t s);       // P1, PX + the M-step's k-sums
 

@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256) void cpd_denominator_kernel(CpdView v)
 }
 
 // den_x = sum of chunk partials + c; Pt1[x] = 1 - c/den (coherentpointdrift.cpp:204-206); operand of the contraction.
-// With xpartials != null the kernel also accumulates the M-step's x-sums (cpd_xsums_kernel's terms, same grid, same order: the
+// With xpartials != null the kernel also accumulates the M-step's x-sums (cpd_xsums_kernel's terms; fp64 partials grouped per 64 points here,
+// per 256 there -- cpd_api.hip cpd_standalone_sum_blocks: the same sums to ~1e-16, not the same bits; round 4's comment claimed the
 // same bits) -- one launch and one gap less per EM iteration.
 // Round 4: a QUAD of lanes per fixed point.  The chunk partials of one point are a chain of cache round trips (134 chunks on the bunny clouds,
 // eight loads in flight per trip: 17 trips), and with one lane per point only 59 workgroups have anything to do; each lane of the quad now adds

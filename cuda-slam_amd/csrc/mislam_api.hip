@@ -1089,6 +1089,18 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
     // The grid search carries the whole O(N) part of the iteration (nn_grid.hip) unless a stand-alone step has to come between
     // the search and the sums: the key all-reduce of a sharded fixed cloud, or cpu-slam's sequential running sums.
     const int mode = resolve_nn_mode(c, params->nn_mode, m_local_pre);
+    // Every way out of this function joins the lanes into `stream`: an early return between here and the join below -- the
+    // hierarchy refusing an over-tall cloud, a failed reserve -- used to leave work on aux / aux2 that `stream`, the only stream the next call's
+    // buffer retirement and ~CtxScope look at, knew nothing about.
+    struct LaneJoin {
+        mi_ctx* c; bool on; bool joined = false;
+        ~LaneJoin()
+        {
+            if (!on || joined) return;
+            if (hipEventRecord(c->aux_event[1], c->aux) == hipSuccess) (void)hipStreamWaitEvent(c->stream, c->aux_event[1], 0);
+            if (hipEventRecord(c->aux_event[2], c->aux2) == hipSuccess) (void)hipStreamWaitEvent(c->stream, c->aux_event[2], 0);
+        }
+    } lane_join{c, lanes};
     {
         LaneScope ls(c, lanes ? c->aux : nullptr, lanes ? 1 : 0);
         MI_TRY(upload_target_shard(c, after_xyz, n_after, c->source_sharded));
@@ -1115,6 +1127,7 @@ extern "C" int mi_icp_load(mi_ctx* c, const float* before_xyz, int n_before, con
         MI_HIP(hipEventRecord(c->aux_event[2], c->aux2));
         MI_HIP(hipStreamWaitEvent(c->stream, c->aux_event[1], 0));
         MI_HIP(hipStreamWaitEvent(c->stream, c->aux_event[2], 0));
+        lane_join.joined = true;
     }
     c->icp_loaded = true;
     MI_TRY(mi_icp_reset(c));

@@ -309,6 +309,7 @@ __device__ __forceinline__ unsigned int grid_rows_mask(int y0, int y1, int z0, i
 
 struct GridLane {
     float q[3];
+    float gx2;                           // squared gap (a lower bound) between the query and the grid's extent along x: every row's test starts from it
     float u1, u2;                        // the query's cell coordinates on y and z
     int cy, cz;                          // its own row (clamped into the grid)
     unsigned long long kbest;            // fp32 bits of the best distance << 32 | its global index
@@ -477,7 +478,7 @@ __device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, uns
             static_assert(GRID_BATCH == 4, "the block's 2 x 2 rows are one batch");
             have = ((j & 1) == 0 || blk.y1 > blk.y0) && ((j & 2) == 0 || blk.z1 > blk.z0);
             iy = (j & 1) ? blk.y1 : blk.y0; iz = (j & 2) ? blk.z1 : blk.z0;
-            g2 = gy2b[j & 1] + gz2b[(j >> 1) & 1];
+            g2 = (gy2b[j & 1] + gz2b[(j >> 1) & 1]) + s.gx2;
         } else {
             have = mask != 0u;
             const int b = have ? __builtin_ctz(mask) : 0;
@@ -485,7 +486,7 @@ __device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, uns
             const int oz = (b * ((256 + GRID_ROWS_W - 1) / GRID_ROWS_W)) >> 8, oy = b - GRID_ROWS_W * oz;   // b / W, b % W (b < 64)
             iy = s.cy + oy - GRID_ROWS_R; iz = s.cz + oz - GRID_ROWS_R;
             const float gy = gap_cells(s.u1, iy) * g.h_lo, gz = gap_cells(s.u2, iz) * g.h_lo;
-            g2 = gy * gy + gz * gz;
+            g2 = (gy * gy + gz * gz) + s.gx2;
         }
         // a row is skipped only if it is strictly farther than the search radius: then it cannot win or tie
         const bool ok = have && s.alive && x1 >= x0 && g2 <= r2;
@@ -603,7 +604,7 @@ __device__ __forceinline__ void grid_rows_dealt(const NnGridView& g, GridLane& s
     const unsigned int first = below(B0) + 2u * below(B1) + 4u * below(B2) + 8u * below(B3) + 16u * below(B4);
     const unsigned long long producers = B0 | B1 | B2 | B3 | B4;
     const unsigned int n_rec = (unsigned int)__builtin_popcountll(producers), rank = below(producers);
-    L.deal_q[lane] = make_float4(s.q[0], s.q[1], s.q[2], r2);
+    L.deal_q[lane] = make_float4(s.q[0], s.q[1], s.q[2], r2 - s.gx2);       // (.w: what a row's y-z gap is tested against -- the x face gap taken off)
     L.deal_key[lane] = s.kbest;
     L.own_x[lane] = (unsigned int)x0 | ((unsigned int)x1 << 16);
     L.own_c[lane] = (unsigned int)s.cy | ((unsigned int)s.cz << 16);
@@ -691,6 +692,41 @@ __device__ __forceinline__ void grid_rows_dealt(const NnGridView& g, GridLane& s
     wave_lds_sync();                                            // (the records are read: the next use of the arrays may write)
 }
 
+// How far the scan of a query reaches (round 5).  The scan looks at the cells within GRID_REACH_CELLS of the query's own (clamped) cell on every
+// axis -- the width of the row masks and of row_occ.  For a query INSIDE the grid's extent that covers every point within two cells: cap = 2 h,
+// rounds 2-4's rule for everybody.  A query OUTSIDE the extent by g cells along an axis (early and middle iterations: a shell of the moving
+// cloud still hangs out of the fixed cloud's box, one chunk in five at iteration 20) has all its candidates on ONE side: a point within r of
+// it differs from it by at least g on that axis, hence by at most sqrt(r^2 - g^2) on the two others -- the lens the sphere cuts out of the
+// cloud's face is two cells wide for r^2 <= 4 + g^2.  In general a point within r lies, on axis a, within sqrt(r^2 - sum_{b != a} g_b^2) of the
+// query, of which g_a is spent before the extent begins: the cells it can be in stay within two of the clamped own cell iff
+//   r^2 <= (g_a + 2)^2 + sum_{b != a} g_b^2   on every axis a,
+// in cell units, every g shrunk by the rounding slack.  Such lanes used to walk the hierarchy whatever the shape of their lens (cap 2 h):
+// 37 % of all wave-time at iteration 20 for 16 % of the lanes (profiles/r04_wave_timeline.log).  Beyond 16 cells outside the relative
+// slacks of the cell arithmetic outgrow the absolute ones: cap 0, those lanes walk as before.
+__device__ __forceinline__ float grid_lane_cap2(const NnGridView& g, float u0, float u1, float u2, float (&gs)[3])
+{
+    gs[0] = fmaxf(fmaxf(-u0, u0 - (float)g.nx) - 1e-3f, 0.f);
+    gs[1] = fmaxf(fmaxf(-u1, u1 - (float)g.ny) - 1e-3f, 0.f);
+    gs[2] = fmaxf(fmaxf(-u2, u2 - (float)g.nz) - 1e-3f, 0.f);
+    const float e = GRID_DU_MAX - 2e-3f;
+    const float s0 = gs[0] * gs[0], s1 = gs[1] * gs[1], s2 = gs[2] * gs[2];
+    const float c0 = (gs[0] + e) * (gs[0] + e) + (s1 + s2), c1 = (gs[1] + e) * (gs[1] + e) + (s0 + s2), c2 = (gs[2] + e) * (gs[2] + e) + (s0 + s1);
+    const float far_out = fmaxf(gs[0], fmaxf(gs[1], gs[2]));
+    const float cells2 = far_out <= 16.f ? fminf(c0, fminf(c1, c2)) : 0.f;
+    return cells2 * (g.h_lo * g.h_lo) * (1.f - 1e-5f);
+}
+__device__ __forceinline__ float grid_lane_cap2(const NnGridView& g, const float q[3])
+{
+    float gs[3];
+    return grid_lane_cap2(g, cell_u(q[0], g.ox, g.inv_h), cell_u(q[1], g.oy, g.inv_h), cell_u(q[2], g.oz, g.inv_h), gs);
+}
+// cells (as a float count) a radius^2 of r2 spans on an axis once the squared face gaps of the two OTHER axes are taken off it; the slack of
+// the cell arithmetic added (raw v_sqrt_f32, 1 ulp: covered by it)
+__device__ __forceinline__ float grid_du(const NnGridView& g, float r2, float other_gaps2)
+{
+    return __builtin_amdgcn_sqrtf(fmaxf(r2 - other_gaps2, 0.f) * 1.000001f) * g.inv_h * 1.00001f + 1e-3f;
+}
+
 // Grid part of one lane's search.  Returns true if the lane gave up (it must then walk the hierarchy from (best, bidx)).
 //
 // The lane tests the points of every cell row within r2 = min(best, cap2) of the query; every point with d <= the FINAL r2 is
@@ -707,9 +743,12 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
                                             )
 {
     const float u0 = cell_u(q[0], g.ox, g.inv_h), u1 = cell_u(q[1], g.oy, g.inv_h), u2 = cell_u(q[2], g.oz, g.inv_h);
-    const float cap = (GRID_DU_MAX - 2e-3f) * g.h_lo;          // every point within `cap` of the query lies within GRID_DU_MAX cells
-    const float cap2 = cap * cap * (1.f - 1e-5f);
+    float gs[3];
+    const float cap2 = grid_lane_cap2(g, u0, u1, u2, gs);      // every point within sqrt(cap2) of the query lies within GRID_REACH_CELLS cells of its clamped own cell
+    // squared face gaps in length units, lower bounds (h_lo): what a point within r has already spent on an axis before the extent begins
+    const float G0 = (gs[0] * g.h_lo) * (gs[0] * g.h_lo), G1 = (gs[1] * g.h_lo) * (gs[1] * g.h_lo), G2 = (gs[2] * g.h_lo) * (gs[2] * g.h_lo);
     GridLane s;
+    s.gx2 = G0;
     s.q[0] = q[0]; s.q[1] = q[1]; s.q[2] = q[2];
     s.u1 = u1; s.u2 = u2;
     s.kbest = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
@@ -724,8 +763,8 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
     // like the points' own cell indices.  raw v_sqrt_f32 (1 ulp): covered by the slack.  du < GRID_DU_MAX, so every row lies
     // within GRID_ROWS_R rows of the query's own: the masks' width.
     float r2 = fminf(best, cap2);
-    float du = __builtin_amdgcn_sqrtf(r2 * 1.000001f) * g.inv_h * 1.00001f + 1e-3f;
-    float fx0 = floorf(u0 - du), fx1 = floorf(u0 + du), fy0 = floorf(u1 - du), fy1 = floorf(u1 + du), fz0 = floorf(u2 - du), fz1 = floorf(u2 + du);
+    float dux = grid_du(g, r2, G1 + G2), duy = grid_du(g, r2, G0 + G2), duz = grid_du(g, r2, G0 + G1);
+    float fx0 = floorf(u0 - dux), fx1 = floorf(u0 + dux), fy0 = floorf(u1 - duy), fy1 = floorf(u1 + duy), fz0 = floorf(u2 - duz), fz1 = floorf(u2 + duz);
     // (alive: geometry only so far; the reach byte joins in inside the first batch)
     s.alive = lane_on && fx1 >= 0.f && fx0 <= (float)(g.nx - 1) && fy1 >= 0.f && fy0 <= (float)(g.ny - 1) && fz1 >= 0.f && fz0 <= (float)(g.nz - 1);
     // ---- the nearest 2 x 2 x 2 block (what of it the starting radius reaches)
@@ -747,8 +786,8 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
 #endif
     // ---- what the radius as it stands now still reaches, minus the rows of the block if their cells were all covered
     r2 = fminf(__uint_as_float((unsigned int)(s.kbest >> 32)), cap2);
-    du = __builtin_amdgcn_sqrtf(r2 * 1.000001f) * g.inv_h * 1.00001f + 1e-3f;
-    fx0 = floorf(u0 - du); fx1 = floorf(u0 + du); fy0 = floorf(u1 - du); fy1 = floorf(u1 + du); fz0 = floorf(u2 - du); fz1 = floorf(u2 + du);
+    dux = grid_du(g, r2, G1 + G2); duy = grid_du(g, r2, G0 + G2); duz = grid_du(g, r2, G0 + G1);
+    fx0 = floorf(u0 - dux); fx1 = floorf(u0 + dux); fy0 = floorf(u1 - duy); fy1 = floorf(u1 + duy); fz0 = floorf(u2 - duz); fz1 = floorf(u2 + duz);
     {
         const int x0 = (int)fmaxf(fx0, 0.f), x1 = (int)fminf(fx1, (float)(g.nx - 1));
         const int y0 = (int)fmaxf(fy0, 0.f), y1 = (int)fminf(fy1, (float)(g.ny - 1));
@@ -773,8 +812,8 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
         // the cells of a row from the radius as it stands now: one range for the whole batch (a superset of what each row's own
         // gap would leave of it)
         r2 = fminf(__uint_as_float((unsigned int)(s.kbest >> 32)), cap2);
-        du = __builtin_amdgcn_sqrtf(r2 * 1.000001f) * g.inv_h * 1.00001f + 1e-3f;
-        const float flo = floorf(u0 - du), fhi = floorf(u0 + du);
+        dux = grid_du(g, r2, G1 + G2);
+        const float flo = floorf(u0 - dux), fhi = floorf(u0 + dux);
 #ifdef MISLAM_DEV_WAVE_TIMELINE
         s.batches_rest += 1;
 #endif
@@ -997,8 +1036,7 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
         row_store_error(e0, e1, row, nullptr);
         {
             // next iteration's class of this chunk: 0 = no lane walked, 1 = some did, 2 = most lanes lie beyond the grid's reach
-            const float cap = (GRID_DU_MAX - 2e-3f) * g.h_lo;
-            const float cap2 = cap * cap * (1.f - 1e-5f);
+            const float cap2 = grid_lane_cap2(g, q);         // (this lane's own reach: grid_search's rule)
             const int beyond = (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && !(best <= cap2)));
             if (tid == 0) a.far[chunk] = beyond >= GRID_WALK_ONLY_MIN ? 2 : (walked ? 1 : 0);
             // (the helper wave's share next time: the lanes the scan cannot serve -- NOT "the lanes that walked", which would keep every lane

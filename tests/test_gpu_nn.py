@@ -141,6 +141,37 @@ def test_grid_boundary_and_outside_queries(ctx, capi, oracle, mode):
     assert np.array_equal(idx, ridx) and np.array_equal(d2.view(np.uint32), rd2.view(np.uint32))
 
 
+@pytest.mark.parametrize("ppc", ["0.5", "1.25", "4"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_grid_serves_queries_outside_the_cloud_exactly(capi, monkeypatch, ppc, mode):
+    # Round 5: a query OUTSIDE the grid's extent by g cells is served by the scan as long as the lens its sphere cuts out of the cloud stays within
+    # two cells of its clamped own cell (r^2 <= (g_a + 2)^2 + the other axes' gaps^2, nn_grid.hip grid_lane_cap2) instead of walking the hierarchy
+    # as soon as its neighbour is farther than two cells.  Shells of queries at 0.3 .. 40 cells outside a uniform cloud -- off faces, edges and
+    # corners, axis by axis and sign by sign -- plus queries whose lens is too wide (sparse corner regions) and that must still fall back: bit for bit
+    # the every-pair search, with and without a starting candidate (plain search: none; fused ICP: the previous match).
+    monkeypatch.setenv("MISLAM_GRID_PPC", ppc)
+    rng = np.random.default_rng(77)
+    tgt = rng.uniform(-5, 5, (24000, 3)).astype(np.float32)
+    tgt = tgt[~((tgt[:, 0] > 3) & (tgt[:, 1] > 3) & (tgt[:, 2] > 3))]             # a corner bitten off: outside queries there see a hollow
+    h = 10.0 / (len(tgt) / float(ppc)) ** (1.0 / 3.0)                            # ~ the cell size the grid will choose
+    parts = []
+    for d_cells in (0.3, 1.0, 1.9, 2.1, 3.0, 4.5, 7.0, 8.5, 12.0, 15.9, 16.1, 25.0, 40.0):
+        for axes in ((0,), (1,), (2,), (0, 1), (1, 2), (0, 2), (0, 1, 2)):
+            q = rng.uniform(-5, 5, (40, 3))
+            for a in axes:
+                sign = rng.choice([-1.0, 1.0], 40)
+                q[:, a] = sign * (5.0 + d_cells * h * rng.uniform(0.9, 1.1, 40))
+            parts.append(q)
+    src = np.concatenate(parts + [rng.uniform(-6, 6, (3000, 3))]).astype(np.float32)
+    with capi.Context(0) as c2:
+        want = c2.nn_search(src, tgt, mode, capi.NN_BRUTEFORCE)
+        got = c2.nn_search(src, tgt, mode, capi.NN_GRID)
+        assert np.array_equal(want[0], got[0]) and np.array_equal(want[1].view(np.uint32), got[1].view(np.uint32))
+        # the fused iteration: starting candidates = previous matches, the moving cloud drifting across the faces of the fixed one
+        runs = [c2.icp_register(src, tgt, capi.icp_params(eps=0.0, max_iterations=5, nn_mode=nn, dist_mode=mode)) for nn in (capi.NN_BRUTEFORCE, capi.NN_GRID)]
+        assert runs[0][2] == runs[1][2] and np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and runs[0][3] == runs[1][3]
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_grid_on_awkward_coordinate_ranges(ctx, capi, mode):
     # coordinates far from the origin (the fp32 lattice is coarser than the cell size: duplicates, crowded cells), a thin slab with

@@ -27,6 +27,9 @@ from reg_soak import frob, problems  # noqa: E402
 import oraclebind as oracle  # noqa: E402
 
 
+SENS_RUNS = 12      # reorderings per flagged case (three missed the tail: seed 4 case 202 shows 9e-4 .. 2.9e-2 over twenty)
+
+
 def contexts(capi):
     os.environ.pop("MISLAM_SVD_IEEE", None)
     fast = capi.Context(0)
@@ -68,14 +71,14 @@ def main():
                 runs[name] = frob(R, t, Ro, to) / scale if np.isfinite(R).all() else float("nan")
             if runs["default"] > floor:
                 sens = 0.0
-                for _ in range(3):      # the same problem, the moving cloud in another order: the oracle against itself
+                for _ in range(SENS_RUNS):      # the same problem, the moving cloud in another order: the oracle against itself
                     Rp, tp = oracle.icp(src[prng.permutation(n)], tgt, eps=0.0, max_iterations=3)[:2]
                     sens = max(sens, frob(Rp, tp, Ro, to) / scale)
                 sv = cond_of_pairs(src, tgt, Ro, to)
                 tally["icp"][0] += 1
                 tally["icp"][1] += runs["ieee"] <= 0.1 * runs["default"]
                 tally["icp"][2] += runs["seq"] <= 0.1 * runs["default"]
-                explained = sens >= 0.3 * runs["default"] or runs["seq"] <= 0.1 * runs["default"]
+                explained = sens >= 0.5 * runs["default"] or runs["seq"] <= 0.1 * runs["default"]
                 tally["icp"][3] += explained
                 if not explained:
                     worst_unexplained["icp"] = max(worst_unexplained["icp"], runs["default"])
@@ -95,13 +98,13 @@ def main():
                         runs[name] = frob(sR, t, Ro, to) / scale if np.isfinite(sR).all() else float("nan")
                     if runs["default"] > floor:
                         sens = 0.0
-                        for _ in range(3):      # both clouds reordered: sigma^2_0's, the E-step's and the M-step's sums round differently
+                        for _ in range(SENS_RUNS):      # both clouds reordered: sigma^2_0's, the E-step's and the M-step's sums round differently
                             pb, pa = prng.permutation(n), prng.permutation(m)
                             Rp, tp = oracle.cpd(src[pb], tgt[pa], eps=0.0, max_iterations=5, tolerance=0.0)[:2]
                             sens = max(sens, frob(Rp, tp, Ro, to) / scale)
                         tally["cpd"][0] += 1
                         tally["cpd"][1] += runs["ieee"] <= 0.1 * runs["default"]
-                        explained = sens >= 0.3 * runs["default"]
+                        explained = sens >= 0.5 * runs["default"]
                         tally["cpd"][2] += explained
                         if not explained:
                             worst_unexplained["cpd"] = max(worst_unexplained["cpd"], runs["default"])
