@@ -224,8 +224,9 @@ static int cpd_trunc_prepare(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
     const size_t na = (size_t)cpd_trunc_tiles(w->n) * CPD_TRUNC_TILE, ny = (size_t)cpd_trunc_tiles(w->m) * CPD_TRUNC_TILE;
     MI_TRY(w->t_ax.reserve(na)); MI_TRY(w->t_ay.reserve(na)); MI_TRY(w->t_az.reserve(na)); MI_TRY(w->t_xw4.reserve(na));
     MI_TRY(w->t_yx.reserve(ny)); MI_TRY(w->t_yy.reserve(ny)); MI_TRY(w->t_yz.reserve(ny));
-    MI_TRY(w->t_abox.reserve(6 * (size_t)cpd_trunc_tiles(w->n)));
-    MI_TRY(w->t_ybox.reserve(6 * (size_t)cpd_trunc_tiles(w->m)));
+    constexpr int per_tile = 1 + CPD_TRUNC_TILE / CPD_TRUNC_GROUP;          // a tile's box + its groups' boxes
+    MI_TRY(w->t_abox.reserve(6 * (size_t)per_tile * cpd_trunc_tiles(w->n)));
+    MI_TRY(w->t_ybox.reserve(6 * (size_t)per_tile * cpd_trunc_tiles(w->m)));
     // the fixed cloud along its curve; the moving cloud along the curve of its ORIGINAL points (a similarity transform keeps neighbours together)
     MortonArgs ma{};
     ma.bbox_partials = w->t_bbox.p; ma.bbox = w->t_bbox.p + 256 * 6;
@@ -235,7 +236,8 @@ static int cpd_trunc_prepare(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
     MI_HIP(morton_order(ma, c->stream));
     ma.x = v.bx; ma.y = v.by; ma.z = v.bz; ma.m = w->m; ma.order_out = w->t_border.p;
     MI_HIP(morton_order(ma, c->stream));
-    MI_HIP(cpd_trunc_gather(v.ax, v.ay, v.az, w->t_aorder.p, w->n, w->t_ax.p, w->t_ay.p, w->t_az.p, w->t_abox.p, nullptr, c->stream));
+    MI_HIP(cpd_trunc_gather(v.ax, v.ay, v.az, w->t_aorder.p, w->n, w->t_ax.p, w->t_ay.p, w->t_az.p, w->t_abox.p,
+                            w->t_abox.p + 6 * (size_t)cpd_trunc_tiles(w->n), nullptr, c->stream));
     w->trunc_ready = true;
     return MI_OK;
 }
@@ -246,17 +248,18 @@ static int cpd_estep_trunc_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
     CpdTruncView t{};
     t.state = v.state;
     t.ax = w->t_ax.p; t.ay = w->t_ay.p; t.az = w->t_az.p;
-    t.abox = w->t_abox.p;
+    t.abox = w->t_abox.p; t.agroup = w->t_abox.p + 6 * (size_t)cpd_trunc_tiles(w->n);
     t.a_order = w->t_aorder.p; t.n = w->n;
     t.yx = w->t_yx.p; t.yy = w->t_yy.p; t.yz = w->t_yz.p;
-    t.ybox = w->t_ybox.p;
+    t.ybox = w->t_ybox.p; t.ygroup = w->t_ybox.p + 6 * (size_t)cpd_trunc_tiles(w->m);
     t.b_order = w->t_border.p; t.m = w->m;
     t.bx = v.bx; t.by = v.by; t.bz = v.bz;
     t.xw4 = w->t_xw4.p; t.xw4_caller = v.xw4; t.pt1 = v.pt1; t.p1 = v.p1; t.px = v.px;
     t.trunc_log = v.trunc_log;
     const int nxb = std::min(CPD_TRUNC_MAX_BLOCKS, cpd_trunc_tiles(w->n)), nkb = std::min(CPD_TRUNC_MAX_BLOCKS, cpd_trunc_tiles(w->m));
     // the moving cloud's current positions in curve order + this E-step's boxes
-    MI_HIP(cpd_trunc_gather(v.yx, v.yy, v.yz, w->t_border.p, w->m, w->t_yx.p, w->t_yy.p, w->t_yz.p, w->t_ybox.p, v.state, c->stream));
+    MI_HIP(cpd_trunc_gather(v.yx, v.yy, v.yz, w->t_border.p, w->m, w->t_yx.p, w->t_yy.p, w->t_yz.p, w->t_ybox.p,
+                            w->t_ybox.p + 6 * (size_t)cpd_trunc_tiles(w->m), v.state, c->stream));
     { ProfScope ps(c, MI_KERNEL_CPD_DENOM); MI_HIP(cpd_trunc_denominators(t, w->part_x.p, nxb, c->stream)); }
     { ProfScope ps(c, MI_KERNEL_CPD_CONTRACT); MI_HIP(cpd_trunc_contract(t, w->part_k.p, nkb, c->stream)); }
     w->sums_fresh = true;
@@ -419,8 +422,9 @@ static float fgt_ndi(float sigma2, float weight, int m, int n)
     return (float)((std::pow(2 * 3.14159265358979323846 * sigma2, (double)(3.f * 0.5f)) * weight * m) / (double)((1 - weight) * n));
 }
 
+// with_sums: the two post kernels also leave the M-step's x-sums / k-sums (the driver's E-steps; a stand-alone E-step reads P1 / Pt1 / PX back instead)
 static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, float weight, float sigma2, float sigma2_init,
-                                 float ratio_of_far_field, int order)
+                                 float ratio_of_far_field, int order, bool with_sums = false)
 {
     ProfScope ps(c, MI_KERNEL_CPD_FGT);
     w->sums_fresh = false;               // P1 / Pt1 / PX come from the transform below, not from the exact E-step's post kernels
@@ -446,24 +450,29 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
     // (prelaunched: the same replay went onto the stream behind the last transform, cpd_fgt_prelaunch below -- K has not shrunk below the guess)
     cy.replay_done = f->y.prelaunched > 0 && f->y.prelaunched == fgt_replay_limit(cy.guess, cy.K) ? 1 : 0;
     f->y.prelaunched = 0;
+    cy.centers_in_model = 1;                 // (round 5: the cell means come out of the model kernel -- one launch less per side)
     MI_HIP(fgt_cluster(cy, f->sort_temp.p, temp, c->stream));
     f->y.guess_K = K;
-    MI_HIP(fgt_model(cy, nullptr, hsigma, t, f->By.p, c->stream));
+    MI_HIP(fgt_model(cy, nullptr, hsigma, t, f->By.p, c->stream, true));
     MI_HIP(fgt_predict(v.ax, v.ay, v.az, w->n, cy.xc, f->By.p, K, 1, hsigma, ratio_of_far_field, t, Sa, f->kt1.p, c->stream));
-    MI_HIP(fgt_post_kt1(f->kt1.p, Sa, v.ax, v.ay, v.az, w->n, ndi, v.pt1, v.xw4, c->stream));
+    const int nxb = cpd_standalone_sum_blocks(w->n), nkb = cpd_standalone_sum_blocks(w->m);
+    MI_HIP(fgt_post_kt1(f->kt1.p, Sa, v.ax, v.ay, v.az, w->n, ndi, v.pt1, v.xw4, c->stream, with_sums ? w->part_x.p : nullptr, nxb));
     // P1 and PX: sources = fixed cloud weighted by 1/den and x/den, queried at the moving cloud   (:54-66; the reference
     // clusters the fixed cloud four times with the same result -- once is enough)
     // the fixed cloud does not move: the same K needs no new clustering at all, a larger K only the additional centres
     // (a context created under MISLAM_FGT_RESUME=0 re-clusters from scratch every time; the results must not change by a bit -- tests/test_gpu_fgt.py)
     const bool resume = c->tune.fgt_resume != 0;
-    if (!resume || f->a.swept_K != K) {
+    const bool recluster = !resume || f->a.swept_K != K;
+    if (recluster) {
         ca.k_done = resume && f->a.swept_K < K ? f->a.swept_K : 0;
+        ca.centers_in_model = 1;
         MI_HIP(fgt_cluster(ca, f->sort_temp.p, temp, c->stream));
         f->a.swept_K = K;
     }
-    MI_HIP(fgt_model(ca, v.xw4, hsigma, t, f->Ba.p, c->stream));
+    MI_HIP(fgt_model(ca, v.xw4, hsigma, t, f->Ba.p, c->stream, recluster));      // (an unchanged clustering keeps its means)
     MI_HIP(fgt_predict(v.yx, v.yy, v.yz, w->m, ca.xc, f->Ba.p, K, 4, hsigma, ratio_of_far_field, t, Sy, f->v4.p, c->stream));
-    MI_HIP(fgt_post_px(f->v4.p, Sy, w->m, v.p1, v.px, c->stream));
+    MI_HIP(fgt_post_px(f->v4.p, Sy, w->m, v.p1, v.px, c->stream, with_sums ? w->part_k.p : nullptr, nkb, v.bx, v.by, v.bz));
+    if (with_sums) { w->sums_fresh = true; w->sum_rows_x = nxb; w->sum_rows_k = nkb; }
     return MI_OK;
 }
 
@@ -562,7 +571,7 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
                 }
                 if (fgt) {
                     MI_TRY(cpd_estep_fgt_enqueue(c, w, v, rules.weight, sigma2, sigma2_init, params->fgt_ratio_of_far_field,
-                                                 params->fgt_order_of_truncation));
+                                                 params->fgt_order_of_truncation, true));
                 } else {
                     CpdView vt = v;
                     vt.truncate = 1;

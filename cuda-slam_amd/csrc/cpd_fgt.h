@@ -40,6 +40,7 @@ struct FgtClusters {
     unsigned long long* replay_partial;   // [fgt_replay_limit(guess, K)][fgt_replay_waves(n)]
     int* replay_state;                    // [1]  -> the number of leading steps of the guess that were verified
     int replay_done;                      // the replay of this guess is on the stream already (fgt_replay_prelaunch): fgt_cluster only resumes from its verdict
+    int centers_in_model;                 // round 5: fgt_cluster leaves the cluster means to the model build that follows (fgt_model(..., centers = true)): one launch less
 };
 constexpr int FGT_REPLAY_MAX_CENTRES = 4000;       // centres a replay stages in LDS (16 bytes each)
 int fgt_replay_waves(int n);
@@ -53,16 +54,21 @@ size_t fgt_sort_temp_bytes(int n);     // scratch fgt_cluster needs for its memb
 hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
 // coefficients B[w][k][hpos] = C_k * sum_{i in cluster k} weight_w(i) exp(-|dx|^2) dx^alpha, dx = (pt - xc_k) / sigma.
 // w4 == nullptr: one weight set of ones (W = 1); else four: (w4.x, w4.y, w4.z, w4.w) (W = 4).
-hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const FgtTables& t, float* B, hipStream_t s);
+// centers: compute the cluster means first, in the same kernel (what fgt_centers_kernel would have left in c.xc, the same bits), for a
+// clustering made with centers_in_model.
+hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const FgtTables& t, float* B, hipStream_t s, bool centers = false);
 // v[split][w][i] = sum_{k in split} [ |dy|^2 <= e ] exp(-|dy|^2) sum_alpha B[w][k][alpha] dy^alpha, dy = (q_i - xc_k) / sigma
 // (fgt.cpp:88-150); the S = fgt_predict_splits(nq, K) partial sums are added in split order by the post kernels
 int fgt_predict_splits(int nq, int K);
 hipError_t fgt_predict(const float* qx, const float* qy, const float* qz, int nq, const float* xc, const float* B, int K, int W,
                        float sigma, float e_param, const FgtTables& t, int S, float* v, hipStream_t s);
 // Kt1 -> 1/denominator, Pt1 and the four weight sets of the second transform (cpdutils.cpp:45-52, :79-99)
+// (xpartials != null: + the M-step's x-sums of what it has just produced, in nblocks rows of CPD_XSUMS -- the terms, the grouping and hence the
+// bits of cpd_xsums_kernel launched with the same nblocks; round 5: two launches less per FGT iteration with the k-sums below)
 hipError_t fgt_post_kt1(const float* kt1_parts, int S, const float* ax, const float* ay, const float* az, int n, float ndi, float* pt1,
-                        float4* xw4, hipStream_t s);
-// v[S][4][m] -> P1[m], PX[m][3]
-hipError_t fgt_post_px(const float* v_parts, int S, int m, float* p1, float* px, hipStream_t s);
+                        float4* xw4, hipStream_t s, double* xpartials = nullptr, int nblocks = 0);
+// v[S][4][m] -> P1[m], PX[m][3]   (kpartials != null: + the M-step's k-sums, as cpd_ksums_kernel; b = the original moving cloud)
+hipError_t fgt_post_px(const float* v_parts, int S, int m, float* p1, float* px, hipStream_t s, double* kpartials = nullptr, int nblocks = 0,
+                       const float* bx = nullptr, const float* by = nullptr, const float* bz = nullptr);
 
 }  // namespace mislam

@@ -23,6 +23,8 @@
 #include <cstring>
 
 #include "cpd_fgt.h"
+#include "cpd_kernels.h"
+#include "reduce.hpp"
 
 namespace mislam {
 
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(FGT_TILE) void fgt_centers_kernel(const float* __re
 // reference's order.  Per tile of 128 members each lane prepares ONE member (powers of its scaled offset, exp(-|dx|^2),
 // weights) in LDS; all lanes then walk the tile: three power look-ups, three multiplies and W multiply-adds per member.
 // ---------------------------------------------------------------------------------------------------------------
-template <int W>
+template <int W, bool CENTERS>
 __global__ __launch_bounds__(FGT_TILE) void fgt_model_kernel(FgtClusters c, const float4* __restrict__ w4, float inv_sigma, FgtTables t,
                                                              float* __restrict__ B)
 {
@@ -508,11 +510,40 @@ __global__ __launch_bounds__(FGT_TILE) void fgt_model_kernel(FgtClusters c, cons
     const bool live = m < t.pd;
     const unsigned int e = t.mono[live ? m : 0];
     const int ea = e & 0xff, eb = (e >> 8) & 0xff, ec = (e >> 16) & 0xff;
-    const float cx = c.xc[3 * k], cy = c.xc[3 * k + 1], cz = c.xc[3 * k + 2];
+    const int j0 = c.off[k], j1 = c.off[k + 1];
+    float cx, cy, cz;
+    if (CENTERS) {
+        // the cell's mean first -- fgt_centers_kernel's arithmetic (sequential fp32 sums in ascending point order, * (1.0f / count): fgt.cpp:195-210),
+        // here instead of in a launch of its own; every workgroup of the cell computes it, the first one leaves it in xc for the transform
+        __shared__ float sc[3][FGT_TILE];
+        __shared__ float mean[3];
+        float sum = 0.f;
+        for (int base = j0; base < j1; base += FGT_TILE) {
+            const int cnt = min(FGT_TILE, j1 - base);
+            if (tid < cnt) {
+                const int i = c.memb[base + tid];
+                sc[0][tid] = c.x[i]; sc[1][tid] = c.y[i]; sc[2][tid] = c.z[i];
+            }
+            __syncthreads();
+            if (tid < 3) {
+#pragma unroll 8
+                for (int q = 0; q < cnt; q++) sum += sc[tid][q];
+            }
+            __syncthreads();
+        }
+        if (tid < 3) {
+            const float v = sum * (1.0f / (float)(j1 - j0));     // (an empty cell: 0 * inf = NaN, exactly as the reference)
+            mean[tid] = v;
+            if (blockIdx.y == 0) c.xc[3 * k + tid] = v;
+        }
+        __syncthreads();
+        cx = mean[0]; cy = mean[1]; cz = mean[2];
+    } else {
+        cx = c.xc[3 * k]; cy = c.xc[3 * k + 1]; cz = c.xc[3 * k + 2];
+    }
     float acc[W];
 #pragma unroll
     for (int w = 0; w < W; w++) acc[w] = 0.f;
-    const int j0 = c.off[k], j1 = c.off[k + 1];
     for (int base = j0; base < j1; base += FGT_TILE) {
         const int cnt = min(FGT_TILE, j1 - base);
         if (tid < cnt) {
@@ -645,31 +676,53 @@ __global__ __launch_bounds__(64) void fgt_predict_kernel(const float* __restrict
     }
 }
 
+// (grid-stride over the points: with xpartials the workgroup count is the M-step's row count -- cpd_xsums_kernel's own mapping, terms and order)
 __global__ __launch_bounds__(256) void fgt_post_kt1_kernel(const float* __restrict__ kt1_parts, int S, const float* __restrict__ ax,
                                                            const float* __restrict__ ay, const float* __restrict__ az, int n, float ndi,
-                                                           float* __restrict__ pt1, float4* __restrict__ xw4)
+                                                           float* __restrict__ pt1, float4* __restrict__ xw4, double* __restrict__ xpartials)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float kt1 = 0.f;
-    for (int sp = 0; sp < S; sp++) kt1 += kt1_parts[(size_t)sp * n + i];
-    const float inv = 1.0f / (kt1 + ndi);                          // cpdutils.cpp:49
-    pt1[i] = 1.0f - ndi * inv;                                     // CalculatePt1, cpdutils.cpp:79-88
-    xw4[i] = make_float4(ax[i] * inv, ay[i] * inv, az[i] * inv, inv);   // CalculateWeightsForPX :90-99; .w doubles as 1/denominator
+    double acc[CPD_XSUMS] = {0};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float kt1 = 0.f;
+        for (int sp = 0; sp < S; sp++) kt1 += kt1_parts[(size_t)sp * n + i];
+        const float inv = 1.0f / (kt1 + ndi);                          // cpdutils.cpp:49
+        const float x = ax[i], y = ay[i], z = az[i];
+        const float p = 1.0f - ndi * inv;                              // CalculatePt1, cpdutils.cpp:79-88
+        pt1[i] = p;
+        xw4[i] = make_float4(x * inv, y * inv, z * inv, inv);          // CalculateWeightsForPX :90-99; .w doubles as 1/denominator
+        if (xpartials != nullptr) {
+            acc[0] += (double)logf(1.0f / inv);                         // error -= log(denominator), cpdutils.cpp:69-71
+            acc[1] += (double)x * p; acc[2] += (double)y * p; acc[3] += (double)z * p;
+            acc[4] += (double)(x * x) * p + (double)(y * y) * p + (double)(z * z) * p;     // coherentpointdrift.cpp:257
+        }
+    }
+    if (xpartials != nullptr) block_sum_store<CPD_XSUMS>(acc, xpartials + (size_t)blockIdx.x * CPD_XSUMS);
 }
 
 __global__ __launch_bounds__(256) void fgt_post_px_kernel(const float* __restrict__ v_parts, int S, int m, float* __restrict__ p1,
-                                                          float* __restrict__ px)
+                                                          float* __restrict__ px, double* __restrict__ kpartials, const float* __restrict__ bx,
+                                                          const float* __restrict__ by, const float* __restrict__ bz)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= m) return;
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int sp = 0; sp < S; sp++)
-        for (int w = 0; w < 4; w++) a[w] += v_parts[((size_t)sp * 4 + w) * m + k];
-    px[3 * (size_t)k] = a[0];
-    px[3 * (size_t)k + 1] = a[1];
-    px[3 * (size_t)k + 2] = a[2];
-    p1[k] = a[3];
+    double acc[CPD_KSUMS] = {0};
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < m; k += gridDim.x * 256) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < S; sp++)
+            for (int w = 0; w < 4; w++) a[w] += v_parts[((size_t)sp * 4 + w) * m + k];
+        px[3 * (size_t)k] = a[0];
+        px[3 * (size_t)k + 1] = a[1];
+        px[3 * (size_t)k + 2] = a[2];
+        p1[k] = a[3];
+        if (kpartials != nullptr) {
+            const float b[3] = {bx[k], by[k], bz[k]};
+            acc[0] += (double)a[3];
+            for (int r = 0; r < 3; r++) {
+                acc[1 + r] += (double)b[r] * a[3];
+                for (int c = 0; c < 3; c++) acc[4 + 3 * r + c] += (double)b[r] * a[c];
+                acc[13] += (double)(b[r] * b[r]) * a[3];                                          // coherentpointdrift.cpp:259
+            }
+        }
+    }
+    if (kpartials != nullptr) block_sum_store<CPD_KSUMS>(acc, kpartials + (size_t)blockIdx.x * CPD_KSUMS);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -765,16 +818,21 @@ hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_b
         hipLaunchKernelGGL(fgt_lists_offsets_kernel, dim3(1), dim3(1024), 0, s, tot, c.K, c.off);
         hipLaunchKernelGGL((fgt_lists_pass_kernel<true, false>), dim3(G), dim3(64), lds ? sizeof(int) * (size_t)c.K : 0, s, c.indx, c.n, c.K, chunk, label_bits, H, tot, c.off, c.memb);
     }
-    hipLaunchKernelGGL(fgt_centers_kernel, dim3(c.K), dim3(FGT_TILE), 0, s, c.x, c.y, c.z, c.memb, c.off, c.K, c.xc);
+    if (!c.centers_in_model) hipLaunchKernelGGL(fgt_centers_kernel, dim3(c.K), dim3(FGT_TILE), 0, s, c.x, c.y, c.z, c.memb, c.off, c.K, c.xc);
     return hipGetLastError();
 }
 
-hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const FgtTables& t, float* B, hipStream_t s)
+hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const FgtTables& t, float* B, hipStream_t s, bool centers)
 {
     const float inv = 1.0f / sigma;                                // fgt.cpp:260
     const dim3 grid(c.K, (t.pd + FGT_TILE - 1) / FGT_TILE);
-    if (w4) hipLaunchKernelGGL(fgt_model_kernel<4>, grid, dim3(FGT_TILE), 0, s, c, w4, inv, t, B);
-    else hipLaunchKernelGGL(fgt_model_kernel<1>, grid, dim3(FGT_TILE), 0, s, c, w4, inv, t, B);
+    if (centers) {
+        if (w4) hipLaunchKernelGGL((fgt_model_kernel<4, true>), grid, dim3(FGT_TILE), 0, s, c, w4, inv, t, B);
+        else hipLaunchKernelGGL((fgt_model_kernel<1, true>), grid, dim3(FGT_TILE), 0, s, c, w4, inv, t, B);
+    } else {
+        if (w4) hipLaunchKernelGGL((fgt_model_kernel<4, false>), grid, dim3(FGT_TILE), 0, s, c, w4, inv, t, B);
+        else hipLaunchKernelGGL((fgt_model_kernel<1, false>), grid, dim3(FGT_TILE), 0, s, c, w4, inv, t, B);
+    }
     return hipGetLastError();
 }
 
@@ -802,15 +860,18 @@ hipError_t fgt_predict(const float* qx, const float* qy, const float* qz, int nq
 }
 
 hipError_t fgt_post_kt1(const float* kt1_parts, int S, const float* ax, const float* ay, const float* az, int n, float ndi, float* pt1,
-                        float4* xw4, hipStream_t s)
+                        float4* xw4, hipStream_t s, double* xpartials, int nblocks)
 {
-    hipLaunchKernelGGL(fgt_post_kt1_kernel, dim3((n + 255) / 256), dim3(256), 0, s, kt1_parts, S, ax, ay, az, n, ndi, pt1, xw4);
+    const int blocks = xpartials != nullptr ? nblocks : (n + 255) / 256;
+    hipLaunchKernelGGL(fgt_post_kt1_kernel, dim3(blocks), dim3(256), 0, s, kt1_parts, S, ax, ay, az, n, ndi, pt1, xw4, xpartials);
     return hipGetLastError();
 }
 
-hipError_t fgt_post_px(const float* v_parts, int S, int m, float* p1, float* px, hipStream_t s)
+hipError_t fgt_post_px(const float* v_parts, int S, int m, float* p1, float* px, hipStream_t s, double* kpartials, int nblocks, const float* bx,
+                       const float* by, const float* bz)
 {
-    hipLaunchKernelGGL(fgt_post_px_kernel, dim3((m + 255) / 256), dim3(256), 0, s, v_parts, S, m, p1, px);
+    const int blocks = kpartials != nullptr ? nblocks : (m + 255) / 256;
+    hipLaunchKernelGGL(fgt_post_px_kernel, dim3(blocks), dim3(256), 0, s, v_parts, S, m, p1, px, kpartials, bx, by, bz);
     return hipGetLastError();
 }
 

@@ -66,17 +66,18 @@ struct CpdView {
 
 // K7t: the truncated E-step of the hybrid mode, culled by tile boxes along a space-filling curve (cpd_trunc.hip)
 constexpr int CPD_TRUNC_TILE = 64;        // points per tile = one wave
+constexpr int CPD_TRUNC_GROUP = 16;       // points per group: what is tested and staged on the side that is streamed
 constexpr int CPD_TRUNC_MAX_BLOCKS = 4096;   // workgroups (= rows of M-step partial sums) of its two kernels
 struct CpdTruncView {
     CpdState* state;
     // fixed cloud in curve order (padded to whole tiles), its tile boxes (component-major: [6][tiles]), sorted slot -> caller's index
     const float *ax, *ay, *az;
-    const float* abox;
+    const float *abox, *agroup;           // boxes of its tiles of 64 / groups of 16
     const int* a_order;
     int n;
     // moving cloud: CURRENT positions in the curve order of the original cloud (padded to whole tiles), boxes of this E-step, slot -> caller's index
     const float *yx, *yy, *yz;
-    const float* ybox;
+    const float *ybox, *ygroup;
     const int* b_order;
     int m;
     const float *bx, *by, *bz;            // the original moving cloud, caller's order (M-step k-sums)
@@ -87,7 +88,7 @@ struct CpdTruncView {
 };
 // out = in[order] (padded to whole tiles with copies of the last point) and the tiles' boxes; state != null: nothing once it says done
 hipError_t cpd_trunc_gather(const float* x, const float* y, const float* z, const int* order, int n, float* ox, float* oy, float* oz,
-                            float* tile_box, const CpdState* state, hipStream_t s);
+                            float* tile_box, float* group_box, const CpdState* state, hipStream_t s);
 hipError_t cpd_trunc_denominators(const CpdTruncView& v, double* xpartials, int nblocks, hipStream_t s);   // den, Pt1, xw4 + the M-step's x-sums
 hipError_t cpd_trunc_contract(const CpdTruncView& v, double* kpartials, int nblocks, hipStream_t s);       // P1, PX + the M-step's k-sums
 

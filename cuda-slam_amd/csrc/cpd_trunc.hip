@@ -10,7 +10,11 @@
 // waves owns a tile (lane = point); the OTHER cloud's tiles are dealt to the four waves round-robin, every lane tests ONE tile's box against the
 // owner's (64 box tests per wave and step, no dependent chain), and a tile whose box is farther from the owner's than the truncation radius is
 // skipped before any exp: every pair in it has its exponent below log(truncate) and would have added 0.0f.  A tile that survives is staged through
-// LDS (one coalesced load, then 64 broadcast reads) and evaluated for all 64 owners; the four waves' partial sums are added in wave order.
+// LDS (one coalesced load, then broadcast reads) and evaluated for all 64 owners; the four waves' partial sums are added in wave order.
+// What is tested and staged on the OTHER side are GROUPS of 16 points with boxes of their own, four groups to a load: 64 consecutive points of a
+// surface along the curve span 1.0 x 1.5 x 1.1 length units on the bunny clouds (10 units across), and with whole tiles on both sides 11 tiles
+// survived per owner tile even at a truncation radius of 0.12 (26 - 40 us per kernel with next to nothing in reach; a quarter of a tile is half as
+// wide).
 // (First form, measured on the bunny clouds: ONE wave per owner tile walking super-tiles and tiles through scalar loads -- a chain of ~250 dependent
 // scalar round trips per wave, 0.10 ms per kernel with NOTHING in reach, slower than the every-pair kernel; profiles/r05_cpd_bench.log.)  Skipping a term that is exactly zero does not change a floating-point sum, so the only difference to the unculled kernel is the ORDER of
 // the remaining terms (curve order instead of the caller's order): P1 / Pt1 / PX agree with it, and with the reference's sequential sums, to the
@@ -61,32 +65,48 @@ __device__ __forceinline__ float wave_max_f32(float v)
     return v;
 }
 
-// out[s] = in[order[s]] for the n points of a cloud (entries up to the next multiple of 64 replicate the last one: they are never summed, they
-// only keep a tile's tail in bounds) and the box of every tile of 64, component-major (tile_box[q * n_tiles + tile], q = lo xyz, hi xyz: the
-// lane-parallel box tests read it coalesced).  One wave per tile.
+// out[s] = in[order[s]] for the n points of a cloud (entries up to the next multiple of 64 replicate the last one: they keep a tile's tail in bounds
+// and leave the boxes alone; the kernels below stage points past the cloud's end as points at infinity -- exponent -inf, affinity exactly 0), the box
+// of every tile of 64 and of every GROUP of 16, component-major (box[q * count + index], q = lo xyz, hi xyz: the lane-parallel box tests read them
+// coalesced).  One wave per tile.
 __global__ __launch_bounds__(256) void cpd_trunc_gather_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
                                                                const int* __restrict__ order, int n, float* __restrict__ ox, float* __restrict__ oy,
-                                                               float* __restrict__ oz, float* __restrict__ tile_box, const CpdState* __restrict__ state)
+                                                               float* __restrict__ oz, float* __restrict__ tile_box, float* __restrict__ group_box,
+                                                               const CpdState* __restrict__ state)
 {
     if (state != nullptr && state->done != 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = blockIdx.x * 4 + wave;
-    const int n_tiles = (n + CPD_TRUNC_TILE - 1) / CPD_TRUNC_TILE;
+    const int n_tiles = (n + CPD_TRUNC_TILE - 1) / CPD_TRUNC_TILE, n_groups = n_tiles * (CPD_TRUNC_TILE / CPD_TRUNC_GROUP);
     if (tile >= n_tiles) return;
     const int s = tile * CPD_TRUNC_TILE + lane;
     const int j = order[min(s, n - 1)];
     const float px = x[j], py = y[j], pz = z[j];
     ox[s] = px; oy[s] = py; oz[s] = pz;                      // (s < n_tiles * 64: the arrays are padded to whole tiles)
-    const float b[6] = {wave_min_f32(px), wave_min_f32(py), wave_min_f32(pz), wave_max_f32(px), wave_max_f32(py), wave_max_f32(pz)};
+    float b[6] = {px, py, pz, px, py, pz};
+#pragma unroll
+    for (int m = 1; m < CPD_TRUNC_GROUP; m <<= 1) {          // within the lane's group of 16
+#pragma unroll
+        for (int q = 0; q < 3; q++) { b[q] = fminf(b[q], __shfl_xor(b[q], m, 64)); b[3 + q] = fmaxf(b[3 + q], __shfl_xor(b[3 + q], m, 64)); }
+    }
+    if ((lane & (CPD_TRUNC_GROUP - 1)) < 6) {
+        const int q = lane & (CPD_TRUNC_GROUP - 1);
+        group_box[(size_t)q * n_groups + tile * (CPD_TRUNC_TILE / CPD_TRUNC_GROUP) + lane / CPD_TRUNC_GROUP] = b[q];
+    }
+#pragma unroll
+    for (int m = CPD_TRUNC_GROUP; m < 64; m <<= 1) {         // ... then across the tile's groups
+#pragma unroll
+        for (int q = 0; q < 3; q++) { b[q] = fminf(b[q], __shfl_xor(b[q], m, 64)); b[3 + q] = fmaxf(b[3 + q], __shfl_xor(b[3 + q], m, 64)); }
+    }
     if (lane < 6) tile_box[(size_t)lane * n_tiles + tile] = b[lane];
 }
 
-// squared gap between box T of `boxes` (component-major, n_tiles per component) and the box `mine`: a lower bound of the squared distance of any
+// squared gap between box T of `boxes` (component-major, `count` per component) and the box `mine`: a lower bound of the squared distance of any
 // two points, one from each
-__device__ __forceinline__ float box_gap2(const float* __restrict__ boxes, int n_tiles, int T, const float (&mine)[6])
+__device__ __forceinline__ float box_gap2(const float* __restrict__ boxes, int count, int T, const float (&mine)[6])
 {
-    const float lo_x = boxes[T], lo_y = boxes[(size_t)n_tiles + T], lo_z = boxes[2 * (size_t)n_tiles + T];
-    const float hi_x = boxes[3 * (size_t)n_tiles + T], hi_y = boxes[4 * (size_t)n_tiles + T], hi_z = boxes[5 * (size_t)n_tiles + T];
+    const float lo_x = boxes[T], lo_y = boxes[(size_t)count + T], lo_z = boxes[2 * (size_t)count + T];
+    const float hi_x = boxes[3 * (size_t)count + T], hi_y = boxes[4 * (size_t)count + T], hi_z = boxes[5 * (size_t)count + T];
     const float gx = fmaxf(fmaxf(lo_x - mine[3], mine[0] - hi_x), 0.f);
     const float gy = fmaxf(fmaxf(lo_y - mine[4], mine[1] - hi_y), 0.f);
     const float gz = fmaxf(fmaxf(lo_z - mine[5], mine[2] - hi_z), 0.f);
@@ -102,8 +122,29 @@ __device__ __forceinline__ void trunc_wave_sync()
 }
 
 constexpr int CPD_TRUNC_WAVES = 4;
+constexpr int CPD_TRUNC_PER_LOAD = CPD_TRUNC_TILE / CPD_TRUNC_GROUP;      // surviving groups one staging load brings in (a lane each point)
 
-// ---- denominators: a workgroup per tile of the FIXED cloud (lane = fixed point x, in each of the four waves), the moving cloud's tiles dealt to
+// The next (up to) four surviving groups of `todo` (bit b = group base + b * WAVES + wave), as this lane's point to stage -- lane L stages point
+// L % 16 of the (L / 16)-th of them -- and how many groups that was.  Groups are taken in ascending order: every sum keeps a fixed order.
+__device__ __forceinline__ int trunc_next_groups(unsigned long long& todo, int base, int wave, int lane, int& my_point)
+{
+    int ids[CPD_TRUNC_PER_LOAD], count = 0;
+#pragma unroll
+    for (int b = 0; b < CPD_TRUNC_PER_LOAD; b++) {
+        ids[b] = 0;
+        if (todo != 0ull) {
+            ids[b] = base + (int)__builtin_ctzll(todo) * CPD_TRUNC_WAVES + wave;
+            todo &= todo - 1ull;
+            count++;
+        }
+    }
+    const int slot = lane / CPD_TRUNC_GROUP;
+    const int g = slot == 0 ? ids[0] : slot == 1 ? ids[1] : slot == 2 ? ids[2] : ids[3];
+    my_point = slot < count ? g * CPD_TRUNC_GROUP + (lane & (CPD_TRUNC_GROUP - 1)) : -1;
+    return count;
+}
+
+// ---- denominators: a workgroup per tile of the FIXED cloud (lane = fixed point x, in each of the four waves), the moving cloud's groups dealt to
 // the waves
 __global__ __launch_bounds__(64 * CPD_TRUNC_WAVES) void cpd_trunc_den_kernel(CpdTruncView v, double* __restrict__ xpartials)
 {
@@ -114,7 +155,9 @@ __global__ __launch_bounds__(64 * CPD_TRUNC_WAVES) void cpd_trunc_den_kernel(Cpd
     const float c = v.state->constant;
     const float mult = -0.5f / v.state->sigma2;              // coherentpointdrift.cpp:176
     const float reach2 = (v.trunc_log / mult) * 1.0001f;     // pairs farther apart than this have index < trunc_log (slack: see the head of the file)
-    const int n_tiles_a = (v.n + CPD_TRUNC_TILE - 1) / CPD_TRUNC_TILE, n_tiles_y = (v.m + CPD_TRUNC_TILE - 1) / CPD_TRUNC_TILE;
+    const int n_tiles_a = (v.n + CPD_TRUNC_TILE - 1) / CPD_TRUNC_TILE;
+    const int n_groups_y = (v.m + CPD_TRUNC_TILE - 1) / CPD_TRUNC_TILE * CPD_TRUNC_PER_LOAD;
+    const float far = __builtin_inff();
     double acc[CPD_XSUMS] = {0};
     for (int tile = blockIdx.x; tile < n_tiles_a; tile += gridDim.x) {
         const int i = tile * CPD_TRUNC_TILE + lane;
@@ -123,29 +166,26 @@ __global__ __launch_bounds__(64 * CPD_TRUNC_WAVES) void cpd_trunc_den_kernel(Cpd
 #pragma unroll
         for (int q = 0; q < 6; q++) mine[q] = v.abox[(size_t)q * n_tiles_a + tile];   // wave-uniform -> scalar loads
         float sum = 0.f;
-        for (int base = 0; base < n_tiles_y; base += 64 * CPD_TRUNC_WAVES) {
-            const int T = base + lane * CPD_TRUNC_WAVES + wave;                 // this lane's tile to test: tiles are dealt to the waves round-robin
-            const bool in_reach = T < n_tiles_y && box_gap2(v.ybox, n_tiles_y, min(T, n_tiles_y - 1), mine) <= reach2;
+        for (int base = 0; base < n_groups_y; base += 64 * CPD_TRUNC_WAVES) {
+            const int T = base + lane * CPD_TRUNC_WAVES + wave;                 // this lane's group to test: groups are dealt to the waves round-robin
+            const bool in_reach = T < n_groups_y && box_gap2(v.ygroup, n_groups_y, min(T, n_groups_y - 1), mine) <= reach2;
             unsigned long long todo = __builtin_amdgcn_ballot_w64(in_reach);
             while (todo != 0ull) {                                              // (wave-uniform)
-                const int Tt = base + (int)__builtin_ctzll(todo) * CPD_TRUNC_WAVES + wave;
-                todo &= todo - 1ull;
-                const int k = Tt * CPD_TRUNC_TILE + lane;
-                trunc_wave_sync();                                              // (the last tile's reads are done)
-                stage[wave][lane] = make_float4(v.yx[k], v.yy[k], v.yz[k], 0.f);
+                int k;
+                const int count = trunc_next_groups(todo, base, wave, lane, k);
+                // (points past the cloud's end -- the last group's tail -- and the unused quarter-loads: at infinity, their affinity is exactly 0)
+                const bool real = k >= 0 && k < v.m;
+                const float4 pt = make_float4(real ? v.yx[k] : far, real ? v.yy[k] : far, real ? v.yz[k] : far, 0.f);
+                trunc_wave_sync();                                              // (the last load's reads are done)
+                stage[wave][lane] = pt;
                 trunc_wave_sync();
-                const int cnt = min(CPD_TRUNC_TILE, v.m - Tt * CPD_TRUNC_TILE);
-                int j = 0;
-                for (; j + 8 <= cnt; j += 8) {
+                const int cnt = count * CPD_TRUNC_GROUP;
+                for (int j = 0; j < cnt; j += 8) {                              // (cnt is a multiple of 16)
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         const float4 y = stage[wave][j + u];                    // one address for the whole wave: a broadcast read
                         sum += trunc_affinity(mult * trunc_sq_dist(ax, ay, az, y.x, y.y, y.z), v.trunc_log);
                     }
-                }
-                for (; j < cnt; j++) {
-                    const float4 y = stage[wave][j];
-                    sum += trunc_affinity(mult * trunc_sq_dist(ax, ay, az, y.x, y.y, y.z), v.trunc_log);
                 }
             }
         }
@@ -176,7 +216,7 @@ __global__ __launch_bounds__(64 * CPD_TRUNC_WAVES) void cpd_trunc_den_kernel(Cpd
     }
 }
 
-// ---- contraction: a workgroup per tile of the MOVING cloud (lane = moving point k), the fixed cloud's tiles (static boxes) dealt to the waves
+// ---- contraction: a workgroup per tile of the MOVING cloud (lane = moving point k), the fixed cloud's groups (static boxes) dealt to the waves
 __global__ __launch_bounds__(64 * CPD_TRUNC_WAVES) void cpd_trunc_contract_kernel(CpdTruncView v, double* __restrict__ kpartials)
 {
     if (v.state->done != 0) return;
@@ -185,7 +225,9 @@ __global__ __launch_bounds__(64 * CPD_TRUNC_WAVES) void cpd_trunc_contract_kerne
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float mult = -0.5f / v.state->sigma2;
     const float reach2 = (v.trunc_log / mult) * 1.0001f;
-    const int n_tiles_a = (v.n + CPD_TRUNC_TILE - 1) / CPD_TRUNC_TILE, n_tiles_y = (v.m + CPD_TRUNC_TILE - 1) / CPD_TRUNC_TILE;
+    const int n_tiles_y = (v.m + CPD_TRUNC_TILE - 1) / CPD_TRUNC_TILE;
+    const int n_groups_a = (v.n + CPD_TRUNC_TILE - 1) / CPD_TRUNC_TILE * CPD_TRUNC_PER_LOAD;
+    const float far = __builtin_inff();
     double acc[CPD_KSUMS] = {0};
     for (int tile = blockIdx.x; tile < n_tiles_y; tile += gridDim.x) {
         const int k = tile * CPD_TRUNC_TILE + lane;
@@ -194,21 +236,21 @@ __global__ __launch_bounds__(64 * CPD_TRUNC_WAVES) void cpd_trunc_contract_kerne
 #pragma unroll
         for (int q = 0; q < 6; q++) mine[q] = v.ybox[(size_t)q * n_tiles_y + tile];
         float p1 = 0.f, pxx = 0.f, pxy = 0.f, pxz = 0.f;
-        for (int base = 0; base < n_tiles_a; base += 64 * CPD_TRUNC_WAVES) {
+        for (int base = 0; base < n_groups_a; base += 64 * CPD_TRUNC_WAVES) {
             const int T = base + lane * CPD_TRUNC_WAVES + wave;
-            const bool in_reach = T < n_tiles_a && box_gap2(v.abox, n_tiles_a, min(T, n_tiles_a - 1), mine) <= reach2;
+            const bool in_reach = T < n_groups_a && box_gap2(v.agroup, n_groups_a, min(T, n_groups_a - 1), mine) <= reach2;
             unsigned long long todo = __builtin_amdgcn_ballot_w64(in_reach);
             while (todo != 0ull) {
-                const int Tt = base + (int)__builtin_ctzll(todo) * CPD_TRUNC_WAVES + wave;
-                todo &= todo - 1ull;
-                const int x = Tt * CPD_TRUNC_TILE + lane;
+                int x;
+                const int count = trunc_next_groups(todo, base, wave, lane, x);
+                const bool real = x >= 0 && x < v.n;
+                const float4 pa = make_float4(real ? v.ax[x] : far, real ? v.ay[x] : far, real ? v.az[x] : far, 0.f);
+                const float4 pw = real ? v.xw4[x] : make_float4(0.f, 0.f, 0.f, 0.f);
                 trunc_wave_sync();
-                stage_a[wave][lane] = make_float4(v.ax[x], v.ay[x], v.az[x], 0.f);
-                stage_w[wave][lane] = v.xw4[min(x, v.n - 1)];                  // (xw4 holds n records: the tail of the last tile is never read below)
+                stage_a[wave][lane] = pa; stage_w[wave][lane] = pw;
                 trunc_wave_sync();
-                const int cnt = min(CPD_TRUNC_TILE, v.n - Tt * CPD_TRUNC_TILE);
-                int j = 0;
-                for (; j + 4 <= cnt; j += 4) {
+                const int cnt = count * CPD_TRUNC_GROUP;
+                for (int j = 0; j < cnt; j += 4) {
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const float4 a = stage_a[wave][j + u], w = stage_w[wave][j + u];
@@ -218,11 +260,6 @@ __global__ __launch_bounds__(64 * CPD_TRUNC_WAVES) void cpd_trunc_contract_kerne
                         pxy += p * w.y;
                         pxz += p * w.z;
                     }
-                }
-                for (; j < cnt; j++) {
-                    const float4 a = stage_a[wave][j], w = stage_w[wave][j];
-                    const float p = trunc_affinity(mult * trunc_sq_dist(a.x, a.y, a.z, yx, yy, yz), v.trunc_log);
-                    p1 += p * w.w; pxx += p * w.x; pxy += p * w.y; pxz += p * w.z;
                 }
             }
         }
@@ -254,10 +291,10 @@ __global__ __launch_bounds__(64 * CPD_TRUNC_WAVES) void cpd_trunc_contract_kerne
 }
 
 hipError_t cpd_trunc_gather(const float* x, const float* y, const float* z, const int* order, int n, float* ox, float* oy, float* oz,
-                            float* tile_box, const CpdState* state, hipStream_t s)
+                            float* tile_box, float* group_box, const CpdState* state, hipStream_t s)
 {
     const int n_tiles = (n + CPD_TRUNC_TILE - 1) / CPD_TRUNC_TILE;
-    hipLaunchKernelGGL(cpd_trunc_gather_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, s, x, y, z, order, n, ox, oy, oz, tile_box, state);
+    hipLaunchKernelGGL(cpd_trunc_gather_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, s, x, y, z, order, n, ox, oy, oz, tile_box, group_box, state);
     return hipGetLastError();
 }
 

@@ -703,11 +703,25 @@ __device__ __forceinline__ void grid_rows_dealt(const NnGridView& g, GridLane& s
 // in cell units, every g shrunk by the rounding slack.  Such lanes used to walk the hierarchy whatever the shape of their lens (cap 2 h):
 // 37 % of all wave-time at iteration 20 for 16 % of the lanes (profiles/r04_wave_timeline.log).  Beyond 16 cells outside the relative
 // slacks of the cell arithmetic outgrow the absolute ones: cap 0, those lanes walk as before.
-__device__ __forceinline__ float grid_lane_cap2(const NnGridView& g, float u0, float u1, float u2, float (&gs)[3])
+#ifndef MISLAM_GRID_EXTENT_REACH
+#define MISLAM_GRID_EXTENT_REACH 1       // 0 (tools/build_variant.sh): rounds 2-4's rule -- a cap of two cells for every query
+#endif
+// `extend` (wave-uniform): WHEN the wider reach is used.  Measured (profiles/r05_search_experiments.log, the bench's two cubes with their roles
+// swapped, so that the moving cloud's shell hangs out of the fixed cloud's extent): it pays while the starting candidates are poor -- a search
+// without any (the plain mi_nn_search), the first iterations of a registration (0.289 -> 0.237 ms per search in iterations 0-4, walking lanes
+// 77 -> 72 %) -- and LOSES once they are good (iterations 20-24: walking lanes 16.6 -> 5.7 %, search 0.084 -> 0.101 ms): a lens across the row
+// direction is one boundary cell per row, ten rows per lane where an inside lane scans 3.6, and the walk it replaces is then a short verification.
+// So: plain searches and the cold iterations of a fused registration only.
+__device__ __forceinline__ float grid_lane_cap2(const NnGridView& g, float u0, float u1, float u2, float (&gs)[3], bool extend)
 {
-    gs[0] = fmaxf(fmaxf(-u0, u0 - (float)g.nx) - 1e-3f, 0.f);
-    gs[1] = fmaxf(fmaxf(-u1, u1 - (float)g.ny) - 1e-3f, 0.f);
-    gs[2] = fmaxf(fmaxf(-u2, u2 - (float)g.nz) - 1e-3f, 0.f);
+#if MISLAM_GRID_EXTENT_REACH
+    gs[0] = extend ? fmaxf(fmaxf(-u0, u0 - (float)g.nx) - 1e-3f, 0.f) : 0.f;
+    gs[1] = extend ? fmaxf(fmaxf(-u1, u1 - (float)g.ny) - 1e-3f, 0.f) : 0.f;
+    gs[2] = extend ? fmaxf(fmaxf(-u2, u2 - (float)g.nz) - 1e-3f, 0.f) : 0.f;
+#else
+    (void)u0; (void)u1; (void)u2; (void)extend;
+    gs[0] = gs[1] = gs[2] = 0.f;
+#endif
     const float e = GRID_DU_MAX - 2e-3f;
     const float s0 = gs[0] * gs[0], s1 = gs[1] * gs[1], s2 = gs[2] * gs[2];
     const float c0 = (gs[0] + e) * (gs[0] + e) + (s1 + s2), c1 = (gs[1] + e) * (gs[1] + e) + (s0 + s2), c2 = (gs[2] + e) * (gs[2] + e) + (s0 + s1);
@@ -715,10 +729,10 @@ __device__ __forceinline__ float grid_lane_cap2(const NnGridView& g, float u0, f
     const float cells2 = far_out <= 16.f ? fminf(c0, fminf(c1, c2)) : 0.f;
     return cells2 * (g.h_lo * g.h_lo) * (1.f - 1e-5f);
 }
-__device__ __forceinline__ float grid_lane_cap2(const NnGridView& g, const float q[3])
+__device__ __forceinline__ float grid_lane_cap2(const NnGridView& g, const float q[3], bool extend)
 {
     float gs[3];
-    return grid_lane_cap2(g, cell_u(q[0], g.ox, g.inv_h), cell_u(q[1], g.oy, g.inv_h), cell_u(q[2], g.oz, g.inv_h), gs);
+    return grid_lane_cap2(g, cell_u(q[0], g.ox, g.inv_h), cell_u(q[1], g.oy, g.inv_h), cell_u(q[2], g.oz, g.inv_h), gs, extend);
 }
 // cells (as a float count) a radius^2 of r2 spans on an axis once the squared face gaps of the two OTHER axes are taken off it; the slack of
 // the cell arithmetic added (raw v_sqrt_f32, 1 ulp: covered by it)
@@ -736,7 +750,7 @@ __device__ __forceinline__ float grid_du(const NnGridView& g, float r2, float ot
 // `reach_word` = row_occ of the query's cell: 0 says no cell the scan could visit holds a point, a clear bit that its row holds none.  `lane_on`: the lane has a point.
 template <bool FMA, bool STATS>
 __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3], bool lane_on, unsigned int reach_word, float& best, unsigned int& bidx,
-                                            unsigned int& bslot, unsigned int& n_cand, unsigned int& n_rows, bool deal_rows
+                                            unsigned int& bslot, unsigned int& n_cand, unsigned int& n_rows, bool deal_rows, bool extend_reach
 #ifdef MISLAM_DEV_WAVE_TIMELINE
                                             , unsigned long long (&dev_tl)[3]
 #endif
@@ -744,7 +758,7 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
 {
     const float u0 = cell_u(q[0], g.ox, g.inv_h), u1 = cell_u(q[1], g.oy, g.inv_h), u2 = cell_u(q[2], g.oz, g.inv_h);
     float gs[3];
-    const float cap2 = grid_lane_cap2(g, u0, u1, u2, gs);      // every point within sqrt(cap2) of the query lies within GRID_REACH_CELLS cells of its clamped own cell
+    const float cap2 = grid_lane_cap2(g, u0, u1, u2, gs, extend_reach);      // every point within sqrt(cap2) of the query lies within GRID_REACH_CELLS cells of its clamped own cell
     // squared face gaps in length units, lower bounds (h_lo): what a point within r has already spent on an axis before the extent begins
     const float G0 = (gs[0] * g.h_lo) * (gs[0] * g.h_lo), G1 = (gs[1] * g.h_lo) * (gs[1] * g.h_lo), G2 = (gs[2] * g.h_lo) * (gs[2] * g.h_lo);
     GridLane s;
@@ -945,21 +959,23 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
     }
     const bool mine_to_walk = WAVES == 2 && ((predicted >> tid) & 1ull) != 0ull;   // (of a scanning chunk: this lane is the helper's)
     if (WAVES == 2 && helper != 0 && !walk_only && predicted == 0ull) return;   // (nothing to help with: the first wave scans alone, as ever)
-    const bool halves = WAVES == 2 && a.split_walks != 2;                  // a chunk that walks at once: half the lanes per wave
-    if (walk_only) hard = valid && (!halves || (tid >> 5) == helper);
-    else if (WAVES == 2 && helper != 0) hard = valid && mine_to_walk;
-#ifdef MISLAM_DEV_WAVE_TIMELINE
-    else hard = grid_search<FMA, STATS>(g, q, valid && !mine_to_walk, near_word, best, bidx, bslot, n_cand, n_rows, a.deal_rows != 0, dev_tl) && valid && !mine_to_walk;
-#else
-    else hard = grid_search<FMA, STATS>(g, q, valid && !mine_to_walk, near_word, best, bidx, bslot, n_cand, n_rows, a.deal_rows != 0) && valid && !mine_to_walk;   // (all lanes: the loops run in step)
-#endif
-    bool walked = __builtin_amdgcn_ballot_w64(hard) != 0ull;
     // the first iterations of a registration move the cloud by many cells: the starting candidates (previous matches) are STALE, and a walk
-    // that enters the children in index order meets the true neighbourhood late; there the nearest child goes first (a lane vote per step)
+    // that enters the children in index order meets the true neighbourhood late; there the nearest child goes first (a lane vote per step) -- and
+    // the scan reaches farther for queries outside the grid's extent (grid_lane_cap2), as it does for a plain search, which has no candidates at all
 #ifndef MISLAM_GRID_COLD_PASSES
 #define MISLAM_GRID_COLD_PASSES 6
 #endif
     const bool cold = FUSED && a.state->passes < MISLAM_GRID_COLD_PASSES;
+    const bool extend_reach = !FUSED || cold;
+    const bool halves = WAVES == 2 && a.split_walks != 2;                  // a chunk that walks at once: half the lanes per wave
+    if (walk_only) hard = valid && (!halves || (tid >> 5) == helper);
+    else if (WAVES == 2 && helper != 0) hard = valid && mine_to_walk;
+#ifdef MISLAM_DEV_WAVE_TIMELINE
+    else hard = grid_search<FMA, STATS>(g, q, valid && !mine_to_walk, near_word, best, bidx, bslot, n_cand, n_rows, a.deal_rows != 0, extend_reach, dev_tl) && valid && !mine_to_walk;
+#else
+    else hard = grid_search<FMA, STATS>(g, q, valid && !mine_to_walk, near_word, best, bidx, bslot, n_cand, n_rows, a.deal_rows != 0, extend_reach) && valid && !mine_to_walk;   // (all lanes: the loops run in step)
+#endif
+    bool walked = __builtin_amdgcn_ballot_w64(hard) != 0ull;
 #ifdef MISLAM_DEV_WAVE_TIMELINE
     tl_scan = wall_clock64();
 #endif
@@ -1036,7 +1052,8 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
         row_store_error(e0, e1, row, nullptr);
         {
             // next iteration's class of this chunk: 0 = no lane walked, 1 = some did, 2 = most lanes lie beyond the grid's reach
-            const float cap2 = grid_lane_cap2(g, q);         // (this lane's own reach: grid_search's rule)
+            // (this lane's reach under the rule the NEXT search will apply: the class is a prediction for it)
+            const float cap2 = grid_lane_cap2(g, q, !FUSED || a.state->passes + 1 < MISLAM_GRID_COLD_PASSES);
             const int beyond = (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && !(best <= cap2)));
             if (tid == 0) a.far[chunk] = beyond >= GRID_WALK_ONLY_MIN ? 2 : (walked ? 1 : 0);
             // (the helper wave's share next time: the lanes the scan cannot serve -- NOT "the lanes that walked", which would keep every lane

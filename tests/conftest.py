@@ -165,3 +165,28 @@ def write_noise_meshes(meshes, directory):
             for k, c in enumerate(cuts):
                 end = len(f) if k == len(cuts) - 1 else c + 3
                 out.write("f " + " ".join(str(int(i) + 1) for i in f[c:end]) + "\n")
+
+
+# ---- measured values beside generous bars ----
+# A bar that is 10x what is measured lets a silent 10x regression through.  check_measured(key, value, bar) asserts the bar AND, where
+# tests/golden/measured_bounds.json holds this quantity's value as measured on MI355X (tools/collect_measured.py writes it from the "MEASURED"
+# lines of a GPU run's log), value <= factor x that measurement (+ an absolute floor for quantities that sit at rounding level).
+def _measured_bounds():
+    path = os.path.join(GOLD, "measured_bounds.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["values"]
+    except (OSError, ValueError, KeyError):
+        return {}
+
+
+MEASURED = _measured_bounds()
+
+
+def check_measured(key, value, bar, factor=2.0, floor=0.0):
+    value = float(value)
+    print("MEASURED %s %.6e" % (key, value))
+    assert value <= bar, (key, value, bar)
+    m = MEASURED.get(key)
+    if m is not None:
+        assert value <= factor * float(m) + floor, "%s: %.3e against %.3e measured when the fixture was written (x %.1f allowed): a regression inside the bar %.3e" % (key, value, float(m), factor, bar)

@@ -9,7 +9,7 @@ Tolerances (floating point, written per quantity):
 import numpy as np
 import pytest
 
-from conftest import frob
+from conftest import check_measured, frob
 
 pytestmark = pytest.mark.gpu
 
@@ -101,13 +101,13 @@ def test_bunny_cpd_matches_cpu_slam(ctx, capi, golden, bunny):
     assert it == f["iterations"]
     d = frob(sR, t, f["sR"], f["t"])
     print("bunny CPD |d(sR|t)|_F vs cpu-slam = %.3e, final sigma^2 %.4g (cpu-slam %.4g)" % (d, err, f["error"]))
-    assert d < 1e-4
+    check_measured("bunny_cpd_scale_free_vs_cpu_slam", d, 1e-4)
     # `error` is the final sigma^2 (cpdcuda.cu:355): at convergence a difference of O(10) sums, i.e. cancellation noise of the M-step's
     # arithmetic -- cpu-slam's fp32 M-step lands on 6.7e-5, the fp64-summing restatement on 9.8e-5.  The HIP path sums in fp64 like
     # the restatement: within 15 % of IT (measured: +5 % with the MFMA contraction, -2 % with the VALU one); against cpu-slam only
     # the size of that noise can be stated (4e-5 on a quantity that started at 3.6)
     o = golden.json("bunny_cpd_oracle.json")["final_scale_free"]
-    assert abs(err - o["error"]) <= 0.15 * o["error"]
+    check_measured("bunny_cpd_final_sigma2_rel_vs_oracle", abs(err - o["error"]) / o["error"], 0.15, floor=0.02)
     assert abs(err - f["error"]) <= 6e-5
 
 
@@ -169,8 +169,13 @@ def test_bunny_cpd_const_scale(ctx, capi, golden, bunny):
     assert it == o["iterations"] == g["final_const_scale"]["iterations"]
     d = frob(sR, t, o["sR"], o["t"])
     print("bunny CPD const-scale |d(sR|t)|_F vs oracle = %.3e" % d)
-    assert d < 5e-3
-    assert frob(sR, t, g["final_const_scale"]["sR"], g["final_const_scale"]["t"]) < 0.1
+    # Round 5 (tools/cpd_const_scale_trace.py, profiles/r05_cpd_const_scale_trace.log): the device leaves the oracle by ~2.5e-5 of sigma^2 per EM
+    # iteration from the first one on -- the E-step's SUMMATION ORDER: cpu-slam (and the oracle) add a point's 14 904 affinities one by one in fp32,
+    # and a running sum of ~1e2 drops every term below half its ulp (~4e-6) whole, a one-sided error; chunked sums keep them.  3e-4 of sigma^2
+    # by iteration 10, 1.6e-4 of s*R|t; the last five iterations (sigma^2 < 5e-3: |sub + den - 2 num| cancels to 1e-7 of its terms) turn that into
+    # 1.1e-3.  K3's fast forms have no part in it (IEEE: 7e-4 -- the same noise).  The M-step's fp64 sums are what separates BOTH from cpu-slam.
+    check_measured("bunny_cpd_const_scale_vs_oracle", d, 3e-3, factor=2.5)
+    check_measured("bunny_cpd_const_scale_vs_cpu_slam", frob(sR, t, g["final_const_scale"]["sR"], g["final_const_scale"]["t"]), 0.1, factor=1.5)
 
 
 def test_bunny_cpd_with_device_sigma(ctx, capi, bunny):

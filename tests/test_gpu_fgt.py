@@ -5,7 +5,7 @@ from cpu-slam by expf's last bit and the polynomial evaluation order only -- tol
 import numpy as np
 import pytest
 
-from conftest import frob
+from conftest import check_measured, frob
 
 pytestmark = pytest.mark.gpu
 
@@ -310,7 +310,7 @@ def test_bunny_hybrid_run_matches_cpu_slam(ctx, capi, golden, bunny):
     p = capi.cpd_params(max_iterations=r["max_iterations"], sigma2_init=g["sigma2_init"], approximation=capi.CPD_APPROX_HYBRID)
     sR, t, sc, it, err = ctx.cpd_register(before, after, p)
     assert it == r["iterations"] == 23
-    assert frob(sR, t, np.array(r["R"]), np.array(r["t"])) < 1e-4
+    check_measured("bunny_hybrid_vs_cpu_slam", frob(sR, t, np.array(r["R"]), np.array(r["t"])), 1e-4)
     assert err < 1e-3
 
 

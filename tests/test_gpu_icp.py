@@ -6,7 +6,7 @@ reference's cpu-slam result (BASELINE.json north_star) -- in practice ~1e-5, the
 import numpy as np
 import pytest
 
-from conftest import frob, synth_cloud
+from conftest import check_measured, frob, synth_cloud
 
 pytestmark = pytest.mark.gpu
 
@@ -77,13 +77,14 @@ def test_bunny_icp_matches_cpu_slam(ctx, capi, oracle, golden, bunny):
     R, t, it, err = ctx.icp_register(before, after, p)
     assert it == g["iterations"] == 39
     d_ref = frob(R, t, g["R"], g["t"])
-    assert d_ref < 1e-4
+    check_measured("bunny_icp_vs_cpu_slam", d_ref, 1e-4, factor=1.5)
     assert abs(err - g["error"]) < 1e-6
     # against the oracle restatement run here, tighter
     Ro, to, ito, eo = oracle.icp(before, after, 1e-3, 400.0, 50)
     d_or = frob(R, t, Ro, to)
     print("bunny ICP |d(R|t)|_F vs cpu-slam = %.3e, vs oracle = %.3e" % (d_ref, d_or))
-    assert ito == it and d_or < 2e-5
+    assert ito == it
+    check_measured("bunny_icp_vs_oracle", d_or, 2e-5, factor=1.5)
 
 
 @pytest.mark.parametrize("k", [1, 2, 3, 5, 10, 20])
@@ -204,7 +205,8 @@ def test_planar_and_duplicated_clouds_stay_finite_and_match_the_oracle(ctx, capi
         R, t, it, err = ctx.icp_register(src, tgt, capi.icp_params(eps=0.0, max_iterations=3, nn_mode=nn))[:4]
         assert np.isfinite(R).all() and np.isfinite(t).all() and np.isfinite(err)
         assert it == ito == 3
-        assert frob(R, t, Ro, to) < 2e-4 * max(1.0, float(np.abs(to).max())), (seed, nn, frob(R, t, Ro, to))
+        # (2e-4: three iterations on a rank-deficient problem; what each seed measures is recorded and held to 2x: tests/golden/measured_bounds.json)
+        check_measured("planar_seed%d_nn%d_vs_oracle" % (seed, nn), frob(R, t, Ro, to) / max(1.0, float(np.abs(to).max())), 2e-4, floor=2e-6)
 
 
 @pytest.fixture(scope="module")
@@ -357,7 +359,8 @@ def test_cfg2_size_properties(ctx, capi, oracle):
     ctx.icp_run(-1)
     R1, t1, it1, e1, _ = ctx.icp_result()
     Ro, to, ito, eo = oracle.icp(nb, na, 1e-3, 1000.0, 1)
-    assert it1 == ito == 1 and np.abs(R1 - Ro).max() < 2e-6 and frob(R1, t1, Ro, to) < 5e-4
+    assert it1 == ito == 1 and np.abs(R1 - Ro).max() < 2e-6
+    check_measured("cfg2_slice_first_iteration_vs_oracle", frob(R1, t1, Ro, to), 5e-4, factor=1.5)     # (cpu-slam's fp32 centroid: see above)
     idx, _ = ctx.nn_search(nb, na)
     B, A = nb.astype(np.float64), na[idx].astype(np.float64)
     cb, ca = B.mean(0), A.mean(0)

@@ -17,6 +17,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 group = int(sys.argv[3]) if len(sys.argv) > 3 else 5          # iterations per measurement, enqueued back to back (an idle GPU clocks down)
 before, after = synth_cloud(np, n)
+if os.environ.get("GRID_PROBE_SWAP") == "1":      # register the ROTATED cube onto the axis-aligned one: the fixed cloud then fills its grid's extent, and
+    before, after = after, before                  # the moving cloud's shell hangs OUT of the extent (what an oriented grid would make of the bench workload)
 with capi.Context(0) as ctx:
     ctx.icp_load(before, after, capi.icp_params(eps=0.0, max_iterations=-1, sync_every=group))
     ctx.profile_enable(True)
