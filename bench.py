@@ -310,7 +310,7 @@ def cpd_bunny(np, capi, ctx, world):
                 ceiling = cal.get("valu_busy_ceiling", VALU_BUSY_CEILING)
                 # the kernels of the EXACT mode only: the `<.., true>` instantiations are the hybrid mode's truncated E-step
                 ks = {k: v for k, v in prof_c["kernels"].items()
-                      if v.get("valu_busy_quadcycles_per_gui_cycle") and v.get("launch_ms") and not k.rstrip().endswith("true>")}
+                      if v.get("valu_busy_quadcycles_per_gui_cycle") and v.get("launch_ms") and not k.rstrip().endswith("true>") and "cpd_trunc_" not in k}
                 if ks:
                     t_all = sum(v["launch_ms"] for v in ks.values())
                     busy = sum(v["valu_busy_quadcycles_per_gui_cycle"] * v["launch_ms"] for v in ks.values()) / t_all

@@ -194,6 +194,7 @@ struct mi_ctx {
     int m_total = 0, shard_lo = 0, shard_hi = 0;
     bool source_sharded = false;                         // MI_SHARD_SOURCE in effect: n = this rank's slice, fixed cloud replicated
     bool fused = false;                                  // the grid search carries the O(N) part of the iteration (nn_grid.hip)
+    int enqueued_passes = 0;                             // fused iterations enqueued since the load / reset (GridSearchArgs::extend_reach)
     mi_icp_params icp{};
     double load_ms[MI_LOAD_STAGES] = {0};                // mi_icp_load_times
 

@@ -985,6 +985,7 @@ extern "C" int mi_icp_reset(mi_ctx* c)
     if (!c || !c->icp_loaded) { set_error("mi_icp_reset: no problem loaded"); return MI_ERR_STATE; }
     MI_ENTER(c);
     state_identity(c->h_state);
+    c->enqueued_passes = 0;
     if (c->icp.max_iterations == 0) {   // "while (iterations < maxIterations)" never enters
         c->h_state->done = 1;
         c->h_state->stop_reason = MI_STOP_MAX_ITERATIONS;
@@ -1199,10 +1200,14 @@ static int icp_enqueue_iteration(mi_ctx* c)
         a.rows = c->rows.p;
         a.order = c->sched_order.p; a.far = c->sched_far.p; a.far_lanes = c->sched_lanes.p;
         a.deal_rows = c->tune.grid_deal_rows < 0 ? (c->n >= GRID_DEAL_ROWS_MIN_POINTS ? 1 : 0) : c->tune.grid_deal_rows;
+        // (the host's own count of the iterations it has enqueued since the load / reset: the device's `passes` as long as the registration runs)
+        a.extend_reach = c->enqueued_passes < GRID_COLD_PASSES ? 1 : 0;
+        a.extend_reach_next = c->enqueued_passes + 1 < GRID_COLD_PASSES ? 1 : 0;
         a.split_walks = c->tune.grid_split_walks < 0 ? (c->n <= GRID_HELPER_FULL_MAX_POINTS ? 1 : (c->n <= GRID_HELPER_MAX_POINTS ? 2 : 0)) : c->tune.grid_split_walks;
         hipEvent_t e0 = nullptr, e1 = nullptr;           // timed, if at all, by events attached to the launch itself (nn_grid_query)
         MI_TRY(c->prof_span(MI_KERNEL_NN, &e0, &e1));
         MI_HIP(nn_grid_query(c->grid, c->tree, a, v.fma, c->stream, e0, e1));
+        c->enqueued_passes += 1;
     } else {
         // K1 (+ C1), K2
         MI_TRY(launch_nn(c, c->cx.p, c->cy.p, c->cz.p, c->n, m_local, c->shard_lo, v.fma, &c->d_state->done, c->icp.nn_mode));

@@ -35,7 +35,11 @@ constexpr int GRID_REACH_CELLS = (int)GRID_DU_MAX + ((float)(int)GRID_DU_MAX < G
 #ifndef MISLAM_GRID_WALK_ONLY_MIN
 #define MISLAM_GRID_WALK_ONLY_MIN 32
 #endif
-constexpr int GRID_WALK_ONLY_MIN = MISLAM_GRID_WALK_ONLY_MIN;   // lanes of a chunk beyond the grid's reach from which the chunk skips the scan next time (> 64: never)
+constexpr int GRID_WALK_ONLY_MIN = MISLAM_GRID_WALK_ONLY_MIN;
+#ifndef MISLAM_GRID_COLD_PASSES
+#define MISLAM_GRID_COLD_PASSES 6
+#endif
+constexpr int GRID_COLD_PASSES = MISLAM_GRID_COLD_PASSES;    // iterations of a registration whose starting candidates count as stale (nn_grid.hip: walk order, reach of the scan)   // lanes of a chunk beyond the grid's reach from which the chunk skips the scan next time (> 64: never)
 
 struct NnGridView {
     const float4* pts;                     // the m fixed points sorted by cell (row-major: x fastest), w = GLOBAL index bits; + GRID_PTS_PAD
@@ -97,6 +101,8 @@ struct GridSearchArgs {
     unsigned long long* far_lanes;         // in/out, may be null: per chunk, the lanes whose answer came from a walk (the helper wave's share next time)
     int split_walks;                       // fused iterations of small clouds: a helper wave per workgroup takes half of every immediate walk (nn_grid.hip)
     int deal_rows;                         // set by nn_grid_query: leftover rows dealt out one per lane (launches of more waves than the chip holds)
+    int extend_reach, extend_reach_next;   // fused iterations: this search / the next one is among the first GRID_COLD_PASSES of its registration (the HOST's count of
+                                           // enqueued iterations: the wider reach for queries outside the grid's extent is compiled in or out, nn_grid.hip grid_lane_cap2)
 };
 hipError_t nn_grid_query(const NnGridView& g, const NnTreeView& t, const GridSearchArgs& a, int fma, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 const char* nn_grid_kernel_name(bool fused);

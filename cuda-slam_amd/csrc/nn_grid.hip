@@ -864,7 +864,9 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
 // at once.  Everything after the walk is the first wave's, unchanged -- an exact walk and an exact scan find the same neighbour, so the
 // keys and the rows are the same to the last bit (tests/test_gpu_icp.py).  Search at 1e4 / 1e5 / 3e5 points: 0.0245 -> 0.0178 / 0.0370 ->
 // 0.0281 / 0.0487 -> 0.0425 ms; beyond 4.5e5 points the helpers cost more slots than they save time (nn_grid.h: modes by size).
-template <bool FMA, bool FUSED, bool STATS, int WAVES = 1>
+// EXTEND (fused iterations; a plain search always has it): the scan's wider reach for queries outside the grid's extent -- compiled OUT of the warm
+// iterations' kernel, where it loses (grid_lane_cap2) and its three face gaps would cost the 72-register budget more spills.
+template <bool FMA, bool FUSED, bool STATS, int WAVES = 1, bool EXTEND = true>
 __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel(NnGridView g, NnTreeView t, GridSearchArgs a)
 {
     static_assert(GRID_BLOCK == 64 && ICP_ROW_POINTS == 64, "one wave = one workgroup = one row of partial sums");
@@ -962,11 +964,8 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
     // the first iterations of a registration move the cloud by many cells: the starting candidates (previous matches) are STALE, and a walk
     // that enters the children in index order meets the true neighbourhood late; there the nearest child goes first (a lane vote per step) -- and
     // the scan reaches farther for queries outside the grid's extent (grid_lane_cap2), as it does for a plain search, which has no candidates at all
-#ifndef MISLAM_GRID_COLD_PASSES
-#define MISLAM_GRID_COLD_PASSES 6
-#endif
-    const bool cold = FUSED && a.state->passes < MISLAM_GRID_COLD_PASSES;
-    const bool extend_reach = !FUSED || cold;
+    const bool cold = FUSED && a.state->passes < GRID_COLD_PASSES;
+    constexpr bool extend_reach = !FUSED || EXTEND;
     const bool halves = WAVES == 2 && a.split_walks != 2;                  // a chunk that walks at once: half the lanes per wave
     if (walk_only) hard = valid && (!halves || (tid >> 5) == helper);
     else if (WAVES == 2 && helper != 0) hard = valid && mine_to_walk;
@@ -1053,7 +1052,7 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
         {
             // next iteration's class of this chunk: 0 = no lane walked, 1 = some did, 2 = most lanes lie beyond the grid's reach
             // (this lane's reach under the rule the NEXT search will apply: the class is a prediction for it)
-            const float cap2 = grid_lane_cap2(g, q, !FUSED || a.state->passes + 1 < MISLAM_GRID_COLD_PASSES);
+            const float cap2 = grid_lane_cap2(g, q, !FUSED || a.extend_reach_next != 0);
             const int beyond = (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && !(best <= cap2)));
             if (tid == 0) a.far[chunk] = beyond >= GRID_WALK_ONLY_MIN ? 2 : (walked ? 1 : 0);
             // (the helper wave's share next time: the lanes the scan cannot serve -- NOT "the lanes that walked", which would keep every lane
@@ -1077,22 +1076,27 @@ hipError_t nn_grid_query(const NnGridView& g, const NnTreeView& t, const GridSea
     const bool helped = fused && a.stats == nullptr && a.split_walks != 0 && a.far_lanes != nullptr;   // two waves per workgroup (nn_grid_kernel<.., 2>)
     if (fused && (a.order == nullptr || a.far == nullptr || a.rows == nullptr || a.match_slot == nullptr)) return hipErrorInvalidValue;   // (the fused kernel does not test for them)
     const bool timed = e0 != nullptr && e1 != nullptr;
-#define MI_GRID_LAUNCH(F, U, S) do { if (timed) hipExtLaunchKernelGGL((nn_grid_kernel<F, U, S>), grid, block, 0, s, e0, e1, 0, g, t, a); \
-                                     else hipLaunchKernelGGL((nn_grid_kernel<F, U, S>), grid, block, 0, s, g, t, a); } while (0)
+    const bool ext = !fused || a.extend_reach != 0;
+#define MI_GRID_LAUNCH_E(F, U, S, E) do { if (timed) hipExtLaunchKernelGGL((nn_grid_kernel<F, U, S, 1, E>), grid, block, 0, s, e0, e1, 0, g, t, a); \
+                                          else hipLaunchKernelGGL((nn_grid_kernel<F, U, S, 1, E>), grid, block, 0, s, g, t, a); } while (0)
+#define MI_GRID_LAUNCH(F, U, S) do { if (!(U) || ext) MI_GRID_LAUNCH_E(F, U, S, true); else MI_GRID_LAUNCH_E(F, U, S, false); } while (0)
     if (a.stats != nullptr) {          // counting build of the same kernel (mi_profile_search_stats)
         if (fused) { if (fma) MI_GRID_LAUNCH(true, true, true); else MI_GRID_LAUNCH(false, true, true); }
         else { if (fma) MI_GRID_LAUNCH(true, false, true); else MI_GRID_LAUNCH(false, false, true); }
     } else if (helped) {
         const dim3 block2(2 * GRID_BLOCK);
-#define MI_GRID_LAUNCH2(F) do { if (timed) hipExtLaunchKernelGGL((nn_grid_kernel<F, true, false, 2>), grid, block2, 0, s, e0, e1, 0, g, t, a); \
-                                else hipLaunchKernelGGL((nn_grid_kernel<F, true, false, 2>), grid, block2, 0, s, g, t, a); } while (0)
+#define MI_GRID_LAUNCH2_E(F, E) do { if (timed) hipExtLaunchKernelGGL((nn_grid_kernel<F, true, false, 2, E>), grid, block2, 0, s, e0, e1, 0, g, t, a); \
+                                     else hipLaunchKernelGGL((nn_grid_kernel<F, true, false, 2, E>), grid, block2, 0, s, g, t, a); } while (0)
+#define MI_GRID_LAUNCH2(F) do { if (ext) MI_GRID_LAUNCH2_E(F, true); else MI_GRID_LAUNCH2_E(F, false); } while (0)
         if (fma) MI_GRID_LAUNCH2(true); else MI_GRID_LAUNCH2(false);
 #undef MI_GRID_LAUNCH2
+#undef MI_GRID_LAUNCH2_E
     } else {
         if (fused) { if (fma) MI_GRID_LAUNCH(true, true, false); else MI_GRID_LAUNCH(false, true, false); }
         else { if (fma) MI_GRID_LAUNCH(true, false, false); else MI_GRID_LAUNCH(false, false, false); }
     }
 #undef MI_GRID_LAUNCH
+#undef MI_GRID_LAUNCH_E
     return hipGetLastError();
 }
 

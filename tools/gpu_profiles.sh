@@ -1,11 +1,12 @@
 #!/bin/bash
-# Profiles (round tag R, default r04) of the driver's default bench command (python bench.py --steps 20 --warmup 5): rocprofv3 kernel-trace stats + the
+# Profiles (round tag R, default r05) of the driver's default bench command (python bench.py --steps 20 --warmup 5): rocprofv3 kernel-trace stats + the
 # rows of the TIMED dispatches, the --pmc passes (one per counter set, never mixed with tracing) for the search kernel, the every-pair
 # kernel and the CPD E-step kernels of the same run, and the same SQ counters on tools/valu_probe (kernels of a known instruction
 # count at 8 waves per SIMD) -- what bench.py's `issue` rooflines are calibrated by.
 #   gpurun -- 'bash tools/gpu_profiles.sh'   ->   gpurun_out/<R>_*  (copy the summaries into profiles/)
 mkdir -p gpurun_out; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-S=${STEPS:-20}; W=${WARMUP:-5}; R=${R:-r04}; export R
+S=${STEPS:-20}; W=${WARMUP:-5}; R=${R:-r05}; export R
+export MISLAM_BENCH_NO_RCCL_FLOOR=1   # (the one-rank RCCL communicator of the all-reduce floor leg is not part of what is profiled)
 B="python3 bench.py --steps $S --warmup $W --no-cpu-baseline --no-sizes --no-whole-call"
 run() { d=gpurun_out/${R}_$1; shift; rm -rf $d; timeout -k 10 500 rocprofv3 "$@" -d $d --output-format csv -- $B > $d.log 2>&1 || { tail -5 $d.log; exit 1; }; echo "pass $d done"; }
 probe() { d=gpurun_out/${R}_$1; shift; rm -rf $d; timeout -k 10 200 rocprofv3 "$@" -d $d --output-format csv -- tools/valu_probe > $d.log 2>&1 || { tail -5 $d.log; exit 1; }; }

@@ -16,7 +16,7 @@ import subprocess
 import sys
 
 S, W = int(sys.argv[1]), int(sys.argv[2])
-R = os.environ.get("R", "r04")
+R = os.environ.get("R", "r05")
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "gpurun_out")
 
@@ -129,7 +129,7 @@ print(json.dumps({k: {kk: v.get(kk) for kk in ("wave_instructions_per_s", "valu_
 pairs = 14904.0 * 14904.0
 cpd = {"workload": "cpd_bunny_14904", "kernel": "cpd_estep", "steps": None, "warmup": None, "git_head": head,
        "command": doc["command"].split(";")[0] + " (its cpd_bunny leg: exact P)", "pairs_per_launch": pairs, "kernels": {}}
-names = sorted({r["Kernel_Name"] for r in rows("sq1", "counter_collection.csv") if "cpd_denominator_kernel" in r["Kernel_Name"] or "cpd_contract" in r["Kernel_Name"]})
+names = sorted({r["Kernel_Name"] for r in rows("sq1", "counter_collection.csv") if "cpd_denominator_kernel" in r["Kernel_Name"] or "cpd_contract" in r["Kernel_Name"] or "cpd_trunc_" in r["Kernel_Name"]})
 for kn in names:
     e = {k: mean(counter_series(d, k, kn)) for d, ks in (("sq1", SQ1), ("sq2", SQ2)) for k in ks}
     t = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows("stats", "kernel_trace.csv") if r["Kernel_Name"] == kn]
