@@ -24,7 +24,13 @@ Rank 0 prints one JSON line.
   rccl            N > 1 only: what the communicator itself reports (ranks, bit mask of ranks seen in one all-reduce)
   cpd_bunny       the CPD leg of the metric (cfg 4), with its own roofline object
   cpu_baseline    the REFERENCE's own GetCorrespondingPoints (oracle/_ref, all host threads) on a bounded sample of source rows,
-                  scaled to a full iteration
+                  scaled to a full iteration; sizes['10000'] / ['100000'] carry their own, timed DIRECTLY (one whole search each, SURVEY 8d);
+                  cpd_bunny carries one too (one ComputePMatrix + one MStep of cpu-slam on the bunny clouds, single thread as the reference runs it)
+  cpd_bunny.published_size   the size the reference publishes CPD times for (N = 49 000, doc/plots/ms-cpd-3.png): exact and hybrid, ms per EM iteration
+  runtime         which libamdhip64 / librccl objects libmislam.so's calls bind to in this process, their versions, every copy mapped; a rank that
+                  finds two different RCCL (HIP) runtimes of different versions mapped refuses to start (exit 3, before any device call)
+  allreduce_f64_sum_floor    N = 1: the headline path's one collective (64 x 18 doubles) through a ONE-rank RCCL communicator, event-timed
+  expected_scaling           N > 1: what the one-GPU emulation of a rank's share predicts, so that the first multi-GPU numbers are read against it
 """
 import argparse
 import glob
