@@ -496,16 +496,24 @@ __global__ __launch_bounds__(FGT_TILE) void fgt_centers_kernel(const float* __re
 // reference's order.  Per tile of 128 members each lane prepares ONE member (powers of its scaled offset, exp(-|dx|^2),
 // weights) in LDS; all lanes then walk the tile: three power look-ups, three multiplies and W multiply-adds per member.
 // ---------------------------------------------------------------------------------------------------------------
+// Round 5: FGT_MODEL_GROUPS groups of 128 threads per workgroup.  A cell has 130 - 550 members on the bunny clouds and there are only 51 - 117 cells:
+// with one group (rounds 1 - 4) a workgroup walked its members tile after tile on two waves while most of the chip idled -- 24 - 30 us per launch.
+// Group g now takes the tiles g, g + G, ... of the cell (prepares and walks them on its own LDS arrays), and the groups' sums are added in group
+// order at the end: ((g0 + g1) + g2) + g3 -- a fixed order (bitwise reproducible); against the reference's one-by-one order the last bits move, as
+// they do in every fp32 sum of this E-step (FGT arrays agree with the reference's to 1e-5 of the largest entry, tests/test_gpu_fgt.py).  A cell of
+// at most 128 members is group 0's alone: the same bits as before.
+constexpr int FGT_MODEL_GROUPS = 4;
 template <int W, bool CENTERS>
-__global__ __launch_bounds__(FGT_TILE) void fgt_model_kernel(FgtClusters c, const float4* __restrict__ w4, float inv_sigma, FgtTables t,
-                                                             float* __restrict__ B)
+__global__ __launch_bounds__(FGT_TILE * FGT_MODEL_GROUPS) void fgt_model_kernel(FgtClusters c, const float4* __restrict__ w4, float inv_sigma, FgtTables t,
+                                                                                float* __restrict__ B)
 {
+    constexpr int G = FGT_MODEL_GROUPS;
     // powers d^0..d^(p-1) of the three scaled offsets of every member of the tile; rows padded by one word so that lanes
     // reading different powers of the same member fall into different LDS banks
-    __shared__ float sp[3][FGT_MAX_ORDER][FGT_TILE + 1];
-    __shared__ float se[FGT_TILE];
-    __shared__ float sw[W][FGT_TILE];
-    const int k = blockIdx.x, tid = threadIdx.x;
+    __shared__ float sp[G][3][FGT_MAX_ORDER][FGT_TILE + 1];
+    __shared__ float se[G][FGT_TILE];
+    __shared__ float sw[G][W][FGT_TILE];
+    const int k = blockIdx.x, tid = threadIdx.x & (FGT_TILE - 1), grp = threadIdx.x / FGT_TILE;
     const int m = blockIdx.y * FGT_TILE + tid;
     const bool live = m < t.pd;
     const unsigned int e = t.mono[live ? m : 0];
@@ -515,26 +523,26 @@ __global__ __launch_bounds__(FGT_TILE) void fgt_model_kernel(FgtClusters c, cons
     if (CENTERS) {
         // the cell's mean first -- fgt_centers_kernel's arithmetic (sequential fp32 sums in ascending point order, * (1.0f / count): fgt.cpp:195-210),
         // here instead of in a launch of its own; every workgroup of the cell computes it, the first one leaves it in xc for the transform
-        __shared__ float sc[3][FGT_TILE];
+        __shared__ float sc[3][FGT_TILE * G];
         __shared__ float mean[3];
         float sum = 0.f;
-        for (int base = j0; base < j1; base += FGT_TILE) {
-            const int cnt = min(FGT_TILE, j1 - base);
-            if (tid < cnt) {
-                const int i = c.memb[base + tid];
-                sc[0][tid] = c.x[i]; sc[1][tid] = c.y[i]; sc[2][tid] = c.z[i];
+        for (int base = j0; base < j1; base += FGT_TILE * G) {
+            const int cnt = min(FGT_TILE * G, j1 - base);
+            if ((int)threadIdx.x < cnt) {
+                const int i = c.memb[base + threadIdx.x];
+                sc[0][threadIdx.x] = c.x[i]; sc[1][threadIdx.x] = c.y[i]; sc[2][threadIdx.x] = c.z[i];
             }
             __syncthreads();
-            if (tid < 3) {
+            if (threadIdx.x < 3) {
 #pragma unroll 8
-                for (int q = 0; q < cnt; q++) sum += sc[tid][q];
+                for (int q = 0; q < cnt; q++) sum += sc[threadIdx.x][q];
             }
             __syncthreads();
         }
-        if (tid < 3) {
+        if (threadIdx.x < 3) {
             const float v = sum * (1.0f / (float)(j1 - j0));     // (an empty cell: 0 * inf = NaN, exactly as the reference)
-            mean[tid] = v;
-            if (blockIdx.y == 0) c.xc[3 * k + tid] = v;
+            mean[threadIdx.x] = v;
+            if (blockIdx.y == 0) c.xc[3 * k + threadIdx.x] = v;
         }
         __syncthreads();
         cx = mean[0]; cy = mean[1]; cz = mean[2];
@@ -544,46 +552,58 @@ __global__ __launch_bounds__(FGT_TILE) void fgt_model_kernel(FgtClusters c, cons
     float acc[W];
 #pragma unroll
     for (int w = 0; w < W; w++) acc[w] = 0.f;
-    for (int base = j0; base < j1; base += FGT_TILE) {
-        const int cnt = min(FGT_TILE, j1 - base);
+    for (int base = j0; base < j1; base += FGT_TILE * G) {
+        const int mine = base + grp * FGT_TILE;                    // this group's tile of the round
+        const int cnt = max(0, min(FGT_TILE, j1 - mine));
         if (tid < cnt) {
-            const int i = c.memb[base + tid];
+            const int i = c.memb[mine + tid];
             const float d[3] = {(c.x[i] - cx) * inv_sigma, (c.y[i] - cy) * inv_sigma, (c.z[i] - cz) * inv_sigma};
 #pragma unroll
             for (int a = 0; a < 3; a++) {
                 float pw = 1.0f;
-                for (int r = 0; r < t.p; r++) { sp[a][r][tid] = pw; pw = d[a] * pw; }
+                for (int r = 0; r < t.p; r++) { sp[grp][a][r][tid] = pw; pw = d[a] * pw; }
             }
-            se[tid] = expf(-len2(d[0], d[1], d[2]));
+            se[grp][tid] = expf(-len2(d[0], d[1], d[2]));
             if (W == 4) {
                 const float4 w = w4[i];
-                sw[0][tid] = w.x; sw[1 % W][tid] = w.y; sw[2 % W][tid] = w.z; sw[3 % W][tid] = w.w;
+                sw[grp][0][tid] = w.x; sw[grp][1 % W][tid] = w.y; sw[grp][2 % W][tid] = w.z; sw[grp][3 % W][tid] = w.w;
             }
         }
         __syncthreads();
         if (live) {
-            const float* __restrict__ pz = sp[2][ec];
-            const float* __restrict__ py = sp[1][eb];
-            const float* __restrict__ px = sp[0][ea];
+            const float* __restrict__ pz = sp[grp][2][ec];
+            const float* __restrict__ py = sp[grp][1][eb];
+            const float* __restrict__ px = sp[grp][0][ea];
 #pragma unroll 4
             for (int q = 0; q < cnt; q++) {
                 // exp(-|d|^2) z^c y^b x^a, the factors applied in the recursion's order (z, then y, then x); the powers
                 // themselves are formed first, which moves the last bit only
-                const float pr = ((se[q] * pz[q]) * py[q]) * px[q];
+                const float pr = ((se[grp][q] * pz[q]) * py[q]) * px[q];
                 if (W == 1) acc[0] += pr;                          // weights of ones (cpdutils.cpp:42)
                 else {
 #pragma unroll
-                    for (int w = 0; w < W; w++) acc[w] += sw[w][q] * pr;
+                    for (int w = 0; w < W; w++) acc[w] += sw[grp][w][q] * pr;
                 }
             }
         }
         __syncthreads();
     }
-    if (!live) return;
+    // the groups' sums, added in group order (the tiles' arrays are free now: their memory carries the hand-over)
+    float* comb = &sp[0][0][0][0];                                 // [G][W][FGT_TILE]
+    static_assert(sizeof(sp) >= sizeof(float) * G * 4 * FGT_TILE, "the hand-over fits the tile arrays");
+#pragma unroll
+    for (int w = 0; w < W; w++) comb[(grp * W + w) * FGT_TILE + tid] = acc[w];
+    __syncthreads();
+    if (grp != 0 || !live) return;
     const float ck = t.ck[m];
     const int h = t.hpos[m];
 #pragma unroll
-    for (int w = 0; w < W; w++) B[((size_t)w * c.K + k) * t.pd + h] = acc[w] * ck;     // fgt.cpp:299-305
+    for (int w = 0; w < W; w++) {
+        float tot = comb[w * FGT_TILE + tid];
+#pragma unroll
+        for (int g2 = 1; g2 < G; g2++) tot += comb[(g2 * W + w) * FGT_TILE + tid];
+        B[((size_t)w * c.K + k) * t.pd + h] = tot * ck;            // fgt.cpp:299-305
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -827,11 +847,11 @@ hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const 
     const float inv = 1.0f / sigma;                                // fgt.cpp:260
     const dim3 grid(c.K, (t.pd + FGT_TILE - 1) / FGT_TILE);
     if (centers) {
-        if (w4) hipLaunchKernelGGL((fgt_model_kernel<4, true>), grid, dim3(FGT_TILE), 0, s, c, w4, inv, t, B);
-        else hipLaunchKernelGGL((fgt_model_kernel<1, true>), grid, dim3(FGT_TILE), 0, s, c, w4, inv, t, B);
+        if (w4) hipLaunchKernelGGL((fgt_model_kernel<4, true>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
+        else hipLaunchKernelGGL((fgt_model_kernel<1, true>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
     } else {
-        if (w4) hipLaunchKernelGGL((fgt_model_kernel<4, false>), grid, dim3(FGT_TILE), 0, s, c, w4, inv, t, B);
-        else hipLaunchKernelGGL((fgt_model_kernel<1, false>), grid, dim3(FGT_TILE), 0, s, c, w4, inv, t, B);
+        if (w4) hipLaunchKernelGGL((fgt_model_kernel<4, false>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
+        else hipLaunchKernelGGL((fgt_model_kernel<1, false>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
     }
     return hipGetLastError();
 }
