@@ -40,13 +40,14 @@ struct FgtWork {
     DevBuf<float> By, Ba;                // coefficients: [1][K][pd] (moving cloud as sources), [4][K][pd] (fixed cloud as sources)
     DevBuf<float> kt1, v4;               // transform outputs, per split of the cells: [S][n], [S][4][m]
     DevBuf<unsigned char> sort_temp;
+    DevBuf<unsigned char> sort_temp_a;   // the fixed side's own scratch when its clustering runs beside the moving side's (round 5)
     DevBuf<unsigned int> mono;
     DevBuf<float> ck;
     DevBuf<int> hpos;
     int p = 0, pd = 0;
     void release()
     {
-        y.release(); a.release(); By.release(); Ba.release(); kt1.release(); v4.release(); sort_temp.release();
+        y.release(); a.release(); By.release(); Ba.release(); kt1.release(); v4.release(); sort_temp.release(); sort_temp_a.release();
         mono.release(); ck.release(); hpos.release(); p = pd = 0;
     }
 };
@@ -444,6 +445,29 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
     const int Sa = fgt_predict_splits(w->n, K), Sy = fgt_predict_splits(w->m, K);
     MI_TRY(f->kt1.reserve((size_t)Sa * w->n)); MI_TRY(f->v4.reserve(4 * (size_t)Sy * w->m));
     const size_t temp = f->sort_temp.cap;
+    // Round 5: the FIXED cloud's clustering (the additional centres of a larger K, its member lists: ~18 us of small launches) depends on nothing the
+    // moving side computes -- it runs on the context's auxiliary stream, with its own scratch, while `stream` clusters the moving cloud, builds its
+    // model and evaluates it; `stream` waits for it just before the fixed side's model.  (With profiling on everything stays on `stream`, one after
+    // the other.)  The fixed cloud does not move: the same K needs no new clustering at all, a larger K only the additional centres
+    // (a context created under MISLAM_FGT_RESUME=0 re-clusters from scratch every time; the results must not change by a bit -- tests/test_gpu_fgt.py)
+    const bool resume = c->tune.fgt_resume != 0;
+    const bool recluster = !resume || f->a.swept_K != K;
+    const bool beside = recluster && !c->profile && c->aux != nullptr && c->tune.fgt_two_streams != 0;
+    struct AuxJoin {                       // every way out joins the auxiliary stream into `stream`
+        mi_ctx* c; bool armed;
+        ~AuxJoin() { if (armed && hipEventRecord(c->aux_event[1], c->aux) == hipSuccess) (void)hipStreamWaitEvent(c->stream, c->aux_event[1], 0); }
+    } aux_join{c, false};
+    if (recluster) {
+        ca.k_done = resume && f->a.swept_K < K ? f->a.swept_K : 0;
+        ca.centers_in_model = 1;
+        if (beside) {
+            MI_TRY(f->sort_temp_a.reserve(std::max<size_t>(fgt_sort_temp_bytes(w->n), 16)));
+            MI_HIP(hipEventRecord(c->aux_event[0], c->stream));                 // behind the last readers of the fixed side's lists
+            MI_HIP(hipStreamWaitEvent(c->aux, c->aux_event[0], 0));
+            aux_join.armed = true;
+            MI_HIP(fgt_cluster(ca, f->sort_temp_a.p, f->sort_temp_a.cap, c->aux));
+        }
+    }
     // Kt1 = K^T 1: sources = moving cloud, unit weights, queried at the fixed cloud   (cpdutils.cpp:42-43)
     // (the moving cloud's sweep: last E-step's choices replayed and checked in parallel, MISLAM_FGT_REPLAY=0: swept step by step every time)
     MI_TRY(fgt_arm_replay(c, &f->y, &cy, c->tune.fgt_replay != 0 ? f->y.guess_K : 0));
@@ -459,14 +483,13 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
     MI_HIP(fgt_post_kt1(f->kt1.p, Sa, v.ax, v.ay, v.az, w->n, ndi, v.pt1, v.xw4, c->stream, with_sums ? w->part_x.p : nullptr, nxb));
     // P1 and PX: sources = fixed cloud weighted by 1/den and x/den, queried at the moving cloud   (:54-66; the reference
     // clusters the fixed cloud four times with the same result -- once is enough)
-    // the fixed cloud does not move: the same K needs no new clustering at all, a larger K only the additional centres
-    // (a context created under MISLAM_FGT_RESUME=0 re-clusters from scratch every time; the results must not change by a bit -- tests/test_gpu_fgt.py)
-    const bool resume = c->tune.fgt_resume != 0;
-    const bool recluster = !resume || f->a.swept_K != K;
     if (recluster) {
-        ca.k_done = resume && f->a.swept_K < K ? f->a.swept_K : 0;
-        ca.centers_in_model = 1;
-        MI_HIP(fgt_cluster(ca, f->sort_temp.p, temp, c->stream));
+        if (beside) {
+            MI_HIP(hipEventRecord(c->aux_event[1], c->aux));
+            MI_HIP(hipStreamWaitEvent(c->stream, c->aux_event[1], 0));
+            aux_join.armed = false;
+        } else
+            MI_HIP(fgt_cluster(ca, f->sort_temp.p, temp, c->stream));
         f->a.swept_K = K;
     }
     MI_HIP(fgt_model(ca, v.xw4, hsigma, t, f->Ba.p, c->stream, recluster));      // (an unchanged clustering keeps its means)

@@ -285,6 +285,22 @@ def test_hybrid_run_is_the_same_registration_with_and_without_culling(ctx, every
     assert frob(a[0], a[1], b[0], b[1]) < 2e-5
 
 
+def test_fixed_side_clustering_beside_the_moving_side_changes_no_bit(ctx, capi, golden, bunny, monkeypatch):
+    # Round 5: an FGT E-step clusters the fixed cloud on the context's auxiliary stream while the main stream works on the moving cloud
+    # (MISLAM_FGT_TWO_STREAMS=0: one after the other, as rounds 1-4).  Same kernels, same inputs, another schedule: hybrid and full runs bit for bit.
+    before, after = bunny
+    g = golden.json("bunny_fgt.json")
+    monkeypatch.setenv("MISLAM_FGT_TWO_STREAMS", "0")
+    with capi.Context(0) as one:
+        for approx, cap in ((capi.CPD_APPROX_HYBRID, 50), (capi.CPD_APPROX_FULL, 17)):
+            p = capi.cpd_params(max_iterations=cap, sigma2_init=g["sigma2_init"], approximation=approx)
+            a, b = ctx.cpd_register(before, after, p), one.cpd_register(before, after, p)
+            assert a[3] == b[3] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[4] == b[4]
+            # and again on the same contexts (buffers and clusterings carried over from the run before)
+            a2 = ctx.cpd_register(before, after, p)
+            assert a2[3] == a[3] and np.array_equal(a2[0], a[0]) and np.array_equal(a2[1], a[1])
+
+
 def test_estep_primitives_reject_bad_arguments(ctx, capi):
     y, x = pair(0, 50, 60)
     with pytest.raises(capi.MiSlamError):
