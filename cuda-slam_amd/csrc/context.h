@@ -118,6 +118,7 @@ struct mi_ctx {
         int svd_ieee = 0;                                // MISLAM_SVD_IEEE=1: the 3 x 3 SVD of every solve in IEEE divisions and roots (svd3.hpp)
         int icp_fused_solve = 1;                         // MISLAM_ICP_FUSED_SOLVE=0: rows reduce and solve as two launches at every size
         int icp_pipeline = 1;                            // MISLAM_ICP_PIPELINE=0: every host check of mi_icp_run settles the pending iteration and drains the stream
+        int dev_fail_loads = 0;                          // MISLAM_DEV_FAIL_LOADS=N: the context's first N index builds fail on purpose (tests/test_gpu_context.py)
         int fgt_two_streams = 1;                         // MISLAM_FGT_TWO_STREAMS=0: the fixed cloud's clustering of an FGT E-step on the main stream, behind the moving side's
         int fgt_replay = 1;                              // MISLAM_FGT_REPLAY=0: sweep the moving cloud step by step every E-step (no guess replayed)
     } tune;

@@ -235,6 +235,7 @@ static int ctx_create_common(int device, mi_ctx** out)
         c->tune.fgt_resume = env_i("MISLAM_FGT_RESUME", 1);
         c->tune.fgt_replay = env_i("MISLAM_FGT_REPLAY", 1);
         c->tune.fgt_two_streams = env_i("MISLAM_FGT_TWO_STREAMS", 1);
+        c->tune.dev_fail_loads = env_i("MISLAM_DEV_FAIL_LOADS", 0);
         c->tune.grid_deal_rows = env_i("MISLAM_GRID_DEAL_ROWS", -1);
         c->tune.grid_split_walks = env_i("MISLAM_GRID_SPLIT_WALKS", -1);
         c->tune.icp_pipeline = env_i("MISLAM_ICP_PIPELINE", 1);
@@ -732,6 +733,11 @@ static int ensure_tree(mi_ctx* c, int m_local, int index_base)
     int n_pad = 1, height = 0;
     while (n_pad < n_leaves) { n_pad <<= 1; height++; }
     if (height > TREE_MAX_HEIGHT) { set_error("fixed cloud too large for the box hierarchy"); return MI_ERR_INVALID_ARG; }
+    if (c->tune.dev_fail_loads > 0) {      // MISLAM_DEV_FAIL_LOADS=N (tests): the first N index builds of the context fail HERE -- behind the fixed cloud's
+        c->tune.dev_fail_loads -= 1;       // upload, which is already on the auxiliary stream: the early return mi_icp_load's lane guard exists for
+        set_error("index build failed on request (MISLAM_DEV_FAIL_LOADS)");
+        return MI_ERR_INVALID_ARG;
+    }
     MI_TRY(c->torder_out.reserve((size_t)m_local));
     MI_TRY(c->tpts.reserve((size_t)n_leaves * TREE_LEAF));
     MI_TRY(c->tboxes.reserve((size_t)4 * n_pad));

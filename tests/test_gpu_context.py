@@ -62,3 +62,25 @@ def test_contexts_in_turn_and_in_threads_with_changing_sizes(capi):
         i2, d2 = c2.nn_search(clouds[12000][0], clouds[30000][1])
         assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
         assert same(c1.icp_register(*clouds[150000], p), want[150000])
+
+
+def test_a_failed_load_leaves_the_context_usable(capi, monkeypatch):
+    # mi_icp_load puts the fixed cloud's upload and index builds on auxiliary streams and joins them into the main stream at the end --
+    # an early return in between (a refused hierarchy, a failed reserve) used to leave them un-joined.  MISLAM_DEV_FAIL_LOADS=2 makes the context's
+    # first two index builds fail behind the upload; every exit path now joins the lanes: the failed calls raise, the next one on the SAME context
+    # registers the clouds bit for bit as a fresh context does, also at another size (buffers outgrown and retired in between).
+    from conftest import synth_cloud
+    b1, a1 = synth_cloud(60000, seed=3)[:2]
+    b2, a2 = synth_cloud(150000, seed=4)[:2]
+    p = capi.icp_params(eps=0.0, max_iterations=6)
+    monkeypatch.setenv("MISLAM_DEV_FAIL_LOADS", "2")
+    with capi.Context(0) as bad:
+        monkeypatch.delenv("MISLAM_DEV_FAIL_LOADS")
+        with capi.Context(0) as fresh:
+            with pytest.raises(capi.MiSlamError):
+                bad.icp_register(b1, a1, p)
+            with pytest.raises(capi.MiSlamError):
+                bad.icp_register(b2, a2, p)
+            for b, a in ((b2, a2), (b1, a1)):
+                x, y = bad.icp_register(b, a, p), fresh.icp_register(b, a, p)
+                assert x[2] == y[2] == 6 and np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[3] == y[3]
