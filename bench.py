@@ -18,6 +18,7 @@ Rank 0 prints one JSON line.
                   this command, CALIBRATED by the same counters read off a kernel of known instruction count (tools/valu_probe)
   whole_call      one registration as the reference times it (host buffers in, allocation / upload / index builds / 50 iterations /
                   result included: testrunner.cpp:54-56) at 1e5 and 1e6 points, with the load split into its stages
+  late_iterations the same number of steps LATE in the same registration (the headline's window is a transient: the search gets cheaper as the clouds close in)
   sizes           the same measurement at N = M = 1e4, 1e5, 1e7 (BASELINE.json: "N = 10^4 ... 10^7"), a few steps each
   bruteforce_nn   the every-pair kernel on the same clouds with `valu`, its launch against the fp32 vector-issue rate
   target_sharded  N > 1 only: cfg 3's split -- fixed cloud sharded, every-pair search, ncclAllReduce(u64, min) of the keys
@@ -587,6 +588,16 @@ def main():
     elapsed_default, _ = timed_run(before, after, params_default, args.warmup, args.steps)
     auto_batch = capi.icp_auto_batch(n, m, world, pl["source_sharded"], not pl["indexed"])
     elapsed_plain, _ = timed_run(before, after, params, args.warmup, args.steps, events=False)
+    # The headline's window (iterations warmup .. warmup + steps of one registration) is a TRANSIENT: the search gets cheaper as the clouds close
+    # in.  The same number of steps late in the same registration, for the record: what an iteration costs once a third of
+    # the moving cloud no longer hangs out of the fixed one.
+    steady = None
+    if not args.no_sizes:
+        late = max(40, 2 * (args.warmup + args.steps))
+        el_late, nn_late = timed_run(before, after, params, late, args.steps)
+        steady = {"warmup": late, "steps": args.steps, "iterations_per_s": args.steps / el_late, "ms_per_step": el_late / args.steps * 1e3,
+                  "nn_avg_launch_ms": nn_late[0] / max(nn_late[1], 1), "error_after_steps": ctx.icp_result()[3],
+                  "note": "iterations %d..%d of the same registration (the headline times iterations %d..%d)" % (late + 1, late + args.steps, args.warmup + 1, args.warmup + args.steps)}
     # (the legs below continue from the headline's registration state: reload it)
     timed_run(before, after, params, args.warmup, args.steps)
     headline_allreduce = None
@@ -784,6 +795,8 @@ def main():
                         "BASELINE.json words it (target-sharded every-pair search: `target_sharded`) scales ~linearly but is two orders of magnitude slower than one GPU's grid"}
         if use_dist and rehearsal_transport == "gloo":
             out["rehearsal"] = "ranks share device %d over the gloo exchange context: flow check only, not a measurement" % local_rank
+        if steady is not None:
+            out["late_iterations"] = steady
         if whole is not None:
             out["whole_call"] = whole
         if sizes is not None:
