@@ -98,8 +98,16 @@ CpuCloud add_outliers(const CpuCloud& c, int count)   // common.cpp:121-132
 
 Mat3 rotation_about(const Vec3& axis_in, float angle)   // glm::rotate(mat4(1), angle, normalize(axis)) as a 3x3
 {
-    const float len = std::sqrt(axis_in.x * axis_in.x + axis_in.y * axis_in.y + axis_in.z * axis_in.z);
-    const Vec3 a{axis_in.x / len, axis_in.y / len, axis_in.z / len};
+    // glm::normalize = v * inversesqrt(dot(v, v)), inversesqrt = 1 / sqrt: a MULTIPLICATION by the reciprocal (func_geometric.inl:82-89,
+    // func_exponential.inl:134-139) -- dividing by the length instead differs in the last bit of the axis and of every point of `after`
+    // (round 5: found by the convergence set's fixtures, tests/test_noise_corpus.py)
+    // ... and TWICE: the reference calls glm::rotate(mat4(1), angle, glm::normalize(axis)) (testutils.cpp:45-46) and glm::rotate normalises its axis
+    // argument again (ext/matrix_transform.inl) -- the second pass moves last bits of the axis and 2-4 ulp of the off-diagonal entries
+    const auto normalize = [](const Vec3& v) {
+        const float inv = 1.f / std::sqrt((v.x * v.x + v.y * v.y) + v.z * v.z);
+        return Vec3{v.x * inv, v.y * inv, v.z * inv};
+    };
+    const Vec3 a = normalize(normalize(axis_in));
     const float c = std::cos(angle), s = std::sin(angle), k = 1.f - c;
     Mat3 R;
     R[0][0] = c + k * a.x * a.x;       R[0][1] = k * a.x * a.y + s * a.z; R[0][2] = k * a.x * a.z - s * a.y;

@@ -13,6 +13,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "testutils.h"
 #include "basicicp.h"
 #include "coherentpointdrift.h"
 #include "cpdutils.h"
@@ -122,6 +123,40 @@ REF_API void ref_clouds_from_config_full(const float* raw_before, int nb_raw, co
     from_cloud(after, after_xyz);
     *nb_out = (int)before.size();
     *na_out = (int)after.size();
+}
+
+// The same stage with the RANDOM known transformation of the reference's benchmark sets (configuration.TransformationParameters =
+// (rotation range, translation range): testset.cpp:62, :102, :146-176): Tests::GetRandomRotationMatrix / GetRandomTranslationVector
+// (testutils.cpp:43-55) drawn from rand() where GetCloudsFromConfig draws them -- behind the noise and outlier draws (common.cpp:193-204).
+// The drawn rotation (column-major) and translation are returned too.
+REF_API void ref_clouds_from_config_random(const float* raw_before, int nb_raw, const float* raw_after, int na_raw, int resize_before,
+                                           int resize_after, int has_spread, float spread, unsigned seed, float rot_range, float trans_range,
+                                           float* before_xyz, int* nb_out, float* after_xyz, int* na_out, float* rot9_colmajor, float* trans3)
+{
+    srand(seed);                                                 // mainwrapper.cpp:17-18
+    Common::randomSeed = seed;                                   // common.cpp:136
+    Common::mtRandom = std::mt19937{ seed };                     // common.cpp:137
+    auto before = to_cloud(raw_before, nb_raw);
+    auto after = raw_after ? to_cloud(raw_after, na_raw) : before;   // common.cpp:141-142
+    if (resize_before >= 0) before = Common::GetSubcloud(before, resize_before);   // common.cpp:145-149
+    if (resize_after >= 0) after = Common::GetSubcloud(after, resize_after);       // common.cpp:151-155
+    if (has_spread) {                                            // common.cpp:158-163
+        before = Common::NormalizeCloud(before, spread);
+        after = Common::NormalizeCloud(after, spread);
+    }
+    std::shuffle(before.begin(), before.end(), Common::mtRandom); // common.cpp:166
+    std::shuffle(after.begin(), after.end(), Common::mtRandom);   // common.cpp:167
+    before = Common::AddOutliersToCloud(before, 0);               // common.cpp:180-181 (no outliers: no draws)
+    after = Common::AddOutliersToCloud(after, 0);
+    const auto rotation = Tests::GetRandomRotationMatrix(rot_range);          // common.cpp:198
+    const auto translation = Tests::GetRandomTranslationVector(trans_range);  // common.cpp:199
+    after = Common::GetTransformedCloud(after, rotation, translation);        // common.cpp:201-204
+    from_cloud(before, before_xyz);
+    from_cloud(after, after_xyz);
+    *nb_out = (int)before.size();
+    *na_out = (int)after.size();
+    from_mat3(rotation, rot9_colmajor);
+    trans3[0] = translation.x; trans3[1] = translation.y; trans3[2] = translation.z;
 }
 
 // Consecutive Common::GetRandomPermutationVector draws (common.cpp:554-560) of the given sizes from a freshly seeded generator,

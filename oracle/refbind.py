@@ -264,6 +264,30 @@ def clouds_from_config_full(raw_before, raw_after, seed, R, t, resize_before=Non
     return before, after
 
 
+def clouds_from_config_random(raw_before, raw_after, seed, rot_range, trans_range, resize_before=None, resize_after=None, spread=None):
+    """GetCloudsFromConfig with configuration.TransformationParameters (the reference's benchmark sets): returns (before, after, R, t) with the
+    random rotation (3x3, row = output component) and translation the reference drew."""
+    raw_before = _cloud(raw_before)
+    nbr = len(raw_before)
+    if raw_after is not None:
+        raw_after = _cloud(raw_after)
+    nar = nbr if raw_after is None else len(raw_after)
+    nb = min(resize_before, nbr) if resize_before is not None else nbr
+    na = min(resize_after, nar) if resize_after is not None else nar
+    before = np.empty((nb, 3), np.float32)
+    after = np.empty((na, 3), np.float32)
+    rot = np.empty(9, np.float32)
+    tr = np.empty(3, np.float32)
+    cb, ca = C.c_int(0), C.c_int(0)
+    lib().ref_clouds_from_config_random(
+        _fp(raw_before), nbr, None if raw_after is None else _fp(raw_after), nar,
+        -1 if resize_before is None else resize_before, -1 if resize_after is None else resize_after,
+        0 if spread is None else 1, C.c_float(spread or 0.0), C.c_uint(seed), C.c_float(rot_range), C.c_float(trans_range),
+        _fp(before), C.byref(cb), _fp(after), C.byref(ca), _fp(rot), _fp(tr))
+    assert (cb.value, ca.value) == (nb, na)
+    return before, after, rot.reshape(3, 3).T.copy(), tr
+
+
 def permutation_sequence(seed, sizes):
     sizes = np.ascontiguousarray(sizes, np.int32)
     out = np.empty(int(sizes.sum()), np.int32)

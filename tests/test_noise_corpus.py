@@ -49,3 +49,27 @@ def test_host_input_stage_reproduces_the_reference_clouds(corpus_dir, number):
     assert (len(before), len(after)) == (c["n_before"], c["n_after"])
     assert hashlib.sha256(before.tobytes()).hexdigest() == c["sha256_before"]
     assert hashlib.sha256(after.tobytes()).hexdigest() == c["sha256_after"]
+
+
+# ---- the ICP leg of the reference's convergence test set (testset.cpp:119-187; oracle/make_golden_convergence.py) ----
+CONV = Golden().json("convergence_icp.json")["configs"]
+
+
+@pytest.mark.parametrize("k", range(len(CONV)))
+def test_host_input_stage_draws_the_reference_random_transformation(corpus_dir, k):
+    # "rotation-range" / "translation-range": the known transformation is DRAWN (Tests::GetRandomRotationMatrix / GetRandomTranslationVector,
+    # testutils.cpp:43-55) from rand() behind the shuffles -- the host mirror must draw the same numbers in the same order: the reference's
+    # prepared clouds, bit for bit (sha256), for all nine (rotation, translation) pairs of the set
+    if not os.path.exists(EXE):
+        pytest.skip("mi-slam not built (run __graft_entry__.build())")
+    c = CONV[k]
+    cfg = corpus_dir / ("conv%d.json" % k)
+    cfg.write_text(json.dumps(c["config_json"]))
+    dump = corpus_dir / ("conv_clouds%d.bin" % k)
+    r = subprocess.run([EXE, str(cfg), "--prepare", "host", "--dump-clouds", str(dump)], capture_output=True, text=True,
+                       env=dict(os.environ, MISLAM_DUMP_ONLY="1"), cwd=str(corpus_dir), timeout=120)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    before, after = read_dump(dump)
+    assert (len(before), len(after)) == (c["n_before"], c["n_after"]) == (20000, 20000)
+    assert hashlib.sha256(before.tobytes()).hexdigest() == c["sha256_before"]
+    assert hashlib.sha256(after.tobytes()).hexdigest() == c["sha256_after"]
