@@ -1,4 +1,4 @@
-"""GPU suite: the ICP leg of the reference's convergence test set (GetConvergenceTestSet, source/common/testset.cpp:119-187) at its first size --
+"""GPU suite: the ICP and CPD legs of the reference's convergence test set (GetConvergenceTestSet, source/common/testset.cpp:119-187) at its first size --
 20 000 points of bird.obj, cloud-spread 10, max-iterations 100, max-distance-squared 10000, a RANDOM known transformation of 0.2 / 0.4 / 0.6 rad and
 10 / 20 / 30 units drawn by the reference's generators -- through `mi-slam` (configuration -> OBJ -> input stage on the device incl. the random
 draw -> adapter with cpu-slam's rules -> C ABI) and through the ABI with cpu-slam's sequential sums, against what the reference's own cpu-slam
@@ -30,13 +30,14 @@ from test_host_cpp import EXE, read_dump
 pytestmark = pytest.mark.gpu
 
 CONV = Golden().json("convergence_icp.json")["configs"]
+CONV_CPD = Golden().json("convergence_cpd.json")["configs"]
 
 
 @pytest.fixture(scope="module")
 def corpus_dir(tmp_path_factory):
     d = tmp_path_factory.mktemp("convergence_set")
     _, meshes = noise_corpus(Golden())
-    write_noise_meshes({"bird.obj": meshes["bird.obj"]}, str(d))
+    write_noise_meshes({"bird.obj": meshes["bird.obj"], "bunny.obj": meshes["bunny.obj"]}, str(d))
     return d
 
 
@@ -74,3 +75,38 @@ def test_convergence_set_icp(corpus_dir, ctx, capi, k):
         assert it == orc["iterations"]
     check_measured("convergence_set_%d_vs_restatement" % k, d_orc, 5e-2, floor=2e-5)
     assert d_cpu <= 1.5 * max(c["oracle_vs_cpu_slam"], c["cpu_slam_reordered"]["distance"]) + 1e-4, (d_cpu, c["oracle_vs_cpu_slam"], c["cpu_slam_reordered"]["distance"])
+
+
+@pytest.mark.parametrize("k", range(len(CONV_CPD)))
+def test_convergence_set_cpd(corpus_dir, k):
+    """The CPD leg (testset.cpp:122-151): 4 000 points of bunny.obj, hybrid approximation, cpd-weight 0.1, cpd-tolerance 1e-4, the same nine random
+    transformations, through `mi-slam`.  Unlike the noise corpus this set is well posed (the same cloud before and after, no noise): the restatement
+    lands 9e-6 ... 5e-4 from cpu-slam with cpu-slam's iteration count on all nine, cpu-slam reordered 2e-5 ... 1.6e-3 from itself; at translation
+    30 cpu-slam stops after 4-5 iterations at sigma^2 = 5.8, 1.7 from the known motion (its tolerance rule, coherentpointdrift.cpp:113-117) -- and
+    so must the device.  Bars: clouds bit for bit; the restatement's iteration count; distance to the restatement recorded and held to 2 x the
+    record; no farther from cpu-slam than 1.5 x what the restatement or cpu-slam reordered sits from it (+ 1e-4)."""
+    if not os.path.exists(EXE):
+        pytest.skip("mi-slam not built")
+    c = CONV_CPD[k]
+    cfg = corpus_dir / ("conv_cpd%d.json" % k)
+    cfg.write_text(json.dumps(c["config_json"]))
+    dump, res_path = corpus_dir / ("cpd_clouds%d.bin" % k), corpus_dir / ("cpd_result%d.json" % k)
+    r = subprocess.run([EXE, str(cfg), "--dump-clouds", str(dump), "--result-json", str(res_path)], capture_output=True, text=True, cwd=str(corpus_dir), timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    before, after = read_dump(dump)
+    assert hashlib.sha256(before.tobytes()).hexdigest() == c["sha256_before"]
+    assert hashlib.sha256(after.tobytes()).hexdigest() == c["sha256_after"]
+    res = json.loads(res_path.read_text().replace("-nan", "NaN").replace("nan", "NaN"))
+    sR = np.array(res["R_colmajor"], np.float64).reshape(3, 3).T
+    t = np.array(res["t"], np.float64)
+    ref, orc = c["cpu_slam"], c["oracle"]
+    d_orc, d_cpu = frob(sR, t, orc["sR"], orc["t"]), frob(sR, t, ref["sR"], ref["t"])
+    spread = max([q["distance"] for q in c["cpu_slam_reordered"]] + [c["oracle_vs_cpu_slam"]])
+    print("CPD rot %.1f trans %2.0f: iterations %d (restatement %d, cpu-slam %d), |d(sR|t)|_F vs restatement %.3e, vs cpu-slam %.3e (restatement vs cpu-slam %.3e, "
+          "cpu-slam vs itself reordered %s), sigma^2 %.4g (cpu-slam %.4g)" % (c["rotation_range"], c["translation_range"], res["iterations"], orc["iterations"], ref["iterations"],
+                                                                             d_orc, d_cpu, c["oracle_vs_cpu_slam"], ["%.1e" % q["distance"] for q in c["cpu_slam_reordered"]],
+                                                                             res["error"], ref["error"]))
+    assert np.isfinite(sR).all() and np.isfinite(t).all()
+    assert res["iterations"] == orc["iterations"] == ref["iterations"]
+    check_measured("convergence_set_cpd_%d_vs_restatement" % k, d_orc, 3e-4, floor=1e-5)
+    assert d_cpu <= 1.5 * spread + 1e-4, (d_cpu, spread)

@@ -73,3 +73,24 @@ def test_host_input_stage_draws_the_reference_random_transformation(corpus_dir, 
     assert (len(before), len(after)) == (c["n_before"], c["n_after"]) == (20000, 20000)
     assert hashlib.sha256(before.tobytes()).hexdigest() == c["sha256_before"]
     assert hashlib.sha256(after.tobytes()).hexdigest() == c["sha256_after"]
+
+
+# ---- the CPD leg of the same set (hybrid, cpd-weight 0.1, cpd-tolerance 1e-4; 4 000 points of bunny.obj; oracle/make_golden_convergence.py --cpd) ----
+CONV_CPD = Golden().json("convergence_cpd.json")["configs"]
+
+
+@pytest.mark.parametrize("k", range(len(CONV_CPD)))
+def test_host_input_stage_of_the_cpd_convergence_set(corpus_dir, k):
+    if not os.path.exists(EXE):
+        pytest.skip("mi-slam not built (run __graft_entry__.build())")
+    c = CONV_CPD[k]
+    cfg = corpus_dir / ("conv_cpd%d.json" % k)
+    cfg.write_text(json.dumps(c["config_json"]))
+    dump = corpus_dir / ("conv_cpd_clouds%d.bin" % k)
+    r = subprocess.run([EXE, str(cfg), "--prepare", "host", "--dump-clouds", str(dump)], capture_output=True, text=True,
+                       env=dict(os.environ, MISLAM_DUMP_ONLY="1"), cwd=str(corpus_dir), timeout=120)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    before, after = read_dump(dump)
+    assert (len(before), len(after)) == (c["n_before"], c["n_after"]) == (4000, 4000)
+    assert hashlib.sha256(before.tobytes()).hexdigest() == c["sha256_before"]
+    assert hashlib.sha256(after.tobytes()).hexdigest() == c["sha256_after"]
