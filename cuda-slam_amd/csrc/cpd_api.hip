@@ -460,6 +460,7 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
     if (recluster) {
         ca.k_done = resume && f->a.swept_K < K ? f->a.swept_K : 0;
         ca.centers_in_model = 1;
+        ca.lists_in_model = c->tune.fgt_lists_in_model;
         if (beside) {
             MI_TRY(f->sort_temp_a.reserve(std::max<size_t>(fgt_sort_temp_bytes(w->n), 16)));
             MI_HIP(hipEventRecord(c->aux_event[0], c->stream));                 // behind the last readers of the fixed side's lists
@@ -475,6 +476,7 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
     cy.replay_done = f->y.prelaunched > 0 && f->y.prelaunched == fgt_replay_limit(cy.guess, cy.K) ? 1 : 0;
     f->y.prelaunched = 0;
     cy.centers_in_model = 1;                 // (round 5: the cell means come out of the model kernel -- one launch less per side)
+    cy.lists_in_model = c->tune.fgt_lists_in_model;      // (... and so do the member lists, for clouds of at most 32 768 points: three launches less per side)
     MI_HIP(fgt_cluster(cy, f->sort_temp.p, temp, c->stream));
     f->y.guess_K = K;
     MI_HIP(fgt_model(cy, nullptr, hsigma, t, f->By.p, c->stream, true));

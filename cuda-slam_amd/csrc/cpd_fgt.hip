@@ -503,11 +503,17 @@ __global__ __launch_bounds__(FGT_TILE) void fgt_centers_kernel(const float* __re
 // they do in every fp32 sum of this E-step (FGT arrays agree with the reference's to 1e-5 of the largest entry, tests/test_gpu_fgt.py).  A cell of
 // at most 128 members is group 0's alone: the same bits as before.
 constexpr int FGT_MODEL_GROUPS = 4;
-template <int W, bool CENTERS>
+// LISTS (round 5, clouds of at most FGT_LISTS_IN_MODEL_MAX_POINTS points): the cell's member list is made HERE, by the workgroup that is about to walk it --
+// fgt_lists_pass_kernel's stable counting sort seen from one cell: the list starts behind every point with a smaller label (off[k]) and holds the
+// points labelled k in ascending order.  Two passes over the labels (a few tens of KB, in the caches), each wave a contiguous range: count, then place
+// by a ballot prefix.  The same off / memb as the three sort launches leave (every workgroup of the cell writes the same words), without the launches.
+constexpr int FGT_LISTS_IN_MODEL_MAX_POINTS = 32768;
+template <int W, bool CENTERS, bool LISTS>
 __global__ __launch_bounds__(FGT_TILE * FGT_MODEL_GROUPS) void fgt_model_kernel(FgtClusters c, const float4* __restrict__ w4, float inv_sigma, FgtTables t,
                                                                                 float* __restrict__ B)
 {
     constexpr int G = FGT_MODEL_GROUPS;
+    static_assert(!LISTS || CENTERS, "a clustering that leaves its lists to the model build leaves its means too");
     // powers d^0..d^(p-1) of the three scaled offsets of every member of the tile; rows padded by one word so that lanes
     // reading different powers of the same member fall into different LDS banks
     __shared__ float sp[G][3][FGT_MAX_ORDER][FGT_TILE + 1];
@@ -518,7 +524,60 @@ __global__ __launch_bounds__(FGT_TILE * FGT_MODEL_GROUPS) void fgt_model_kernel(
     const bool live = m < t.pd;
     const unsigned int e = t.mono[live ? m : 0];
     const int ea = e & 0xff, eb = (e >> 8) & 0xff, ec = (e >> 16) & 0xff;
-    const int j0 = c.off[k], j1 = c.off[k + 1];
+    int j0, j1;
+    if (LISTS) {
+        constexpr int NW = FGT_TILE * G / 64;
+        __shared__ int s_lt[NW], s_eq[NW];
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int per = ((c.n + NW * 64 - 1) / (NW * 64)) * 64;          // the wave's range of points, whole steps of 64
+        const int r0 = min(c.n, wave * per), r1 = min(c.n, r0 + per);
+        // pass 1: the labels of the wave's range, at most 64 steps (32 768 points over eight waves); what a lane needs of them for pass 2 is one bit
+        // per step -- kept, so that the second pass is stores only (loads behind stores to memory the compiler cannot tell apart would each wait)
+        static_assert(FGT_LISTS_IN_MODEL_MAX_POINTS <= NW * 64 * 64, "a lane's steps fit one 64-bit mask");
+        const int* __restrict__ labels = c.indx;
+        int lt = 0, eq = 0;
+        unsigned long long mine_bits = 0ull;
+        const int steps = (r1 - r0 + 63) / 64;
+        for (int s0 = 0; s0 < steps; s0 += 16) {                        // sixteen steps' labels in flight
+            int lab[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int i = r0 + (s0 + j) * 64 + lane;
+                lab[j] = i < r1 ? labels[i] : 0x7fffffff;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                lt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(lab[j] < k));
+                eq += __builtin_popcountll(__builtin_amdgcn_ballot_w64(lab[j] == k));
+                mine_bits |= (unsigned long long)(lab[j] == k) << (s0 + j);
+            }
+        }
+        if (lane == 0) { s_lt[wave] = lt; s_eq[wave] = eq; }
+        __syncthreads();
+        int first = 0, count = 0, before = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; w2++) {
+            first += s_lt[w2];
+            before += w2 < wave ? s_eq[w2] : 0;
+            count += s_eq[w2];
+        }
+        int at = first + before;
+        for (int step = 0; step < steps; step++) {
+            const bool mine = ((mine_bits >> step) & 1ull) != 0ull;
+            const unsigned long long mk = __builtin_amdgcn_ballot_w64(mine);
+            if (mk == 0ull) continue;
+            if (mine) c.memb[at + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mk, 0u))] = r0 + step * 64 + lane;
+            at += __builtin_popcountll(mk);
+        }
+        if (threadIdx.x == 0) {
+            c.off[k] = first;
+            if (k == c.K - 1) c.off[c.K] = first + count;
+        }
+        __syncthreads();                                               // (the list is this workgroup's own writes: one CU, one L1)
+        j0 = first; j1 = first + count;
+    } else {
+        j0 = c.off[k]; j1 = c.off[k + 1];
+    }
     float cx, cy, cz;
     if (CENTERS) {
         // the cell's mean first -- fgt_centers_kernel's arithmetic (sequential fp32 sums in ascending point order, * (1.0f / count): fgt.cpp:195-210),
@@ -703,8 +762,17 @@ __global__ __launch_bounds__(256) void fgt_post_kt1_kernel(const float* __restri
 {
     double acc[CPD_XSUMS] = {0};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        // the S partial sums in split order -- sixteen loads in flight, then the additions in their order (one load per addition waited a round
+        // trip each: 59 workgroups of a bunny-sized cloud have nothing else to run meanwhile)
         float kt1 = 0.f;
-        for (int sp = 0; sp < S; sp++) kt1 += kt1_parts[(size_t)sp * n + i];
+        for (int sp0 = 0; sp0 < S; sp0 += 16) {
+            float part[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) part[j] = sp0 + j < S ? kt1_parts[(size_t)(sp0 + j) * n + i] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if (sp0 + j < S) kt1 += part[j];
+        }
         const float inv = 1.0f / (kt1 + ndi);                          // cpdutils.cpp:49
         const float x = ax[i], y = ay[i], z = az[i];
         const float p = 1.0f - ndi * inv;                              // CalculatePt1, cpdutils.cpp:79-88
@@ -726,8 +794,19 @@ __global__ __launch_bounds__(256) void fgt_post_px_kernel(const float* __restric
     double acc[CPD_KSUMS] = {0};
     for (int k = blockIdx.x * 256 + threadIdx.x; k < m; k += gridDim.x * 256) {
         float a[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < S; sp++)
-            for (int w = 0; w < 4; w++) a[w] += v_parts[((size_t)sp * 4 + w) * m + k];
+        for (int sp0 = 0; sp0 < S; sp0 += 8) {                          // (eight splits' loads in flight, added in split order: see fgt_post_kt1_kernel)
+            float part[8][4];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int w = 0; w < 4; w++) part[j][w] = sp0 + j < S ? v_parts[((size_t)(sp0 + j) * 4 + w) * m + k] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (sp0 + j < S) {
+#pragma unroll
+                    for (int w = 0; w < 4; w++) a[w] += part[j][w];
+                }
+        }
         px[3 * (size_t)k] = a[0];
         px[3 * (size_t)k + 1] = a[1];
         px[3 * (size_t)k + 2] = a[2];
@@ -817,6 +896,7 @@ hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_b
     else hipLaunchKernelGGL(fgt_kcenter_kernel<0>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, start_ptr, c.K, c.dist, c.indx, c.picked);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (c.lists_in_model && c.centers_in_model && c.n <= FGT_LISTS_IN_MODEL_MAX_POINTS) return hipSuccess;    // (fgt_model(..., centers = true) lists them itself)
     // member lists (stable counting sort on the labels, see fgt_lists_pass_kernel)
     int chunk = 64, G = (c.n + chunk - 1) / chunk;                // one step per wave while the counters fit
     while (G > 4096 || (size_t)G * (size_t)c.K > FGT_LIST_MAX_COUNTERS) { chunk *= 2; G = (c.n + chunk - 1) / chunk; }
@@ -846,12 +926,15 @@ hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const 
 {
     const float inv = 1.0f / sigma;                                // fgt.cpp:260
     const dim3 grid(c.K, (t.pd + FGT_TILE - 1) / FGT_TILE);
-    if (centers) {
-        if (w4) hipLaunchKernelGGL((fgt_model_kernel<4, true>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
-        else hipLaunchKernelGGL((fgt_model_kernel<1, true>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
+    if (centers && c.lists_in_model && c.centers_in_model && c.n <= FGT_LISTS_IN_MODEL_MAX_POINTS) {
+        if (w4) hipLaunchKernelGGL((fgt_model_kernel<4, true, true>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
+        else hipLaunchKernelGGL((fgt_model_kernel<1, true, true>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
+    } else if (centers) {
+        if (w4) hipLaunchKernelGGL((fgt_model_kernel<4, true, false>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
+        else hipLaunchKernelGGL((fgt_model_kernel<1, true, false>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
     } else {
-        if (w4) hipLaunchKernelGGL((fgt_model_kernel<4, false>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
-        else hipLaunchKernelGGL((fgt_model_kernel<1, false>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
+        if (w4) hipLaunchKernelGGL((fgt_model_kernel<4, false, false>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
+        else hipLaunchKernelGGL((fgt_model_kernel<1, false, false>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
     }
     return hipGetLastError();
 }

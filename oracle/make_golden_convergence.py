@@ -3,7 +3,8 @@ cloud-spread 10, max-iterations 100, max-distance-squared 10000, parallel policy
 x 10 / 20 / 30 units -- with a RANDOM known transformation drawn by the reference's own generators) at the set's first size, 20 000 points of
 bird.obj (testset.cpp:19-38: "<= 35 008 -> bird").  The reference's own code (oracle/_ref) prepares the clouds (GetCloudsFromConfig incl. the random
 transformation: ref_clouds_from_config_random) and runs cpu-slam's ICP (basicicp.cpp:23-61); the set has no seeds (std::random_device): the
-fixture fixes one per configuration.  The CPD leg (--cpd) is the same nine pairs at that method's first size, 4 000 points of bunny.obj, hybrid
+fixture fixes one per configuration.  The CPD leg (--cpd) is the same nine pairs at that method's first size, 4 000 points of bunny.obj (and two of
+them at 12 000 points of bunny.obj and at 20 000 of bird.obj, the set's third and last sizes), hybrid
 approximation, cpd-weight 0.1, cpd-tolerance 1e-4 (testset.cpp:122-151) through cpu-slam's GetRigidCPDTransformationMatrix
 (coherentpointdrift.cpp:69-124), with the restatement (oracle/slam_oracle.c + fgt_oracle.c) and two reordered cpu-slam runs beside it.
 Run in the build container (~2 min; the CPD leg ~10 min):
@@ -79,22 +80,26 @@ def main():
 
 
 CPD_SIZE = 4000
+CPD_LARGER = [(12000, "bunny", 1), (12000, "bunny", 5), (20000, "bird", 1), (20000, "bird", 5)]      # (size, object by testset.cpp:19-38, index into PAIRS): later sizes of the set
 
 
 def main_cpd():
     z = np.load(os.path.join(GOLD, "noise_meshes.npz"))
-    raw = np.ascontiguousarray(z["bunny_v"][z["bunny_f"].astype(np.int64)])
-    assert len(raw) == 14904
+    raws = {name: np.ascontiguousarray(z[name + "_v"][z[name + "_f"].astype(np.int64)]) for name in ("bunny", "bird")}
+    assert len(raws["bunny"]) == 14904 and len(raws["bird"]) == 35008
     out = []
     devnull, keep = os.open(os.devnull, os.O_WRONLY), os.dup(1)
     kw = dict(eps=1e-3, weight=0.1, const_scale=False, max_iterations=100, tolerance=1e-4, ratio_of_far_field=10.0, order_of_truncation=8.0)
-    for k, (rot, trans) in enumerate(PAIRS):
-        seed = 2000 + k
-        cfg = {"before-path": "data/bunny.obj", "after-path": "data/bunny.obj", "method": "cpd", "policy": "parallel", "max-iterations": 100,
+    todo = [(CPD_SIZE, "bunny", k) for k in range(len(PAIRS))] + CPD_LARGER
+    for j, (size, name, k) in enumerate(todo):
+        rot, trans = PAIRS[k]
+        seed = 2000 + j
+        raw = raws[name]
+        cfg = {"before-path": "data/%s.obj" % name, "after-path": "data/%s.obj" % name, "method": "cpd", "policy": "parallel", "max-iterations": 100,
                "cloud-spread": 10.0, "max-distance-squared": 10000.0, "rotation-range": rot, "translation-range": trans,
-               "cloud-before-resize": CPD_SIZE, "cloud-after-resize": CPD_SIZE, "random-seed": seed, "approximation-type": "hybrid",
+               "cloud-before-resize": size, "cloud-after-resize": size, "random-seed": seed, "approximation-type": "hybrid",
                "cpd-weight": 0.1, "cpd-tolerance": 1e-4}
-        before, after, R_known, t_known = ref.clouds_from_config_random(raw, None, seed, rot, trans, resize_before=CPD_SIZE, resize_after=CPD_SIZE, spread=10.0)
+        before, after, R_known, t_known = ref.clouds_from_config_random(raw, None, seed, rot, trans, resize_before=size, resize_after=size, spread=10.0)
         os.dup2(devnull, 1)
         try:
             t0 = time.time()
@@ -103,8 +108,8 @@ def main_cpd():
             s20 = ref.cpd_sigma_squared(before, after)
             oR, ot, oit, oerr = O.cpd_approx(before, after, 2, **kw)[:4]
             spread = []
-            for j in range(2):
-                rng = np.random.default_rng(10 * seed + j)
+            for jj in range(2):
+                rng = np.random.default_rng(10 * seed + jj)
                 pR, pt, pit, perr = ref.cpd(before[rng.permutation(len(before))], after[rng.permutation(len(after))], fgt=2, **kw)
                 spread.append({"iterations": int(pit), "distance": frob(pR, pt, sR, t), "error": float(perr)})
         finally:
@@ -115,8 +120,8 @@ def main_cpd():
                     "cpu_slam": {"iterations": int(it), "sR": np.asarray(sR, np.float64).tolist(), "t": np.asarray(t, np.float64).tolist(), "error": float(err), "seconds": round(dt, 1)},
                     "oracle": {"iterations": int(oit), "sR": np.asarray(oR, np.float64).tolist(), "t": np.asarray(ot, np.float64).tolist(), "error": float(oerr)},
                     "oracle_vs_cpu_slam": frob(oR, ot, sR, t), "cpu_slam_vs_known": frob(sR, t, R_known, t_known), "cpu_slam_reordered": spread})
-        print("CPD rot %.1f trans %2.0f: cpu-slam %3d iterations, sigma^2 %.4g, |d| to the known motion %.3g; restatement %3d iterations, |d| vs cpu-slam %.2e; "
-              "cpu-slam reordered %s iterations, |d| vs cpu-slam %s (%.0f s)" % (rot, trans, it, err, out[-1]["cpu_slam_vs_known"], oit, out[-1]["oracle_vs_cpu_slam"],
+        print("CPD %5d points, rot %.1f trans %2.0f: cpu-slam %3d iterations, sigma^2 %.4g, |d| to the known motion %.3g; restatement %3d iterations, |d| vs cpu-slam %.2e; "
+              "cpu-slam reordered %s iterations, |d| vs cpu-slam %s (%.0f s)" % (size, rot, trans, it, err, out[-1]["cpu_slam_vs_known"], oit, out[-1]["oracle_vs_cpu_slam"],
                                                                               [q["iterations"] for q in spread], ["%.2e" % q["distance"] for q in spread], dt), flush=True)
     with open(os.path.join(GOLD, "convergence_cpd.json"), "w") as f:
         json.dump({"source": "GetConvergenceTestSet (testset.cpp:119-187), CPD hybrid, 4 000 points of bunny.obj, run by oracle/_ref; see oracle/make_golden_convergence.py --cpd",

@@ -301,6 +301,29 @@ def test_fixed_side_clustering_beside_the_moving_side_changes_no_bit(ctx, capi, 
             assert a2[3] == a[3] and np.array_equal(a2[0], a[0]) and np.array_equal(a2[1], a[1])
 
 
+def test_member_lists_made_inside_the_model_kernel_change_no_bit(ctx, capi, golden, bunny, monkeypatch):
+    # Round 5: for clouds of at most 32 768 points every cell's workgroup of the model build lists its own members (cpd_fgt.hip, fgt_model_kernel<.., LISTS>)
+    # instead of the stable counting sort's three launches per side (MISLAM_FGT_LISTS_IN_MODEL=0).  The same lists, hence the same sums: E-step
+    # arrays, hybrid and full runs bit for bit -- on the bunny clouds, on ragged sizes (1 .. 4 waves' ranges cut short, fewer points than lanes of a
+    # workgroup), with labels that leave cells empty (duplicated points) and at an order of truncation whose model build takes several workgroups per cell.
+    before, after = bunny
+    g = golden.json("bunny_fgt.json")
+    monkeypatch.setenv("MISLAM_FGT_LISTS_IN_MODEL", "0")
+    with capi.Context(0) as sort:
+        for approx, cap in ((capi.CPD_APPROX_HYBRID, 50), (capi.CPD_APPROX_FULL, 17)):
+            p = capi.cpd_params(max_iterations=cap, sigma2_init=g["sigma2_init"], approximation=approx)
+            a, b = ctx.cpd_register(before, after, p), sort.cpd_register(before, after, p)
+            assert a[3] == b[3] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[4] == b[4]
+        for seed, (m, n) in enumerate(((2, 3), (63, 65), (64, 64), (300, 511), (513, 700), (1025, 4097), (5000, 3000))):
+            y, x = pair(seed, m, n)
+            if seed % 2 == 1:
+                y[m // 2:] = y[: m - m // 2]                     # duplicated points: the sweep leaves cells without members
+            for order in (8, 12):
+                ra, rb = ctx.cpd_estep_fgt(y, x, 0.3, 0.7, 4.0, 10.0, order), sort.cpd_estep_fgt(y, x, 0.3, 0.7, 4.0, 10.0, order)
+                for u, v in zip(ra, rb):
+                    assert np.array_equal(np.asarray(u), np.asarray(v), equal_nan=True), (m, n, order)
+
+
 def test_estep_primitives_reject_bad_arguments(ctx, capi):
     y, x = pair(0, 50, 60)
     with pytest.raises(capi.MiSlamError):

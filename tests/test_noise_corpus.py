@@ -91,6 +91,6 @@ def test_host_input_stage_of_the_cpd_convergence_set(corpus_dir, k):
                        env=dict(os.environ, MISLAM_DUMP_ONLY="1"), cwd=str(corpus_dir), timeout=120)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     before, after = read_dump(dump)
-    assert (len(before), len(after)) == (c["n_before"], c["n_after"]) == (4000, 4000)
+    assert (len(before), len(after)) == (c["n_before"], c["n_after"])
     assert hashlib.sha256(before.tobytes()).hexdigest() == c["sha256_before"]
     assert hashlib.sha256(after.tobytes()).hexdigest() == c["sha256_after"]
