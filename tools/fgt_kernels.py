@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Developer tool: four registrations of the bunny clouds in the reference's approximation-type "full" (17 EM iterations, every E-step a Fast Gauss
+Transform) -- the command to put under `rocprofv3 --kernel-trace --stats` for the per-kernel breakdown of an FGT iteration (K9):
+    rocprofv3 --kernel-trace --stats -d gpurun_out/fgt_kernels --output-format csv -- python3 tools/fgt_kernels.py"""
 import json, os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
