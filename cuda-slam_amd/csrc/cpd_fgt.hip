@@ -508,6 +508,11 @@ constexpr int FGT_MODEL_GROUPS = 4;
 // points labelled k in ascending order.  Two passes over the labels (a few tens of KB, in the caches), each wave a contiguous range: count, then place
 // by a ballot prefix.  The same off / memb as the three sort launches leave (every workgroup of the cell writes the same words), without the launches.
 constexpr int FGT_LISTS_IN_MODEL_MAX_POINTS = 32768;
+constexpr long long FGT_LISTS_IN_MODEL_MAX_READS = 4ll << 20;    // K workgroups read n labels each: beyond this the counting sort's O(n) wins (bunny: K <= 281)
+static bool lists_in_model(const FgtClusters& c)
+{
+    return c.lists_in_model && c.centers_in_model && c.n <= FGT_LISTS_IN_MODEL_MAX_POINTS && (long long)c.K * c.n <= FGT_LISTS_IN_MODEL_MAX_READS;
+}
 template <int W, bool CENTERS, bool LISTS>
 __global__ __launch_bounds__(FGT_TILE * FGT_MODEL_GROUPS) void fgt_model_kernel(FgtClusters c, const float4* __restrict__ w4, float inv_sigma, FgtTables t,
                                                                                 float* __restrict__ B)
@@ -896,7 +901,7 @@ hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_b
     else hipLaunchKernelGGL(fgt_kcenter_kernel<0>, dim3(1), dim3(1024), 0, s, c.x, c.y, c.z, c.n, start, start_ptr, c.K, c.dist, c.indx, c.picked);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (c.lists_in_model && c.centers_in_model && c.n <= FGT_LISTS_IN_MODEL_MAX_POINTS) return hipSuccess;    // (fgt_model(..., centers = true) lists them itself)
+    if (lists_in_model(c)) return hipSuccess;    // (fgt_model(..., centers = true) lists them itself)
     // member lists (stable counting sort on the labels, see fgt_lists_pass_kernel)
     int chunk = 64, G = (c.n + chunk - 1) / chunk;                // one step per wave while the counters fit
     while (G > 4096 || (size_t)G * (size_t)c.K > FGT_LIST_MAX_COUNTERS) { chunk *= 2; G = (c.n + chunk - 1) / chunk; }
@@ -926,7 +931,7 @@ hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const 
 {
     const float inv = 1.0f / sigma;                                // fgt.cpp:260
     const dim3 grid(c.K, (t.pd + FGT_TILE - 1) / FGT_TILE);
-    if (centers && c.lists_in_model && c.centers_in_model && c.n <= FGT_LISTS_IN_MODEL_MAX_POINTS) {
+    if (centers && lists_in_model(c)) {
         if (w4) hipLaunchKernelGGL((fgt_model_kernel<4, true, true>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
         else hipLaunchKernelGGL((fgt_model_kernel<1, true, true>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);
     } else if (centers) {

@@ -322,6 +322,12 @@ def test_member_lists_made_inside_the_model_kernel_change_no_bit(ctx, capi, gold
                 ra, rb = ctx.cpd_estep_fgt(y, x, 0.3, 0.7, 4.0, 10.0, order), sort.cpd_estep_fgt(y, x, 0.3, 0.7, 4.0, 10.0, order)
                 for u, v in zip(ra, rb):
                     assert np.array_equal(np.asarray(u), np.asarray(v), equal_nan=True), (m, n, order)
+        # many cells (K = 450: still listed in the model kernel; K = 2 050: K x n label reads would cost more than the sort's O(n) -- the sort takes over)
+        y, x = pair(11, 5000, 3000)
+        for sigma2 in (0.01, 0.002):
+            ra, rb = ctx.cpd_estep_fgt(y, x, 0.3, sigma2, 4.0, 10.0, 8), sort.cpd_estep_fgt(y, x, 0.3, sigma2, 4.0, 10.0, 8)
+            for u, v in zip(ra, rb):
+                assert np.array_equal(np.asarray(u), np.asarray(v), equal_nan=True), sigma2
 
 
 def test_estep_primitives_reject_bad_arguments(ctx, capi):
