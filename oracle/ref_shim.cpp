@@ -358,6 +358,19 @@ REF_API void ref_nicp(const float* before_xyz, int m, const float* after_xyz, in
     trans3[0] = r.second.x; trans3[1] = r.second.y; trans3[2] = r.second.z;
 }
 
+// The same call as a program of the reference makes it: BEHIND ref_clouds_from_config_* in the same process, on the generator as the input stage
+// left it (mainwrapper.cpp: GetCloudsFromConfig, then the SlamFunc) -- no reseeding.
+REF_API void ref_nicp_continue(const float* before_xyz, int m, const float* after_xyz, int n, float eps, int max_repetitions,
+                               int approximation, int parallel, int subcloud_size, float* rot9_colmajor, float* trans3,
+                               int* repetitions, float* error)
+{
+    auto r = NonIterative::GetNonIterativeTransformationMatrix(to_cloud(before_xyz, m), to_cloud(after_xyz, n), repetitions, error,
+                                                               eps, max_repetitions, static_cast<Common::ApproximationType>(approximation),
+                                                               parallel != 0, subcloud_size);
+    from_mat3(r.first, rot9_colmajor);
+    trans3[0] = r.second.x; trans3[1] = r.second.y; trans3[2] = r.second.z;
+}
+
 // Common::GetRandomPermutationVector  common.cpp:554-560 from a freshly seeded generator; `skip` permutations of the same size
 // are drawn and dropped first (the driver draws one for the subcloud before the repetitions start).
 REF_API void ref_random_permutation(unsigned seed, int size, int skip, int* out)

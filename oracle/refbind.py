@@ -230,6 +230,19 @@ def nicp(before, after, eps=1e-3, max_repetitions=20, approximation=0, parallel=
     return r.reshape(3, 3).T.copy(), t, reps.value, err.value
 
 
+def nicp_continue(before, after, eps=1e-3, max_repetitions=20, approximation=0, parallel=False, subcloud_size=1000):
+    """cpu-slam's NICP on the generator as the last clouds_from_config_* call of this process left it (what the reference's program does)."""
+    before, after = _cloud(before), _cloud(after)
+    r = np.empty(9, np.float32)
+    t = np.empty(3, np.float32)
+    reps = C.c_int(0)
+    err = C.c_float(0)
+    lib().ref_nicp_continue(_fp(before), before.shape[0], _fp(after), after.shape[0], C.c_float(eps), max_repetitions, approximation,
+                            1 if parallel else 0, subcloud_size, _fp(r), _fp(t), C.byref(reps), C.byref(err))
+    _flush()
+    return r.reshape(3, 3).T.copy(), t, reps.value, err.value
+
+
 def random_permutation(seed, size, skip=0):
     out = np.empty(size, np.int32)
     lib().ref_random_permutation(C.c_uint(seed), size, skip, out.ctypes.data_as(C.POINTER(C.c_int)))

@@ -94,3 +94,24 @@ def test_host_input_stage_of_the_cpd_convergence_set(corpus_dir, k):
     assert (len(before), len(after)) == (c["n_before"], c["n_after"])
     assert hashlib.sha256(before.tobytes()).hexdigest() == c["sha256_before"]
     assert hashlib.sha256(after.tobytes()).hexdigest() == c["sha256_after"]
+
+
+# ---- the NICP legs of the reference's sizes and performance sets (testset.cpp:48-116; oracle/make_golden_nicp_sets.py) ----
+NICP_SETS = Golden().json("nicp_sets.json")["configs"]
+
+
+@pytest.mark.parametrize("k", range(len(NICP_SETS)))
+def test_host_input_stage_of_the_nicp_sets(corpus_dir, k):
+    if not os.path.exists(EXE):
+        pytest.skip("mi-slam not built (run __graft_entry__.build())")
+    c = NICP_SETS[k]
+    cfg = corpus_dir / ("nicp_set%d.json" % k)
+    cfg.write_text(json.dumps(c["config_json"]))
+    dump = corpus_dir / ("nicp_set_clouds%d.bin" % k)
+    r = subprocess.run([EXE, str(cfg), "--prepare", "host", "--dump-clouds", str(dump)], capture_output=True, text=True,
+                       env=dict(os.environ, MISLAM_DUMP_ONLY="1"), cwd=str(corpus_dir), timeout=120)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    before, after = read_dump(dump)
+    assert (len(before), len(after)) == (c["n_before"], c["n_after"])
+    assert hashlib.sha256(before.tobytes()).hexdigest() == c["sha256_before"]
+    assert hashlib.sha256(after.tobytes()).hexdigest() == c["sha256_after"]
