@@ -9,7 +9,10 @@ approximation, cpd-weight 0.1, cpd-tolerance 1e-4 (testset.cpp:122-151) through 
 (coherentpointdrift.cpp:69-124), with the restatement (oracle/slam_oracle.c + fgt_oracle.c) and two reordered cpu-slam runs beside it.
 Run in the build container (~2 min; the CPD leg ~10 min):
 
-    python oracle/make_golden_convergence.py [--cpd]
+    python oracle/make_golden_convergence.py [--cpd | --sizes]
+
+--sizes: the ICP leg of GetSizesTestSet instead (testset.cpp:48-80: NO cloud-spread, max-iterations 50, (0.2 rad, 10 units); 1 000 / 5 000 / 13 000 points of
+bunny.obj, 33 000 of bird.obj) -> tests/golden/sizes_icp.json, same fields.
 
 Output  tests/golden/convergence_icp.json   per configuration: the JSON configuration file, sizes and sha256 of the prepared clouds, the transformation
         the reference drew, cpu-slam's iterations / R / t / error, the restatement's (oracle/slam_oracle.c) beside it.
@@ -40,28 +43,39 @@ def frob(R1, t1, R2, t2):
     return float(np.sqrt(((np.asarray(R1, np.float64) - R2) ** 2).sum() + ((np.asarray(t1, np.float64) - t2) ** 2).sum()))
 
 
-def main():
+SIZES_SET = [(1000, "bunny"), (5000, "bunny"), (13000, "bunny"), (33000, "bird")]      # GetSizesTestSet(Icp), testset.cpp:48-80: 1 000 ... 100 000 in steps of 4 000
+
+
+def main(sizes_set=False):
     z = np.load(os.path.join(GOLD, "noise_meshes.npz"))
-    raw = np.ascontiguousarray(z["bird_v"][z["bird_f"].astype(np.int64)])
-    assert len(raw) == 35008
+    raws = {name: np.ascontiguousarray(z[name + "_v"][z[name + "_f"].astype(np.int64)]) for name in ("bunny", "bird")}
+    assert len(raws["bird"]) == 35008
     out = []
     devnull, keep = os.open(os.devnull, os.O_WRONLY), os.dup(1)
-    for k, (rot, trans) in enumerate(PAIRS):
-        seed = 1000 + k
-        cfg = {"before-path": "data/bird.obj", "after-path": "data/bird.obj", "method": "icp", "policy": "parallel", "max-iterations": 100,
-               "cloud-spread": 10.0, "max-distance-squared": 10000.0, "rotation-range": rot, "translation-range": trans,
-               "cloud-before-resize": SIZE, "cloud-after-resize": SIZE, "random-seed": seed}
-        before, after, R_known, t_known = ref.clouds_from_config_random(raw, None, seed, rot, trans, resize_before=SIZE, resize_after=SIZE, spread=10.0)
+    if sizes_set:      # no cloud-spread, max-iterations 50, (0.2 rad, 10 units)
+        todo = [(size, name, 0.2, 10.0, None, 50, 4000 + j) for j, (size, name) in enumerate(SIZES_SET)]
+    else:
+        todo = [(SIZE, "bird", rot, trans, 10.0, 100, 1000 + k) for k, (rot, trans) in enumerate(PAIRS)]
+    for size, name, rot, trans, spread, max_it, seed in todo:
+        raw = raws[name]
+        cfg = {"before-path": "data/%s.obj" % name, "after-path": "data/%s.obj" % name, "method": "icp", "policy": "parallel", "max-iterations": max_it,
+               "max-distance-squared": 10000.0, "rotation-range": rot, "translation-range": trans,
+               "cloud-before-resize": size, "cloud-after-resize": size, "random-seed": seed}
+        if spread is not None:
+            cfg["cloud-spread"] = spread
+        if sizes_set:
+            cfg.update({"approximation-type": "none", "cpd-weight": 0.1})
+        before, after, R_known, t_known = ref.clouds_from_config_random(raw, None, seed, rot, trans, resize_before=size, resize_after=size, spread=spread)
         os.dup2(devnull, 1)
         try:
             t0 = time.time()
-            R, t, it, err = ref.icp(before, after, eps=1e-3, max_distance_squared=10000.0, max_iterations=100, parallel=True)
+            R, t, it, err = ref.icp(before, after, eps=1e-3, max_distance_squared=10000.0, max_iterations=max_it, parallel=True)
             dt = time.time() - t0
-            Ro, to, ito, eo = O.icp(before, after, 1e-3, 10000.0, 100)[:4]
+            Ro, to, ito, eo = O.icp(before, after, 1e-3, 10000.0, max_it)[:4]
             # cpu-slam against itself: the same two point sets in another order (its sequential fp32 centroid and error sums round differently)
             rng = np.random.default_rng(seed)
             Rp, tp, itp, errp = ref.icp(before[rng.permutation(len(before))], after[rng.permutation(len(after))], eps=1e-3, max_distance_squared=10000.0,
-                                        max_iterations=100, parallel=True)
+                                        max_iterations=max_it, parallel=True)
         finally:
             os.dup2(keep, 1)
         out.append({"config_json": cfg, "rotation_range": rot, "translation_range": trans, "seed": seed, "n_before": len(before), "n_after": len(after),
@@ -71,12 +85,15 @@ def main():
                     "oracle": {"iterations": int(ito), "R": np.asarray(Ro, np.float64).tolist(), "t": np.asarray(to, np.float64).tolist(), "error": float(eo)},
                     "oracle_vs_cpu_slam": frob(Ro, to, R, t), "cpu_slam_vs_known": frob(R, t, R_known, t_known),
                     "cpu_slam_reordered": {"iterations": int(itp), "distance": frob(Rp, tp, R, t), "error": float(errp)}})
-        print("rot %.1f trans %2.0f: cpu-slam %3d iterations, error %.4g, |d| to the known motion %.3g; restatement %3d iterations, |d| vs cpu-slam %.2e; "
-              "cpu-slam reordered %3d iterations, |d| vs cpu-slam %.2e (%.0f s)" % (rot, trans, it, err, out[-1]["cpu_slam_vs_known"], ito, out[-1]["oracle_vs_cpu_slam"],
+        print("%6d points, rot %.1f trans %2.0f: cpu-slam %3d iterations, error %.4g, |d| to the known motion %.3g; restatement %3d iterations, |d| vs cpu-slam %.2e; "
+              "cpu-slam reordered %3d iterations, |d| vs cpu-slam %.2e (%.0f s)" % (size, rot, trans, it, err, out[-1]["cpu_slam_vs_known"], ito, out[-1]["oracle_vs_cpu_slam"],
                                                                                  itp, out[-1]["cpu_slam_reordered"]["distance"], dt), flush=True)
-    with open(os.path.join(GOLD, "convergence_icp.json"), "w") as f:
-        json.dump({"source": "GetConvergenceTestSet (testset.cpp:119-187), ICP, 20 000 points of bird.obj, run by oracle/_ref; see oracle/make_golden_convergence.py", "configs": out}, f, indent=1)
-    print("wrote tests/golden/convergence_icp.json")
+    name = "sizes_icp.json" if sizes_set else "convergence_icp.json"
+    with open(os.path.join(GOLD, name), "w") as f:
+        src = ("GetSizesTestSet (testset.cpp:48-80), ICP, 1 000 / 5 000 / 13 000 points of bunny.obj and 33 000 of bird.obj" if sizes_set else
+               "GetConvergenceTestSet (testset.cpp:119-187), ICP, 20 000 points of bird.obj")
+        json.dump({"source": src + ", run by oracle/_ref; see oracle/make_golden_convergence.py", "configs": out}, f, indent=1)
+    print("wrote tests/golden/" + name)
 
 
 CPD_SIZE = 4000
@@ -133,4 +150,4 @@ if __name__ == "__main__":
     if "--cpd" in sys.argv:
         main_cpd()
     else:
-        main()
+        main(sizes_set="--sizes" in sys.argv)
