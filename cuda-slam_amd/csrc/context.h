@@ -121,6 +121,7 @@ struct mi_ctx {
         int dev_fail_loads = 0;                          // MISLAM_DEV_FAIL_LOADS=N: the context's first N index builds fail on purpose (tests/test_gpu_context.py)
         int fgt_two_streams = 1;                         // MISLAM_FGT_TWO_STREAMS=0: the fixed cloud's clustering of an FGT E-step on the main stream, behind the moving side's
         int fgt_lists_in_model = 1;                      // MISLAM_FGT_LISTS_IN_MODEL=0: the member lists of an FGT E-step by the three-launch counting sort (round 4) instead of inside the model kernel
+        int fgt_coop_sweep = 1;                          // MISLAM_FGT_COOP_SWEEP=0: K-centre sweeps of clouds beyond 16 384 points as in rounds 1-4 (one workgroup / two launches per centre); 2: the cooperative kernel for every sweep
         int fgt_replay = 1;                              // MISLAM_FGT_REPLAY=0: sweep the moving cloud step by step every E-step (no guess replayed)
     } tune;
 

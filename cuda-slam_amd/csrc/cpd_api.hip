@@ -370,8 +370,9 @@ static int fgt_side(mi_ctx* c, FgtWork* f, FgtSide* sd, const float* x, const fl
     MI_TRY(sd->dist.reserve(n)); MI_TRY(sd->indx.reserve(n)); MI_TRY(sd->memb.reserve(n));
     MI_TRY(sd->off.reserve((size_t)K + 1)); MI_TRY(sd->xc.reserve(3 * (size_t)K));
     MI_TRY(f->sort_temp.reserve(std::max<size_t>(fgt_sort_temp_bytes(n), 16)));
-    if (n > FGT_GRID_SWEEP_MIN_POINTS) MI_TRY(sd->sweep.reserve(FGT_SWEEP_SCRATCH_BYTES));
-    out->sweep_scratch = n > FGT_GRID_SWEEP_MIN_POINTS ? sd->sweep.p : nullptr;
+    if (n > 16 * 1024) MI_TRY(sd->sweep.reserve(FGT_SWEEP_SCRATCH_BYTES));        // (beyond what one workgroup's registers hold: the cooperative / grid-wide sweeps)
+    out->sweep_scratch = n > 16 * 1024 ? sd->sweep.p : nullptr;
+    out->coop_sweep = c->tune.fgt_coop_sweep;
     // (picked: never shrunk below what a guess still needs -- reserve() keeps the contents when the capacity suffices, and K only grows
     // within a registration; a reallocation loses the guess, so it is dropped with it)
     if (sd->picked.cap < (size_t)K) sd->guess_K = 0;

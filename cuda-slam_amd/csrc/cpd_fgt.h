@@ -41,6 +41,8 @@ struct FgtClusters {
     int* replay_state;                    // [1]  -> the number of leading steps of the guess that were verified
     int replay_done;                      // the replay of this guess is on the stream already (fgt_replay_prelaunch): fgt_cluster only resumes from its verdict
     int centers_in_model;                 // round 5: fgt_cluster leaves the cluster means to the model build that follows (fgt_model(..., centers = true)): one launch less
+    int coop_sweep;                       // round 5: 1 = a sweep of at least 16 steps over more than 16 384 points runs on several workgroups in one cooperative launch
+                                          // (fgt_kcenter_coop_kernel), 2 = every sweep of such a cloud (tests), 0 = never (rounds 1-4)
     int lists_in_model;                   // round 5 (with centers_in_model, clouds of at most 32 768 points): ... and the member lists too -- every cell's workgroup lists its own
                                           // members (the same memb / off as the sort's three launches leave, written by fgt_model instead)
 };

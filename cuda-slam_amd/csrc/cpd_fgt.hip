@@ -176,6 +176,117 @@ __global__ __launch_bounds__(1024) void fgt_kcenter_kernel(const float* __restri
     }
 }
 
+// The same sweep on SEVERAL workgroups in ONE launch (round 5; clouds beyond the 16 384 points one workgroup holds in registers, up to
+// FGT_COOP_MAX_POINTS): workgroup g keeps points [g * 1024 * PER, (g + 1) * 1024 * PER) in registers exactly as the kernel above keeps the whole
+// cloud, and a step's arg-max goes through memory: every workgroup posts its best (key, coordinates) into this step's slot, takes a ticket
+// behind an agent-scope release, waits for the tickets of all G workgroups, and reads the G slots back -- one wave, one slot per lane (G <= 64).
+// Slots are double-buffered by the step's parity (a workgroup can be at most one barrier ahead of the slowest reader); the ticket counter only
+// grows (zeroed by the host before the launch).  The keys are the one-workgroup kernel's (distance bits, complemented index): the same first
+// maximum, the same centres, the same labels, bit for bit.  Launched COOPERATIVELY (all G workgroups resident, or the launch fails and the
+// caller falls back): the wait below ends because every workgroup reaches every barrier -- `start` and K are the same for all of them.
+struct CoopSlot {
+    unsigned long long key;
+    float x, y, z, pad;
+};
+static_assert(sizeof(CoopSlot) == 24 || sizeof(CoopSlot) == 32, "slot layout");
+constexpr int FGT_COOP_MAX_GROUPS = 64;
+constexpr int FGT_COOP_MIN_STEPS = 16;             // (MISLAM_FGT_COOP_SWEEP=2: every sweep, whatever its length -- tests)
+constexpr int FGT_COOP_MAX_POINTS = FGT_COOP_MAX_GROUPS * 1024 * 16;
+static_assert(FGT_SWEEP_SCRATCH_BYTES >= 64 + 2 * FGT_COOP_MAX_GROUPS * sizeof(CoopSlot), "the cooperative sweep's counter and slots fit the sweep scratch");
+template <int PER>
+__global__ __launch_bounds__(1024) void fgt_kcenter_coop_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
+                                                                int start, const int* __restrict__ start_ptr, int K, float* __restrict__ dist,
+                                                                int* __restrict__ indx, int* __restrict__ picked, unsigned int* counter, CoopSlot* slots)
+{
+    if (start_ptr != nullptr) start = *start_ptr;
+    if (start >= K) return;                         // (the same for every workgroup: nobody waits for anybody)
+    __shared__ unsigned long long s_key[16];
+    __shared__ float4 s_xyz[16];
+    __shared__ float4 s_centre;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = (int)gridDim.x;
+    const int base = (int)blockIdx.x * 1024 * PER;
+    float px[PER], py[PER], pz[PER], pd[PER];
+    int pc[PER];
+    ArgMax best = {-1.f, 0x7fffffff, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const int j = base + tid + r * 1024, jc = min(j, n - 1);
+        px[r] = x[jc]; py[r] = y[jc]; pz[r] = z[jc];
+        pd[r] = j < n ? __builtin_inff() : -__builtin_inff(); pc[r] = 0;      // as in fgt_kcenter_kernel
+        if (start > 0) {
+            if (j < n) { pd[r] = dist[jc]; pc[r] = indx[jc]; }
+            if (j < n && pd[r] > best.v) best = {pd[r], j, px[r], py[r], pz[r]};
+        }
+    }
+    float cx = x[1], cy = y[1], cz = z[1];          // the first centre is point 1 (fgt.cpp:162)
+    unsigned int barriers = 0u;
+    for (int step = start; step < K; step++) {
+        if (step > 0) {
+            const unsigned long long mine = argmax_key(best.v, best.i);
+            const unsigned long long wmax = wave_max_u64(mine, 64);
+            if (wmax == 0ull ? lane == 0 : mine == wmax) {
+                s_key[wave] = wmax;
+                s_xyz[wave] = make_float4(best.x, best.y, best.z, 0.f);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const unsigned long long kq = s_key[lane & 15];
+                const unsigned long long kmax = wave_max_u64(kq, 16);
+                const int q = __builtin_ctzll(__builtin_amdgcn_ballot_w64(kq == kmax)) & 15;
+                CoopSlot* row = slots + (size_t)(step & 1) * FGT_COOP_MAX_GROUPS;
+                barriers += 1u;
+                if (lane == 0) {
+                    const float4 w = s_xyz[q];
+                    CoopSlot* mine_slot = row + blockIdx.x;
+                    mine_slot->key = kmax; mine_slot->x = w.x; mine_slot->y = w.y; mine_slot->z = w.z;
+                    __threadfence();                                   // release: the slot before the ticket
+                    atomicAdd(counter, 1u);
+                    const unsigned int target = barriers * (unsigned int)G;
+                    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+                    __threadfence();                                   // acquire: the other workgroups' slots
+                }
+                // (the same wave, behind lane 0's fences in program order)
+                unsigned long long ok = 0ull;
+                float ox = 0.f, oy = 0.f, oz = 0.f;
+                if (lane < G) {
+                    const CoopSlot* o = row + lane;
+                    ok = __hip_atomic_load(&o->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ox = __hip_atomic_load(&o->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    oy = __hip_atomic_load(&o->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    oz = __hip_atomic_load(&o->z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const unsigned long long gmax = wave_max_u64(ok, 64);
+                const int winner = __builtin_ctzll(__builtin_amdgcn_ballot_w64(ok == gmax));   // (keys of distinct points differ; all zero: lane 0, as there)
+                const float wx = __shfl(ox, winner, 64), wy = __shfl(oy, winner, 64), wz = __shfl(oz, winner, 64);
+                if (lane == 0) {
+                    s_centre = make_float4(wx, wy, wz, 0.f);
+                    if (blockIdx.x == 0) picked[step] = (int)(0xffffffffu - (unsigned int)gmax);
+                }
+            }
+            __syncthreads();
+            cx = s_centre.x; cy = s_centre.y; cz = s_centre.z;
+        } else if (blockIdx.x == 0 && tid == 0) picked[0] = 1;
+        best = {-1.f, 0x7fffffff, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int j = base + tid + r * 1024;
+            const float d = len2(px[r] - cx, py[r] - cy, pz[r] - cz);
+            const bool closer = d < pd[r];                               // strict <: fgt.cpp:187
+            const float cur = closer ? d : pd[r];
+            pc[r] = closer ? step : pc[r];
+            pd[r] = cur;
+            const bool further = cur > best.v;                           // ascending j per lane: the first maximum stays
+            best.v = further ? cur : best.v; best.i = further ? j : best.i;
+            best.x = further ? px[r] : best.x; best.y = further ? py[r] : best.y; best.z = further ? pz[r] : best.z;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const int j = base + tid + r * 1024;
+        if (j < n) { indx[j] = pc[r]; dist[j] = pd[r]; }
+    }
+}
+
 // The same sweep for large clouds, one step per launch over the whole grid.  step_kernel applies centre `cur` (step 0: point 1)
 // to every point -- or, scan_only, just reads the distances a finished sweep left -- and posts each workgroup's arg-max (first
 // maximum: every lane walks ascending indices, ties go to the lower index); pick_kernel reduces those to the next centre.
@@ -865,6 +976,39 @@ hipError_t fgt_replay_prelaunch(const FgtClusters& c, hipStream_t s)
     return lim > 0 ? launch_replay_and_check(c, lim, s) : hipErrorInvalidValue;
 }
 
+// The cooperative sweep, if the cloud fits it and the device takes the launch; false: the caller's other paths.
+static bool launch_coop_sweep(const FgtClusters& c, int start, const int* start_ptr, hipStream_t s)
+{
+    const int enabled = c.coop_sweep;
+    if (enabled == 0 || c.sweep_scratch == nullptr || c.n > FGT_COOP_MAX_POINTS) return false;
+    // a cooperative launch costs more than a plain one and does not overlap another stream's: it pays for a sweep of many steps (a cloud's first
+    // clustering), not for the one or two centres a later E-step adds behind a verified replay (measured: CPD at 49 000 points, hybrid, 8 iterations:
+    // 2.92 ms without it, 3.22 ms with it on every sweep)
+    if (enabled != 2 && (start_ptr != nullptr || c.K - start < FGT_COOP_MIN_STEPS)) return false;
+    static int supported = -1;
+    if (supported < 0) {
+        int dev = 0, v = 0;
+        supported = hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeCooperativeLaunch, dev) == hipSuccess && v != 0 ? 1 : 0;
+    }
+    if (supported == 0) return false;
+    int per = 1;
+    while (per < 16 && (long long)FGT_COOP_MAX_GROUPS * 1024 * per < c.n) per *= 2;
+    const int G = (c.n + 1024 * per - 1) / (1024 * per);
+    unsigned int* counter = reinterpret_cast<unsigned int*>(c.sweep_scratch);
+    CoopSlot* slots = reinterpret_cast<CoopSlot*>(reinterpret_cast<unsigned char*>(c.sweep_scratch) + 64);
+    if (hipMemsetAsync(counter, 0, sizeof(unsigned int), s) != hipSuccess) return false;
+    const float *x = c.x, *y = c.y, *z = c.z;
+    int n = c.n, K = c.K;
+    float* dist = c.dist;
+    int *indx = c.indx, *picked = c.picked;
+    void* args[] = {&x, &y, &z, &n, &start, &start_ptr, &K, &dist, &indx, &picked, &counter, &slots};
+    const void* fn = per == 1 ? reinterpret_cast<const void*>(fgt_kcenter_coop_kernel<1>) : per == 2 ? reinterpret_cast<const void*>(fgt_kcenter_coop_kernel<2>)
+                   : per == 4 ? reinterpret_cast<const void*>(fgt_kcenter_coop_kernel<4>) : per == 8 ? reinterpret_cast<const void*>(fgt_kcenter_coop_kernel<8>)
+                   : reinterpret_cast<const void*>(fgt_kcenter_coop_kernel<16>);
+    if (hipLaunchCooperativeKernel(fn, dim3(G), dim3(1024), args, 0, s) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return true;
+}
+
 hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_bytes, hipStream_t s)
 {
     int start = c.k_done > 0 && c.k_done < c.K ? c.k_done : 0;
@@ -883,6 +1027,7 @@ hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_b
         }
     }
     if (start_ptr == nullptr && start >= c.K) { /* every step replayed and verified */ }
+    else if (c.n > 16 * 1024 && launch_coop_sweep(c, start, start_ptr, s)) { /* several workgroups, one launch (fgt_kcenter_coop_kernel) */ }
     else if (c.n > FGT_GRID_SWEEP_MIN_POINTS && c.sweep_scratch != nullptr) {
         // large clouds: one grid-wide launch per step (update + per-workgroup arg-max) and a one-workgroup pick in between --
         // two launches per centre instead of one workgroup streaming the whole cloud K times

@@ -90,6 +90,27 @@ def test_guided_kcenter_is_the_sweep_whatever_the_guess(ctx, oracle, seed, n, K)
             assert 0 <= verified <= K
 
 
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_cooperative_sweep_is_the_one_workgroup_sweep(capi, oracle, monkeypatch, mode):
+    # Round 5: beyond 16 384 points a sweep of 16 or more steps runs on several workgroups in ONE cooperative launch (fgt_kcenter_coop_kernel: every
+    # workgroup keeps its share in registers, a step's arg-max goes through memory behind a ticket barrier) -- the default, which the tests above run.
+    # MISLAM_FGT_COOP_SWEEP=2 sends EVERY sweep of such a cloud there (also the few steps behind a replay: start read from the device), =0 none
+    # (rounds 1-4: one workgroup with its distances in memory, two launches per centre beyond 65 536 points): the oracle's labels and means bit for bit
+    # either way, plain and guided by right / cut / corrupted guesses, 1 / 2 / 4 / 16 points per lane, a last workgroup that is nearly empty
+    monkeypatch.setenv("MISLAM_FGT_COOP_SWEEP", mode)
+    with capi.Context(0) as c2:
+        for seed, n, K in ((7, 16385, 33), (8, 50000, 70), (11, 65537, 37), (15, 131073, 20), (12, 300000, 51), (16, 1000001, 18)):
+            c = cloud(seed, n)
+            xc_o, lab_o = oracle.fgt_kcenter(c, K)
+            xc, lab, picked, v = c2.fgt_kcenter_guided(c, K, np.zeros(0, np.int32))
+            assert v == -1 and np.array_equal(lab, lab_o) and np.array_equal(xc, xc_o), (n, K)
+            bad = picked.copy()
+            bad[K // 2] = (bad[K // 2] + 1) % n
+            for guess in (picked, picked[: K // 3], bad):
+                xg, lg, pg, vg = c2.fgt_kcenter_guided(c, K, guess)
+                assert np.array_equal(lg, lab_o) and np.array_equal(xg, xc_o) and np.array_equal(pg, picked), (n, K, len(guess))
+
+
 def test_guided_kcenter_on_ties_and_under_similarity_transforms(ctx, oracle):
     # a lattice with duplicates: equal distances everywhere, the FIRST maximum must win in the replay as in the sweep
     g = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)

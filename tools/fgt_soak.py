@@ -2,7 +2,9 @@
 """Developer tool: randomized soak of the guided K-centre sweep (mi_fgt_kcenter_guided) against the plain sweep: random clouds (uniform,
 clustered, planar, duplicated, lattice), sizes up to 2e5, K up to 1500, guesses that are right, truncated, corrupted at a random step,
 taken from a transformed copy, or noise -- labels, cell means and choices must be the plain sweep's bit for bit, and `verified` exactly
-the length of the common prefix.      python tools/fgt_soak.py [cases] [seed]"""
+the length of the common prefix.      python tools/fgt_soak.py [cases] [seed] [--coop]
+--coop: the plain sweep comes from a context created under MISLAM_FGT_COOP_SWEEP=0, the guided ones from one under =2 (round 5's cooperative kernel for every sweep
+of a cloud beyond 16 384 points)."""
 import os
 import sys
 
@@ -17,10 +19,16 @@ from nn_soak import cloud  # noqa: E402
 
 
 def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261005)
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    cases = int(argv[0]) if len(argv) > 0 else 60
+    rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 20261005)
     capi = load_package().capi
-    ctx = capi.Context(0)
+    ctx = ref_ctx = capi.Context(0)
+    if "--coop" in sys.argv:         # the plain sweep on a context WITHOUT the cooperative several-workgroup kernel, everything else on one that uses it for every sweep
+        os.environ["MISLAM_FGT_COOP_SWEEP"] = "0"
+        ref_ctx = capi.Context(0)
+        os.environ["MISLAM_FGT_COOP_SWEEP"] = "2"
+        ctx = capi.Context(0)
     bad = 0
     for k in range(cases):
         n = int(10 ** rng.uniform(0.5, 5.3))
@@ -34,7 +42,7 @@ def main():
             c = cloud(rng, max(n, 2), kind).astype(np.float32)
         n = len(c)
         K = max(1, min(K, n))
-        xc0, lab0 = ctx.fgt_kcenter(c, K)
+        xc0, lab0 = ref_ctx.fgt_kcenter(c, K)
         xc1, lab1, picked, v = ctx.fgt_kcenter_guided(c, K, np.zeros(0, np.int32))
         ok = v == -1 and np.array_equal(lab0, lab1) and np.array_equal(xc0.view(np.uint32), xc1.view(np.uint32))
         guesses = [(picked, None)]
