@@ -7,6 +7,8 @@
 mkdir -p gpurun_out; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 S=${STEPS:-20}; W=${WARMUP:-5}; R=${R:-r05}; export R
 export MISLAM_BENCH_NO_RCCL_FLOOR=1   # (the one-rank RCCL communicator of the all-reduce floor leg is not part of what is profiled)
+export MISLAM_FGT_COOP_SWEEP=0        # (rocprofv3 of ROCm 7.2 dies with SIGSEGV in an exit handler of a process that made a cooperative launch -- after its output is
+                                      #  written, but with exit code 139; the bench's CPD leg at 49 000 points makes one (cpd_fgt.hip: fgt_kcenter_coop_kernel).  Plain runs exit cleanly.)
 B="python3 bench.py --steps $S --warmup $W --no-cpu-baseline --no-sizes --no-whole-call"
 run() { d=gpurun_out/${R}_$1; shift; rm -rf $d; timeout -k 10 500 rocprofv3 "$@" -d $d --output-format csv -- $B > $d.log 2>&1 || { tail -5 $d.log; exit 1; }; echo "pass $d done"; }
 probe() { d=gpurun_out/${R}_$1; shift; rm -rf $d; timeout -k 10 200 rocprofv3 "$@" -d $d --output-format csv -- tools/valu_probe > $d.log 2>&1 || { tail -5 $d.log; exit 1; }; }
