@@ -9,9 +9,14 @@
 //             latency-bound; points, distances and labels live in registers (<= 16 per lane) and the arg-max travels with
 //             the winner's coordinates through DPP-free shuffles + one LDS exchange, one barrier per step.  Same arithmetic,
 //             same first-maximum tie rule and same strict-< relabel rule as the reference, so the labels are identical.
-//   members   stable radix sort of (label, point id) -> per-cell member lists in ascending point order
-//   centres   one lane per cell, sequential fp32 sum in member order: bit for bit the reference's cell means
-//   model     one lane per (cell, monomial): sequential fp32 accumulation over the cell's members in the reference's order
+//             Clouds beyond 16 384 points: several workgroups in one cooperative launch, each with its share in registers and the arg-max
+//             through memory behind a ticket barrier (fgt_kcenter_coop_kernel, round 5), or one workgroup with its distances in memory /
+//             two launches per centre (the later E-steps' few additional centres); a sweep can be RESUMED and REPLAYED from a guess.
+//   members   stable counting sort of (label, point id) -> per-cell member lists in ascending point order; for clouds of at most 32 768
+//             points made inside the model kernel instead (every cell's workgroup lists its own members, round 5)
+//   centres   sequential fp32 sum in member order: bit for bit the reference's cell means (inside the model kernel since round 5)
+//   model     a workgroup of four groups of 128 lanes per cell, one lane per monomial: the groups take the member tiles in turn, fp32
+//             accumulation per group in member order, the groups' sums added in group order
 //   predict   one lane per query, cells broadcast from SGPRs, the polynomial evaluated by a nested Horner scheme whose
 //             coefficients stream through scalar loads in traversal order (no per-lane monomial table)
 //
