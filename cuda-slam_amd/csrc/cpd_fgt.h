@@ -56,12 +56,12 @@ hipError_t fgt_replay_prelaunch(const FgtClusters& c, hipStream_t s);
 size_t fgt_sort_temp_bytes(int n);     // scratch fgt_cluster needs for its member-list sort
 // K-centre clustering + member lists + cluster means; everything a model build needs
 hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
-// coefficients B[w][k][hpos] = C_k * sum_{i in cluster k} weight_w(i) exp(-|dx|^2) dx^alpha, dx = (pt - xc_k) / sigma.
+// coefficients B[k][hpos][w] = C_k * sum_{i in cluster k} weight_w(i) exp(-|dx|^2) dx^alpha, dx = (pt - xc_k) / sigma.
 // w4 == nullptr: one weight set of ones (W = 1); else four: (w4.x, w4.y, w4.z, w4.w) (W = 4).
 // centers: compute the cluster means first, in the same kernel (what fgt_centers_kernel would have left in c.xc, the same bits), for a
 // clustering made with centers_in_model.
 hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const FgtTables& t, float* B, hipStream_t s, bool centers = false);
-// v[split][w][i] = sum_{k in split} [ |dy|^2 <= e ] exp(-|dy|^2) sum_alpha B[w][k][alpha] dy^alpha, dy = (q_i - xc_k) / sigma
+// v[split][w][i] = sum_{k in split} [ |dy|^2 <= e ] exp(-|dy|^2) sum_alpha B[k][alpha][w] dy^alpha, dy = (q_i - xc_k) / sigma
 // (fgt.cpp:88-150); the S = fgt_predict_splits(nq, K) partial sums are added in split order by the post kernels
 int fgt_predict_splits(int nq, int K);
 hipError_t fgt_predict(const float* qx, const float* qy, const float* qz, int nq, const float* xc, const float* B, int K, int W,

@@ -782,7 +782,7 @@ __global__ __launch_bounds__(FGT_TILE * FGT_MODEL_GROUPS) void fgt_model_kernel(
         float tot = comb[w * FGT_TILE + tid];
 #pragma unroll
         for (int g2 = 1; g2 < G; g2++) tot += comb[(g2 * W + w) * FGT_TILE + tid];
-        B[((size_t)w * c.K + k) * t.pd + h] = tot * ck;            // fgt.cpp:299-305
+        B[((size_t)k * t.pd + h) * W + w] = tot * ck;              // fgt.cpp:299-305; [cell][Horner slot][weight]: the four weights of a slot side by side
     }
 }
 
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(FGT_TILE * FGT_MODEL_GROUPS) void fgt_model_kernel(
 // pa[w] = sum_a x^a sum_b y^b sum_c z^c Bk[w][h(a,b,c)]; P > 0: compile-time order, fully unrolled; P == 0: any order.
 template <int W, int P>
 struct Horner {
-    static __device__ __forceinline__ void eval(int, float dx, float dy, float dz, const float* __restrict__ Bk, size_t wstride, float (&pa)[W])
+    static __device__ __forceinline__ void eval(int, float dx, float dy, float dz, const float* __restrict__ Bk, float (&pa)[W])
     {
         int h = 0;
 #pragma unroll
@@ -810,7 +810,7 @@ struct Horner {
 #pragma unroll
                 for (int cdeg = P - 1 - a - b; cdeg >= 0; cdeg--, h++) {
 #pragma unroll
-                    for (int w = 0; w < W; w++) pc[w] = __builtin_fmaf(pc[w], dz, Bk[w * wstride + h]);
+                    for (int w = 0; w < W; w++) pc[w] = __builtin_fmaf(pc[w], dz, Bk[h * W + w]);
                 }
 #pragma unroll
                 for (int w = 0; w < W; w++) pb[w] = __builtin_fmaf(pb[w], dy, pc[w]);
@@ -823,7 +823,7 @@ struct Horner {
 
 template <int W>
 struct Horner<W, 0> {
-    static __device__ __forceinline__ void eval(int p, float dx, float dy, float dz, const float* __restrict__ Bk, size_t wstride, float (&pa)[W])
+    static __device__ __forceinline__ void eval(int p, float dx, float dy, float dz, const float* __restrict__ Bk, float (&pa)[W])
     {
         int h = 0;
         for (int a = p - 1; a >= 0; a--) {
@@ -833,7 +833,7 @@ struct Horner<W, 0> {
                 float pc[W];
                 for (int w = 0; w < W; w++) pc[w] = 0.f;
                 for (int cdeg = p - 1 - a - b; cdeg >= 0; cdeg--, h++)
-                    for (int w = 0; w < W; w++) pc[w] = __builtin_fmaf(pc[w], dz, Bk[w * wstride + h]);
+                    for (int w = 0; w < W; w++) pc[w] = __builtin_fmaf(pc[w], dz, Bk[h * W + w]);
                 for (int w = 0; w < W; w++) pb[w] = __builtin_fmaf(pb[w], dy, pc[w]);
             }
             for (int w = 0; w < W; w++) pa[w] = __builtin_fmaf(pa[w], dx, pb[w]);
@@ -857,7 +857,6 @@ __global__ __launch_bounds__(64) void fgt_predict_kernel(const float* __restrict
     float cell[W];
 #pragma unroll
     for (int w = 0; w < W; w++) cell[w] = 0.f;
-    const size_t wstride = (size_t)K * pd;
     for (int k = k_begin; k < k_end; k++) {
         const float dx = (x - xc[3 * k]) * inv_sigma, dy = (y - xc[3 * k + 1]) * inv_sigma, dz = (z - xc[3 * k + 2]) * inv_sigma;
         const float sum = len2(dx, dy, dz);
@@ -866,7 +865,7 @@ __global__ __launch_bounds__(64) void fgt_predict_kernel(const float* __restrict
         float pa[W];
 #pragma unroll
         for (int w = 0; w < W; w++) pa[w] = 0.f;
-        Horner<W, P>::eval(p_runtime, dx, dy, dz, B + (size_t)k * pd, wstride, pa);
+        Horner<W, P>::eval(p_runtime, dx, dy, dz, B + (size_t)k * pd * W, pa);
 #pragma unroll
         for (int w = 0; w < W; w++) cell[w] += e * pa[w];
     }
