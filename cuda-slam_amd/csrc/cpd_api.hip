@@ -37,7 +37,8 @@ struct FgtSide {
 // Fast-Gauss-Transform E-step workspace ("approximation-type" full / hybrid)
 struct FgtWork {
     FgtSide y, a;
-    DevBuf<float> By, Ba;                // coefficients: [1][K][pd] (moving cloud as sources), [4][K][pd] (fixed cloud as sources)
+    DevBuf<float> By, Ba;                // coefficients: [K][pd][1] (moving cloud as sources), [K][pd][4] (fixed cloud as sources)
+    DevBuf<float> By_part, Ba_part;      // big cells (round 5): the partial sums of fgt_model_splits workgroups per cell, [Z][K][pd][W]
     DevBuf<float> kt1, v4;               // transform outputs, per split of the cells: [S][n], [S][4][m]
     DevBuf<unsigned char> sort_temp;
     DevBuf<unsigned char> sort_temp_a;   // the fixed side's own scratch when its clustering runs beside the moving side's (round 5)
@@ -47,7 +48,7 @@ struct FgtWork {
     int p = 0, pd = 0;
     void release()
     {
-        y.release(); a.release(); By.release(); Ba.release(); kt1.release(); v4.release(); sort_temp.release(); sort_temp_a.release();
+        y.release(); a.release(); By.release(); Ba.release(); By_part.release(); Ba_part.release(); kt1.release(); v4.release(); sort_temp.release(); sort_temp_a.release();
         mono.release(); ck.release(); hpos.release(); p = pd = 0;
     }
 };
@@ -443,6 +444,9 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
     MI_TRY(fgt_side(c, f, &f->y, v.yx, v.yy, v.yz, w->m, K, &cy));
     MI_TRY(fgt_side(c, f, &f->a, v.ax, v.ay, v.az, w->n, K, &ca));
     MI_TRY(f->By.reserve((size_t)K * t.pd)); MI_TRY(f->Ba.reserve(4 * (size_t)K * t.pd));
+    const int Zy = c->tune.fgt_model_splits != 0 ? fgt_model_splits(w->m, K, t.pd) : 1, Za = c->tune.fgt_model_splits != 0 ? fgt_model_splits(w->n, K, t.pd) : 1;       // (big cells: a cell's members over several workgroups)
+    if (Zy > 1) MI_TRY(f->By_part.reserve((size_t)Zy * K * t.pd));
+    if (Za > 1) MI_TRY(f->Ba_part.reserve(4 * (size_t)Za * K * t.pd));
     const int Sa = fgt_predict_splits(w->n, K), Sy = fgt_predict_splits(w->m, K);
     MI_TRY(f->kt1.reserve((size_t)Sa * w->n)); MI_TRY(f->v4.reserve(4 * (size_t)Sy * w->m));
     const size_t temp = f->sort_temp.cap;
@@ -480,7 +484,7 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
     cy.lists_in_model = c->tune.fgt_lists_in_model;      // (... and so do the member lists, for clouds of at most 32 768 points: three launches less per side)
     MI_HIP(fgt_cluster(cy, f->sort_temp.p, temp, c->stream));
     f->y.guess_K = K;
-    MI_HIP(fgt_model(cy, nullptr, hsigma, t, f->By.p, c->stream, true));
+    MI_HIP(fgt_model(cy, nullptr, hsigma, t, f->By.p, c->stream, true, Zy > 1 ? f->By_part.p : nullptr, Zy));
     MI_HIP(fgt_predict(v.ax, v.ay, v.az, w->n, cy.xc, f->By.p, K, 1, hsigma, ratio_of_far_field, t, Sa, f->kt1.p, c->stream));
     const int nxb = cpd_standalone_sum_blocks(w->n), nkb = cpd_standalone_sum_blocks(w->m);
     MI_HIP(fgt_post_kt1(f->kt1.p, Sa, v.ax, v.ay, v.az, w->n, ndi, v.pt1, v.xw4, c->stream, with_sums ? w->part_x.p : nullptr, nxb));
@@ -495,7 +499,7 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
             MI_HIP(fgt_cluster(ca, f->sort_temp.p, temp, c->stream));
         f->a.swept_K = K;
     }
-    MI_HIP(fgt_model(ca, v.xw4, hsigma, t, f->Ba.p, c->stream, recluster));      // (an unchanged clustering keeps its means)
+    MI_HIP(fgt_model(ca, v.xw4, hsigma, t, f->Ba.p, c->stream, recluster, Za > 1 ? f->Ba_part.p : nullptr, Za));      // (an unchanged clustering keeps its means)
     MI_HIP(fgt_predict(v.yx, v.yy, v.yz, w->m, ca.xc, f->Ba.p, K, 4, hsigma, ratio_of_far_field, t, Sy, f->v4.p, c->stream));
     MI_HIP(fgt_post_px(f->v4.p, Sy, w->m, v.p1, v.px, c->stream, with_sums ? w->part_k.p : nullptr, nkb, v.bx, v.by, v.bz));
     if (with_sums) { w->sums_fresh = true; w->sum_rows_x = nxb; w->sum_rows_k = nkb; }

@@ -60,7 +60,12 @@ hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_b
 // w4 == nullptr: one weight set of ones (W = 1); else four: (w4.x, w4.y, w4.z, w4.w) (W = 4).
 // centers: compute the cluster means first, in the same kernel (what fgt_centers_kernel would have left in c.xc, the same bits), for a
 // clustering made with centers_in_model.
-hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const FgtTables& t, float* B, hipStream_t s, bool centers = false);
+// part / Z (round 5, big cells): Z = fgt_model_splits(n, K, pd) > 1 and part = Z x K x pd x W floats of scratch: the cells' member lists are split over Z
+// workgroups each, their partial sums added in z order (the means, if asked for, in a launch of their own).
+constexpr int FGT_MODEL_MAX_SPLITS = 16;
+int fgt_model_splits(int n, int K, int pd);
+hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const FgtTables& t, float* B, hipStream_t s, bool centers = false,
+                     float* part = nullptr, int Z = 1);
 // v[split][w][i] = sum_{k in split} [ |dy|^2 <= e ] exp(-|dy|^2) sum_alpha B[k][alpha][w] dy^alpha, dy = (q_i - xc_k) / sigma
 // (fgt.cpp:88-150); the S = fgt_predict_splits(nq, K) partial sums are added in split order by the post kernels
 int fgt_predict_splits(int nq, int K);

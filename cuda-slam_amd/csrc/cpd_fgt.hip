@@ -729,6 +729,15 @@ __global__ __launch_bounds__(FGT_TILE * FGT_MODEL_GROUPS) void fgt_model_kernel(
     } else {
         cx = c.xc[3 * k]; cy = c.xc[3 * k + 1]; cz = c.xc[3 * k + 2];
     }
+    // gridDim.z > 1 (big cells, fgt_model_splits): workgroup z takes a contiguous range of the cell's rounds of G tiles and leaves a PARTIAL sum
+    // (fgt_model_combine_kernel adds the partials in z order)
+    if (gridDim.z > 1) {
+        const int rounds = (j1 - j0 + FGT_TILE * G - 1) / (FGT_TILE * G);
+        const int per = (rounds + (int)gridDim.z - 1) / (int)gridDim.z;
+        const int r0 = min(rounds, (int)blockIdx.z * per), r1 = min(rounds, r0 + per);
+        const int lo = j0 + r0 * FGT_TILE * G, hi = min(j1, j0 + r1 * FGT_TILE * G);
+        j0 = lo; j1 = max(lo, hi);
+    }
     float acc[W];
 #pragma unroll
     for (int w = 0; w < W; w++) acc[w] = 0.f;
@@ -782,8 +791,59 @@ __global__ __launch_bounds__(FGT_TILE * FGT_MODEL_GROUPS) void fgt_model_kernel(
         float tot = comb[w * FGT_TILE + tid];
 #pragma unroll
         for (int g2 = 1; g2 < G; g2++) tot += comb[(g2 * W + w) * FGT_TILE + tid];
-        B[((size_t)k * t.pd + h) * W + w] = tot * ck;              // fgt.cpp:299-305; [cell][Horner slot][weight]: the four weights of a slot side by side
+        // fgt.cpp:299-305; [cell][Horner slot][weight]: the four weights of a slot side by side (gridDim.z > 1: B is the partials' array, [z] outermost)
+        B[(((size_t)blockIdx.z * c.K + k) * t.pd + h) * W + w] = tot * ck;
     }
+}
+
+// B[i] = part[0][i] + part[1][i] + ... in z order (the big cells' partial sums, see above)
+__global__ __launch_bounds__(256) void fgt_model_combine_kernel(const float* __restrict__ part, int Z, size_t count, float* __restrict__ B)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    float tot = part[i];
+    for (int z = 1; z < Z; z++) tot += part[(size_t)z * count + i];
+    B[i] = tot;
+}
+
+// Cell means of BIG cells (thousands of members): fgt_centers_kernel's sums -- sequential fp32 in ascending point order, the reference's bits --
+// with the gathers of the next 512 members in flight while lanes 0..2 of the first wave add up the current ones (two LDS buffers, one barrier per round).
+__global__ __launch_bounds__(512) void fgt_centers_big_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                              const int* __restrict__ memb, const int* __restrict__ off, float* __restrict__ xc)
+{
+    constexpr int PER = 4, R = 512 * PER;              // 2 048 members per round: their sums (~4 us) outlast the next round's gathers
+    __shared__ float s[2][3][R];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int j0 = off[k], j1 = off[k + 1];
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const int q = r * 512 + tid;
+        if (j0 + q < j1) { const int i = memb[j0 + q]; s[0][0][q] = x[i]; s[0][1][q] = y[i]; s[0][2][q] = z[i]; }
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int base = j0; base < j1; base += R, buf ^= 1) {
+        const int cnt = min(R, j1 - base), next = base + R;
+        float nx[PER], ny[PER], nz[PER];
+#pragma unroll
+        for (int r = 0; r < PER; r++) {                                    // (in flight during the sums below)
+            const int q = next + r * 512 + tid;
+            nx[r] = ny[r] = nz[r] = 0.f;
+            if (q < j1) { const int i = memb[q]; nx[r] = x[i]; ny[r] = y[i]; nz[r] = z[i]; }
+        }
+        if (tid < 3) {
+#pragma unroll 8
+            for (int q = 0; q < cnt; q++) sum += s[buf][tid][q];
+        }
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int q = r * 512 + tid;
+            if (next + q < j1) { s[buf ^ 1][0][q] = nx[r]; s[buf ^ 1][1][q] = ny[r]; s[buf ^ 1][2][q] = nz[r]; }
+        }
+        __syncthreads();
+    }
+    if (tid < 3) xc[3 * k + tid] = sum * (1.0f / (float)(j1 - j0));     // (an empty cell: 0 * inf = NaN, exactly as the reference)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1072,13 +1132,39 @@ hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_b
         hipLaunchKernelGGL(fgt_lists_offsets_kernel, dim3(1), dim3(1024), 0, s, tot, c.K, c.off);
         hipLaunchKernelGGL((fgt_lists_pass_kernel<true, false>), dim3(G), dim3(64), lds ? sizeof(int) * (size_t)c.K : 0, s, c.indx, c.n, c.K, chunk, label_bits, H, tot, c.off, c.memb);
     }
-    if (!c.centers_in_model) hipLaunchKernelGGL(fgt_centers_kernel, dim3(c.K), dim3(FGT_TILE), 0, s, c.x, c.y, c.z, c.memb, c.off, c.K, c.xc);
+    if (!c.centers_in_model) {
+        if (c.n / c.K >= 2048) hipLaunchKernelGGL(fgt_centers_big_kernel, dim3(c.K), dim3(512), 0, s, c.x, c.y, c.z, c.memb, c.off, c.xc);   // (the same sums, for big cells)
+        else hipLaunchKernelGGL(fgt_centers_kernel, dim3(c.K), dim3(FGT_TILE), 0, s, c.x, c.y, c.z, c.memb, c.off, c.K, c.xc);
+    }
     return hipGetLastError();
 }
 
-hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const FgtTables& t, float* B, hipStream_t s, bool centers)
+// Big cells: with n / K in the thousands a workgroup per cell leaves most of the chip idle (10^6 points, 51 cells: 0.9 ms per build).  The rounds of a
+// cell's member list are then split over Z workgroups (partial sums, added in z order by a small kernel).  1 for every cloud the bunny-sized tests
+// run: their bits do not move.
+int fgt_model_splits(int n, int K, int pd)
+{
+    const int ny = (pd + FGT_TILE - 1) / FGT_TILE;
+    const long long per_cell = (long long)n / (K > 0 ? K : 1);
+    long long Z = per_cell / (FGT_TILE * FGT_MODEL_GROUPS);                // at least one round of G tiles per workgroup
+    const long long fill = 1024 / ((long long)K * ny > 0 ? (long long)K * ny : 1);   // ... and no more than ~1 024 workgroups in all
+    if (Z > fill) Z = fill;
+    if (Z > FGT_MODEL_MAX_SPLITS) Z = FGT_MODEL_MAX_SPLITS;
+    return Z < 1 ? 1 : (int)Z;
+}
+
+hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const FgtTables& t, float* B, hipStream_t s, bool centers, float* part, int Z)
 {
     const float inv = 1.0f / sigma;                                // fgt.cpp:260
+    if (part != nullptr && Z > 1 && !lists_in_model(c)) {
+        const dim3 gridz(c.K, (t.pd + FGT_TILE - 1) / FGT_TILE, Z);
+        if (centers) hipLaunchKernelGGL(fgt_centers_big_kernel, dim3(c.K), dim3(512), 0, s, c.x, c.y, c.z, c.memb, c.off, c.xc);
+        if (w4) hipLaunchKernelGGL((fgt_model_kernel<4, false, false>), gridz, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, part);
+        else hipLaunchKernelGGL((fgt_model_kernel<1, false, false>), gridz, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, part);
+        const size_t count = (size_t)c.K * t.pd * (w4 ? 4 : 1);
+        hipLaunchKernelGGL(fgt_model_combine_kernel, dim3((unsigned int)((count + 255) / 256)), dim3(256), 0, s, part, Z, count, B);
+        return hipGetLastError();
+    }
     const dim3 grid(c.K, (t.pd + FGT_TILE - 1) / FGT_TILE);
     if (centers && lists_in_model(c)) {
         if (w4) hipLaunchKernelGGL((fgt_model_kernel<4, true, true>), grid, dim3(FGT_TILE * FGT_MODEL_GROUPS), 0, s, c, w4, inv, t, B);

@@ -237,6 +237,7 @@ static int ctx_create_common(int device, mi_ctx** out)
         c->tune.fgt_two_streams = env_i("MISLAM_FGT_TWO_STREAMS", 1);
         c->tune.fgt_lists_in_model = env_i("MISLAM_FGT_LISTS_IN_MODEL", 1);
         c->tune.fgt_coop_sweep = env_i("MISLAM_FGT_COOP_SWEEP", 1);
+        c->tune.fgt_model_splits = env_i("MISLAM_FGT_MODEL_SPLITS", 1);
         c->tune.dev_fail_loads = env_i("MISLAM_DEV_FAIL_LOADS", 0);
         c->tune.grid_deal_rows = env_i("MISLAM_GRID_DEAL_ROWS", -1);
         c->tune.grid_split_walks = env_i("MISLAM_GRID_SPLIT_WALKS", -1);

@@ -213,6 +213,25 @@ def test_fgt_estep_matches_oracle(ctx, oracle, seed, m, n, s2, order):
     assert abs(got[3] - want[3]) < 2e-6 * abs(want[3]) + 1e-3
 
 
+def test_big_cells_split_over_workgroups(ctx, capi, oracle, monkeypatch):
+    # Round 5: with thousands of members per cell the model build splits a cell's member list over several workgroups (partial sums added in a fixed
+    # order) and takes the cell means in a launch of its own (fgt_centers_big_kernel: the same sequential sums).  Against MISLAM_FGT_MODEL_SPLITS=0 (one
+    # workgroup per cell, rounds 1-4): the same arrays up to the summation order of a cell's coefficients; against the oracle: the usual bar.
+    y, x = pair(21, 150000, 120000)
+    s2, s2_init = 2.0, 4.0
+    got = ctx.cpd_estep_fgt(y, x, 0.3, s2, s2_init, 10.0, 8)
+    monkeypatch.setenv("MISLAM_FGT_MODEL_SPLITS", "0")
+    with capi.Context(0) as one:
+        ref = one.cpd_estep_fgt(y, x, 0.3, s2, s2_init, 10.0, 8)
+    for g, r in zip(got[:3], ref[:3]):
+        assert rel(g, r) < 5e-6
+    assert abs(got[3] - ref[3]) < 1e-6 * abs(ref[3])
+    want = oracle.cpd_estep_fgt(y, x, 0.3, s2, s2_init, 10.0, 8.0)
+    for g, w in zip(got[:3], want[:3]):
+        assert rel(g, w) < ESTEP_TOL
+    assert abs(got[3] - want[3]) < 2e-5 * abs(want[3])         # (the oracle adds 120 000 logs one by one in fp32, as cpu-slam does: ~1e-5 of the sum is its own rounding)
+
+
 @pytest.mark.parametrize("name", ["init", "s006"])
 def test_bunny_fgt_estep_golden(ctx, golden, bunny, name):
     before, after = bunny
