@@ -66,7 +66,7 @@ struct CpdView {
 
 // K7t: the truncated E-step of the hybrid mode, culled by tile boxes along a space-filling curve (cpd_trunc.hip)
 constexpr int CPD_TRUNC_TILE = 64;        // points per tile = one wave
-constexpr int CPD_TRUNC_GROUP = 16;       // points per group: what is tested and staged on the side that is streamed
+constexpr int CPD_TRUNC_GROUP = 16;       // points per group: what is tested and staged on the side that is streamed (16 is built into the kernels' lane maps: not a knob)
 constexpr int CPD_TRUNC_MAX_BLOCKS = 4096;   // workgroups (= rows of M-step partial sums) of its two kernels
 struct CpdTruncView {
     CpdState* state;
