@@ -758,7 +758,15 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
 {
     const float u0 = cell_u(q[0], g.ox, g.inv_h), u1 = cell_u(q[1], g.oy, g.inv_h), u2 = cell_u(q[2], g.oz, g.inv_h);
     float gs[3];
-    const float cap2 = grid_lane_cap2(g, u0, u1, u2, gs, extend_reach);      // every point within sqrt(cap2) of the query lies within GRID_REACH_CELLS cells of its clamped own cell
+    float cap2 = grid_lane_cap2(g, u0, u1, u2, gs, extend_reach);            // every point within sqrt(cap2) of the query lies within GRID_REACH_CELLS cells of its clamped own cell
+    // (without the extended reach the cap is the same for every lane -- a product of wave-uniform floats, which only the vector unit can form: said
+    // so, it waits for the end of the scan in a scalar register instead of a vector one the 72-register budget does not have)
+    // (as inline assembly: the builtin is moved up to h_lo^2 and the rest of the product goes back into a vector register)
+    if (!extend_reach) {
+        float cap2_uniform;
+        asm("v_readfirstlane_b32 %0, %1" : "=s"(cap2_uniform) : "v"(cap2));
+        cap2 = cap2_uniform;
+    }
     // squared face gaps in length units, lower bounds (h_lo): what a point within r has already spent on an axis before the extent begins
     const float G0 = (gs[0] * g.h_lo) * (gs[0] * g.h_lo), G1 = (gs[1] * g.h_lo) * (gs[1] * g.h_lo), G2 = (gs[2] * g.h_lo) * (gs[2] * g.h_lo);
     GridLane s;
@@ -907,13 +915,17 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
     float q[3] = {0.f, 0.f, 0.f};
     float best = __builtin_inff();
     unsigned int bidx = 0u, bslot = ~0u;
-    double e0 = 0.0, e1 = 0.0;
+    // the previous pair's squared error and whether it counts, carried to the epilogue as ONE float and a wave mask (two scalar registers) -- as two
+    // doubles they took four vector registers across the whole search, which the 72-register budget paid for in scratch (16 bytes per lane)
+    float e_prev = 0.f;
+    unsigned long long kept_prev = 0ull;
     if (FUSED) {
         float R[9], tr[3];
 #pragma unroll
         for (int k = 0; k < 9; k++) R[k] = a.state->R[k];
 #pragma unroll
         for (int k = 0; k < 3; k++) tr[k] = a.state->t[k];
+        bool kept_lane = false;
         if (valid) {
             const float x = a.bx[i], y = a.by[i], z = a.bz[i];
             // TransformPoint: (rotationMatrix * point) + translationVector  (common.cpp:45-49), glm operation order
@@ -930,12 +942,14 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
                 const float dx = p.x - q[0], dy = p.y - q[1], dz = p.z - q[2];
                 const float e = (dx * dx + dy * dy) + dz * dz;   // diff.LengthSquared(), common.cpp:264-265
                 const bool kept = a.filter_pairs ? (d2 < a.max_distance_squared) : true;
-                if (kept) { e0 = (double)e; e1 = 1.0; }
+                e_prev = kept ? e : 0.f;
+                kept_lane = kept;
                 // the old match under the new transform is a real candidate, evaluated with the search's own arithmetic
                 best = FMA ? __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) : e;
                 bidx = (unsigned int)gidx;
             }
         }
+        kept_prev = __builtin_amdgcn_ballot_w64(kept_lane);
     } else if (valid) {
         q[0] = a.sx[i]; q[1] = a.sy[i]; q[2] = a.sz[i];
         unpack_start(a.keys[i], best, bidx);
@@ -1048,11 +1062,17 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
         } else if (valid) a.match_slot[io] = ~0u;
         double* row = a.rows + (size_t)chunk * ICP_ROW;
         row_store_moments(mom, row, nullptr);
-        row_store_error(e0, e1, row, nullptr);
+        float e_row = e_prev;
+        asm("" : "+v"(e_row));                                 // (the conversion HERE: hoisted to the prologue the double would take two registers across the search)
+        row_store_error((double)e_row, ((kept_prev >> tid) & 1ull) != 0ull ? 1.0 : 0.0, row, nullptr);
         {
             // next iteration's class of this chunk: 0 = no lane walked, 1 = some did, 2 = most lanes lie beyond the grid's reach
             // (this lane's reach under the rule the NEXT search will apply: the class is a prediction for it)
-            const float cap2 = grid_lane_cap2(g, q, !FUSED || a.extend_reach_next != 0);
+            // (the cell size through a scalar register the compiler cannot tell from the one the search used: h_lo^2 -- a wave-uniform product with
+            // no scalar instruction to compute it -- otherwise sits in a vector register from the scan to here, across the whole search)
+            NnGridView ge = g;
+            asm("" : "+s"(ge.h_lo));
+            const float cap2 = grid_lane_cap2(ge, q, !FUSED || a.extend_reach_next != 0);
             const int beyond = (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && !(best <= cap2)));
             if (tid == 0) a.far[chunk] = beyond >= GRID_WALK_ONLY_MIN ? 2 : (walked ? 1 : 0);
             // (the helper wave's share next time: the lanes the scan cannot serve -- NOT "the lanes that walked", which would keep every lane
