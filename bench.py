@@ -32,6 +32,9 @@ Rank 0 prints one JSON line.
                   finds two different RCCL (HIP) runtimes of different versions mapped refuses to start (exit 3, before any device call)
   allreduce_f64_sum_floor    N = 1: the headline path's one collective (64 x 18 doubles) through a ONE-rank RCCL communicator, event-timed
   expected_scaling           N > 1: what the one-GPU emulation of a rank's share predicts, so that the first multi-GPU numbers are read against it
+  (wall budget)   N > 1 only: MISLAM_BENCH_WALL_BUDGET_S (default 420).  Every rank leaves a one-line stage file (start / gloo_init / comm_init /
+                  first_allreduce / load / warmup / timed / ...) and carries a watchdog thread; `--gpus N` without a launcher also watches its child
+                  tree from outside.  On expiry: ONE line with "error", "stages" (every rank's last stage) and "ranks_seen", exit code 124
 """
 import argparse
 import glob
@@ -393,12 +396,102 @@ def runtime_report(capi):
     return rep
 
 
-def self_launch(n_ranks):
+WALL_BUDGET_DEFAULT_S = 420.0
+
+
+def wall_budget_s():
+    """Seconds a `--gpus N` (N > 1) run may take before it is declared hung: MISLAM_BENCH_WALL_BUDGET_S, default 420."""
+    try:
+        return max(1.0, float(os.environ.get("MISLAM_BENCH_WALL_BUDGET_S", WALL_BUDGET_DEFAULT_S)))
+    except ValueError:
+        return WALL_BUDGET_DEFAULT_S
+
+
+def stage_dir():
+    """Where the ranks of ONE run leave their one-line stage files: handed down by the parent that started them, else derived from what every
+    rank of a launcher's tree shares (its run id, or the launcher's pid: torchrun's agent is every worker's parent)."""
+    d = os.environ.get("MISLAM_BENCH_STAGE_DIR")
+    if not d:
+        import tempfile
+        d = os.path.join(tempfile.gettempdir(), "mislam_bench_%s_%d" % (os.environ.get("TORCHELASTIC_RUN_ID", "run"), os.getppid()))
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+_STAGE = {"dir": None, "rank": 0, "t0": time.time()}
+
+
+def stage(name):
+    """One line per rank: the last stage it ENTERED and when (comm_init / first_allreduce / load / timed ... -- an RCCL initialisation that
+    hangs and a kernel that hangs leave different last lines).  Written atomically; costs a rename, never inside a timed region."""
+    d = _STAGE["dir"]
+    if d is None:
+        return
+    path = os.path.join(d, "rank%d.stage" % _STAGE["rank"])
+    try:
+        with open(path + ".tmp", "w") as f:
+            f.write("%s %.3f\n" % (name, time.time() - _STAGE["t0"]))
+        os.replace(path + ".tmp", path)
+    except OSError:
+        pass
+
+
+def read_stages(d):
+    """{rank: {"stage": ..., "t": seconds since that rank started}} from the stage files under d."""
+    out = {}
+    for path in sorted(glob.glob(os.path.join(d, "rank*.stage"))):
+        try:
+            name, t = open(path).read().split()
+            out[int(os.path.basename(path)[4:-6])] = {"stage": name, "t": float(t)}
+        except (OSError, ValueError):
+            continue
+    return out
+
+
+def budget_error_line(n_ranks, steps, warmup, budget, d, who):
+    stages = read_stages(d) if d else {}
+    return json.dumps({"metric": "icp_iterations_per_s", "value": None, "unit": "iterations/s", "n_gpus": n_ranks, "steps": steps, "warmup": warmup,
+                       "error": "wall budget of %.0f s exceeded (%s); the ranks' last stages are in `stages`" % (budget, who),
+                       "wall_budget_s": budget, "ranks_seen": len(stages), "stages": {str(r): v for r, v in sorted(stages.items())}})
+
+
+def start_rank_watchdog(rank, world, steps, warmup):
+    """Ranks started by a launcher other than self_launch (the driver's own torchrun line) have no parent of ours above them: every rank
+    carries a daemon thread that ends ITS process when the budget runs out -- a thread blocked inside ncclCommInitRank or a
+    hipStreamSynchronize holds no Python lock, so the watchdog still runs -- and rank 0's prints the diagnostic line first."""
+    import threading
+    budget = wall_budget_s()
+    d = _STAGE["dir"]
+    # under self_launch the parent's budget is the same number: fire a little earlier so that a live rank 0 gets to print
+    fire_after = budget - (10.0 if os.environ.get("MISLAM_BENCH_PARENT") == "1" and budget > 30.0 else 0.0)
+    done = threading.Event()
+
+    def watch():
+        if done.wait(fire_after):
+            return
+        if rank == 0:
+            sys.stdout.write(budget_error_line(world, steps, warmup, budget, d, "rank watchdog") + "\n")
+            sys.stdout.flush()
+        else:
+            time.sleep(1.0)                    # (rank 0's line first)
+        sys.stderr.write("bench.py rank %d: wall budget of %.0f s exceeded at stage %r\n" % (rank, budget, read_stages(d).get(rank, {}).get("stage")))
+        sys.stderr.flush()
+        os._exit(124)
+    threading.Thread(target=watch, name="bench-wall-budget", daemon=True).start()
+    return done
+
+
+def self_launch(n_ranks, steps, warmup):
     """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks as a fresh child process tree -- `python -m
     torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`, the driver's own launch line -- relay rank 0's
     JSON line and return the child's exit code.  A child, not an exec; called before this process has imported the package or
-    touched the GPU."""
+    touched the GPU.  The child tree gets a WALL BUDGET (wall_budget_s): its stdout is read without ever blocking past it, and on expiry
+    the tree is terminated, ONE JSON line with "error", every rank's last stage and `ranks_seen` is printed and the exit code is 124 --
+    an RCCL initialisation hang on a first unattended multi-GPU run becomes a diagnostic instead of the driver's kill."""
+    import selectors
+    import signal
     import subprocess
+    import tempfile
     # --standalone: the launcher binds its own rendezvous to a free port (no pre-picked port another process could take between a probe
     # and the launcher's bind -- ADVICE r04); --local-addr: the workers' MASTER_ADDR, an address that resolves everywhere
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node=%d" % n_ranks,
@@ -406,19 +499,78 @@ def self_launch(n_ranks):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
-    child = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
-    lines = 0
-    for line in child.stdout:                  # rank 0 prints ONE JSON line; anything else a rank writes to stdout goes to stderr
-        if line.lstrip().startswith("{") and '"metric"' in line:
-            sys.stdout.write(line)
+    budget = wall_budget_s()
+    d = tempfile.mkdtemp(prefix="mislam_bench_")
+    env["MISLAM_BENCH_STAGE_DIR"] = d
+    env["MISLAM_BENCH_PARENT"] = "1"
+    child = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, start_new_session=True)   # own process group: the whole tree can be ended
+    os.set_blocking(child.stdout.fileno(), False)
+    sel = selectors.DefaultSelector()
+    sel.register(child.stdout, selectors.EVENT_READ)
+    deadline = time.time() + budget
+    lines, errors, pending, eof = 0, 0, b"", False
+
+    def relay(raw):
+        nonlocal lines, errors
+        line = raw.decode("utf-8", "replace")
+        if line.lstrip().startswith("{") and '"metric"' in line:      # rank 0 prints ONE JSON line; anything else a rank writes to stdout goes to stderr
+            sys.stdout.write(line if line.endswith("\n") else line + "\n")
             sys.stdout.flush()
             lines += 1
+            errors += '"error"' in line
         else:
             sys.stderr.write(line)
-    rc = child.wait()
-    if rc == 0 and lines != 1:
-        sys.stderr.write("bench.py: the %d-rank child printed %d result lines\n" % (n_ranks, lines))
-        return 1
+
+    while not eof and time.time() < deadline:
+        if not sel.select(timeout=min(1.0, max(0.0, deadline - time.time()))):
+            if child.poll() is not None and not pending:
+                # (the launcher is gone; whatever a straggler still holds the pipe open for is not waited for beyond the budget)
+                pass
+            continue
+        try:
+            chunk = os.read(child.stdout.fileno(), 65536)
+        except BlockingIOError:
+            continue
+        if not chunk:
+            eof = True
+            break
+        pending += chunk
+        while b"\n" in pending:
+            raw, pending = pending.split(b"\n", 1)
+            relay(raw + b"\n")
+    if pending:
+        relay(pending)
+    if not eof:
+        # budget spent: end the tree (TERM, then KILL), say where every rank was
+        for sig, grace in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 5.0)):
+            try:
+                os.killpg(child.pid, sig)
+            except (ProcessLookupError, PermissionError):
+                break
+            try:
+                child.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        if errors == 0:
+            sys.stdout.write(budget_error_line(n_ranks, steps, warmup, budget, d, "parent of the launcher") + "\n")
+            sys.stdout.flush()
+        sys.stderr.write("bench.py: the %d-rank child exceeded its wall budget of %.0f s and was terminated\n" % (n_ranks, budget))
+        rc = 124
+    else:
+        try:
+            rc = child.wait(timeout=max(5.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+            rc = 124
+        if rc == 0 and (lines != 1 or errors):
+            sys.stderr.write("bench.py: the %d-rank child printed %d result lines (%d with an error)\n" % (n_ranks, lines, errors))
+            rc = 1
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
     return rc
 
 
@@ -444,7 +596,7 @@ def main():
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(self_launch(args.gpus))       # (nothing has touched the GPU or imported the package yet)
+        sys.exit(self_launch(args.gpus, args.steps, args.warmup))       # (nothing has touched the GPU or imported the package yet)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -455,8 +607,15 @@ def main():
     use_dist = world > 1 or os.environ.get("MISLAM_BENCH_FORCE_DIST") == "1"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between processes on this driver); before anything loads the HIP runtime
     quiet_host_pools()           # (before numpy / torch are imported)
+    watchdog_done = None
+    if use_dist:
+        # the wall budget of a multi-rank run: stage files + a watchdog per rank, before anything can hang
+        _STAGE.update(dir=stage_dir(), rank=rank, t0=time.time())
+        stage("start")
+        watchdog_done = start_rank_watchdog(rank, world, args.steps, args.warmup)
     dist = None
     if use_dist:
+        stage("gloo_init")
         # torch first: its bundled HIP/RCCL runtime must be the one in the process before libmislam.so is loaded
         import torch  # noqa: F401
         import torch.distributed as dist
@@ -468,6 +627,11 @@ def main():
         # no context is created, nothing is measured, and the line says so
         import torch
         seen = torch.tensor([float(1 << rank)], dtype=torch.float64)
+        stage("comm_init")
+        # (tests/test_bench_launch.py: one rank that never arrives -- what an RCCL initialisation hang looks like from outside)
+        if os.environ.get("MISLAM_BENCH_DRYRUN_HANG_RANK") == str(rank):
+            time.sleep(3600.0)
+        stage("first_allreduce")
         if dist is not None:
             dist.all_reduce(seen, op=dist.ReduceOp.SUM)
             dist.barrier()
@@ -476,10 +640,14 @@ def main():
             print(json.dumps({"metric": "icp_iterations_per_s", "value": None, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "dry_run": "launcher flow only: no device touched, nothing measured",
                               "rccl": {"nranks": world, "ranks_seen_mask": mask, "ranks_seen": bin(mask).count("1"), "transport": "gloo (dry run)"}}), flush=True)
+        stage("done")
+        if watchdog_done is not None:
+            watchdog_done.set()
         if dist is not None:
             dist.destroy_process_group()
         return
 
+    stage("package_load")
     import numpy as np
     from __graft_entry__ import load_package
     capi = load_package().capi
@@ -506,13 +674,24 @@ def main():
                 arr[:] = tk.numpy().view(np.uint64) ^ sign
             else:
                 dist.all_reduce(torch.from_numpy(arr), op=dist.ReduceOp.SUM)
+        stage("comm_init")
         ctx = capi.Context(local_rank, rank, world, exchange=exchange)
     elif use_dist:
         uid = [capi.dist_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
+        stage("comm_init")                     # ncclCommInitRank: every rank must arrive
         ctx = capi.Context(local_rank, rank, world, uid[0])
     else:
         ctx = capi.Context(local_rank)
+    if use_dist:
+        # a 1-element all-reduce on the context's stream right behind the communicator's creation: a hang HERE is the transport's
+        # (initialisation finished, the first collective did not), a hang later is a kernel's or the bench's
+        stage("first_allreduce")
+        nr0, rk0, seen0 = ctx.dist_info()
+        if bin(int(seen0)).count("1") != world:
+            sys.stderr.write("bench.py rank %d: the first all-reduce saw ranks %s of %d\n" % (rank, bin(int(seen0)), world))
+            sys.exit(4)
+    stage("load")
 
     def barrier():
         ctx.synchronize()
@@ -556,13 +735,16 @@ def main():
     def timed_run(before, after, params, warmup, steps, events=True):
         """load (untimed) -> warm-up iterations -> `steps` iterations between barriers, HIP events around the search kernel only
         (events=False: none at all -- the steps as a caller's registration runs them)."""
+        stage("load")
         ctx.icp_load(before, after, params)            # H2D upload, SoA conversion, index build: outside the timed region
+        stage("warmup")
         if warmup > 0:
             ctx.icp_run(warmup)
         ctx.profile_enable(events)
         ctx.profile_select([capi.KERNEL_NN])
         ctx.profile_reset()
         barrier()
+        stage("timed")                                 # (a rename before the clock starts, nothing inside the timed region)
         t0 = time.perf_counter()
         done = ctx.icp_run(steps)
         barrier()
@@ -602,6 +784,7 @@ def main():
     timed_run(before, after, params, args.warmup, args.steps)
     headline_allreduce = None
     # per-kernel breakdown of a step: a few more (untimed) iterations with events around every kernel
+    stage("breakdown")
     ctx.profile_enable(True)
     ctx.profile_select(None)
     ctx.profile_reset()
@@ -640,6 +823,7 @@ def main():
     # a sharded MOVING cloud is what the headline measures, because it is two orders of magnitude faster).
     target_leg, rccl = None, None
     if use_dist:
+        stage("target_sharded_leg")
         ctx.icp_load(before, after, capi.icp_params(eps=0.0, max_iterations=-1, dist_mode=args.dist_mode, nn_mode=capi.NN_BRUTEFORCE,
                                                     shard_mode=capi.SHARD_TARGET))
         ctx.icp_run(1)
@@ -686,6 +870,7 @@ def main():
     # MISLAM_BENCH_CPD=1 also on N > 1 (fixed cloud sharded, one 24-double all-reduce per EM iteration).
     cpd = None
     if not args.no_cpd and (world == 1 or os.environ.get("MISLAM_BENCH_CPD") == "1"):
+        stage("cpd_leg")
         cpd = cpd_bunny(np, capi, ctx, world)
         if world == 1 and rank == 0 and not args.no_cpu_baseline:
             z = np.load(os.path.join(ROOT, "tests", "golden", "bunny_clouds.npz"))
@@ -814,7 +999,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(np, before, after)
         print(json.dumps(out), flush=True)
 
+    stage("report_done")
     ctx.close()
+    stage("done")
+    if watchdog_done is not None:
+        watchdog_done.set()
     if dist is not None:
         dist.barrier()
         destroy = getattr(dist, "destroy_process_group", None)
