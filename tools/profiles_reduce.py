@@ -4,7 +4,8 @@
     <R>_bench_n1e6_nn_grid_timed_dispatches.csv the kernel-trace rows of the TIMED launches of the search kernel (avg_launch_ms recomputable)
     <R>_bench_n1e6_nn_grid_counters.json        per-launch means of the counters over those launches + what produced them (git head, source hash)
     <R>_valu_calibration.json                   the same SQ counters on tools/valu_probe and on the every-pair kernel of the same run
-    <R>_cpd_estep_counters.json                 the CPD E-step kernels of the same run
+    <R>_cpd_estep_counters.json                 the CPD E-step kernels of the same run, one entry per workload (bunny; the published 49 000 points)
+    <R>_cpd_estep_timed_dispatches.csv          the kernel-trace rows those entries are means over, labelled by workload
 """
 import csv
 import glob
@@ -16,7 +17,7 @@ import subprocess
 import sys
 
 S, W = int(sys.argv[1]), int(sys.argv[2])
-R = os.environ.get("R", "r05")
+R = os.environ.get("R", "r06")
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "gpurun_out")
 
@@ -125,30 +126,109 @@ cal["kernels"]["nn_bruteforce_kernel"] = bf
 json.dump(cal, open(os.path.join(OUT, R + "_valu_calibration.json"), "w"), indent=1)
 print(json.dumps({k: {kk: v.get(kk) for kk in ("wave_instructions_per_s", "valu_busy_quadcycles_per_gui_cycle")} for k, v in cal["kernels"].items()}))
 
-# ---- CPD E-step kernels of the same run
-pairs = 14904.0 * 14904.0
-cpd = {"workload": "cpd_bunny_14904", "kernel": "cpd_estep", "steps": None, "warmup": None, "git_head": head,
-       "command": doc["command"].split(";")[0] + " (its cpd_bunny leg: exact P)", "pairs_per_launch": pairs, "kernels": {}}
-names = sorted({r["Kernel_Name"] for r in rows("sq1", "counter_collection.csv") if "cpd_denominator_kernel" in r["Kernel_Name"] or "cpd_contract" in r["Kernel_Name"] or "cpd_trunc_" in r["Kernel_Name"]})
-for kn in names:
-    e = {k: mean(counter_series(d, k, kn)) for d, ks in (("sq1", SQ1), ("sq2", SQ2)) for k in ks}
-    t = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows("stats", "kernel_trace.csv") if r["Kernel_Name"] == kn]
-    e["launches"] = len(t)
-    e["launch_ms"] = mean(t) * 1e-6 if t else None
-    if e.get("SQ_ACTIVE_INST_VALU") and e.get("GRBM_GUI_ACTIVE"):
-        e["valu_busy_quadcycles_per_gui_cycle"] = e["SQ_ACTIVE_INST_VALU"] / e["GRBM_GUI_ACTIVE"]
-    # the matrix pipe: its own pass (SQ_VALU_MFMA_BUSY_CYCLES counts cycles in which a SIMD's matrix pipe is busy, summed over the SIMDs;
-    # GRBM_GUI_ACTIVE of that pass is summed over the 8 XCDs)
-    m = {k: mean(counter_series("mfma", k, kn)) for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE")}
-    if m.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None and m.get("GRBM_GUI_ACTIVE"):
-        cycles = m["GRBM_GUI_ACTIVE"] / 8.0
-        e["mfma"] = {"SQ_VALU_MFMA_BUSY_CYCLES": m["SQ_VALU_MFMA_BUSY_CYCLES"], "SQ_INSTS_VALU_MFMA_MOPS_F32": m["SQ_INSTS_VALU_MFMA_MOPS_F32"],
-                     "SQ_INSTS_MFMA": m.get("SQ_INSTS_MFMA"), "gpu_cycles": cycles,
-                     "mfma_util": m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024.0),
-                     "mfma_flops_per_launch": (m["SQ_INSTS_VALU_MFMA_MOPS_F32"] or 0.0) * 512.0,
-                     "contraction_flops_per_launch": pairs * 8.0,
-                     "note": "mfma_util = busy cycles / (GPU cycles x 1 024 SIMDs); MOPS_F32 counts 512 flops each; the contraction P~ [X|1] is "
-                             "pairs x 4 multiply-adds = pairs x 8 flops, all of it on the matrix pipe when the MFMA form runs"}
-    cpd["kernels"][kn.split("(")[0][-60:]] = e
+# ---- CPD E-step kernels of the same run, ONE ENTRY PER WORKLOAD
+# The bench command runs the exact E-step kernels on two workloads -- the bunny clouds (cfg 4: 14 904 x 14 904; the hybrid leg's exact iterations are the
+# same kernels on the same clouds) and the reference's published size (49 000 x 49 000) -- and round 5 averaged every launch of a kernel in the process
+# under the bunny label.  A launch's workload is read off its GRID: the grid is a function of (n, m) alone (cpd_kernels.hip cpd_denominators /
+# cpd_contract), so the dispatches of one kernel fall into one grid size per workload; a workload's entry holds only ITS dispatches -- trace rows and
+# counter rows alike (both files carry the grid) -- and the selected trace rows are committed as <R>_cpd_estep_timed_dispatches.csv.
+CPD_WORKLOADS = (("cpd_bunny_14904", 14904, 14904), ("cpd_synthetic_uniform_n49000", 49000, 49000))
+
+
+def is_estep_kernel(name):
+    return "cpd_denominator_kernel" in name or "cpd_contract" in name
+
+
+def short(name):
+    return name.split("(")[0][-60:]
+
+
+def exact_form(name):            # the `<.., true>` instantiations are the hybrid mode's truncated E-step: other arithmetic, not this roofline's
+    return not short(name).rstrip().endswith("true>")
+
+
+def grid_of_trace(r):
+    return int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+
+
+trace = [r for r in rows("stats", "kernel_trace.csv") if is_estep_kernel(r["Kernel_Name"]) and exact_form(r["Kernel_Name"])]
+trace.sort(key=lambda r: int(r["Start_Timestamp"]))
+by_kernel_grid = {}
+for r in trace:
+    by_kernel_grid.setdefault((r["Kernel_Name"], grid_of_trace(r)), []).append(r)
+# per kernel: its grid sizes in ascending order of work; the workloads in ascending order of pairs -- the k-th largest grid that carries more than a
+# handful of launches belongs to the k-th largest workload (tiny grids: primitives called on small inputs, e.g. a self-test -- listed under "other")
+grids_of = {}
+for (kn, g), rs in by_kernel_grid.items():
+    grids_of.setdefault(kn, []).append((g, len(rs)))
+assign = {}                                                       # (kernel, grid) -> workload
+for kn, gl in grids_of.items():
+    big = sorted([g for g, cnt in gl if cnt >= 8], reverse=True)[:len(CPD_WORKLOADS)]
+    for g, wl in zip(big, sorted(CPD_WORKLOADS, key=lambda w: -w[1] * w[2])):
+        assign[(kn, g)] = wl[0]
+
+
+def counter_rows_of(d, kn, grid):
+    return [r for r in rows(d, "counter_collection.csv") if r["Kernel_Name"] == kn and int(r["Grid_Size"]) == grid]
+
+
+def counter_mean(d, counter, kn, grid):
+    v = [float(r["Counter_Value"]) for r in counter_rows_of(d, kn, grid) if r["Counter_Name"] == counter]
+    return mean(v)
+
+
+cpd = {"kernel": "cpd_estep", "steps": None, "warmup": None, "git_head": head,
+       "command": doc["command"].split(";")[0] + " (its cpd_bunny leg: exact P on the bunny clouds and at the reference's published size)",
+       "selection": "per kernel, the dispatches whose grid is the workload's (the grid is a function of (n, m) alone); means over ALL such dispatches of the "
+                    "process; the rows themselves: " + R + "_cpd_estep_timed_dispatches.csv",
+       "workloads": {}, "other_dispatches": {}}
+with open(os.path.join(OUT, R + "_cpd_estep_timed_dispatches.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["workload", "kernel", "Dispatch_Id", "grid_work_items", "Start_Timestamp", "End_Timestamp", "duration_ns"])
+    for (kn, g), rs in sorted(by_kernel_grid.items(), key=lambda kv: (assign.get(kv[0], "~"), kv[0][0], kv[0][1])):
+        wl = assign.get((kn, g))
+        if wl is None:
+            cpd["other_dispatches"]["%s grid %d" % (short(kn), g)] = {"launches": len(rs), "mean_ms": mean([(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in rs])}
+            continue
+        for r in rs:
+            w.writerow([wl, short(kn), r.get("Dispatch_Id", ""), g, r["Start_Timestamp"], r["End_Timestamp"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
+for wl, n_, m_ in CPD_WORKLOADS:
+    pairs = float(n_) * float(m_)
+    entry = {"points": [n_, m_], "pairs_per_launch": pairs, "kernels": {}}
+    for (kn, g), rs in by_kernel_grid.items():
+        if assign.get((kn, g)) != wl:
+            continue
+        e = {k: counter_mean(d, k, kn, g) for d, ks in (("sq1", SQ1), ("sq2", SQ2)) for k in ks}
+        t = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs]
+        e["grid_work_items"] = g
+        e["launches"] = len(t)
+        e["launch_ms"] = mean(t) * 1e-6
+        e["launch_ms_min_max"] = [min(t) * 1e-6, max(t) * 1e-6]
+        e["counter_launches"] = len([r for r in counter_rows_of("sq1", kn, g) if r["Counter_Name"] == "SQ_INSTS_VALU"])
+        if e.get("SQ_INSTS_VALU"):
+            e["valu_instructions_per_pair"] = e["SQ_INSTS_VALU"] * 64.0 / pairs
+        if e.get("SQ_ACTIVE_INST_VALU") and e.get("GRBM_GUI_ACTIVE"):
+            e["valu_busy_quadcycles_per_gui_cycle"] = e["SQ_ACTIVE_INST_VALU"] / e["GRBM_GUI_ACTIVE"]
+        # the matrix pipe: its own pass (SQ_VALU_MFMA_BUSY_CYCLES counts cycles in which a SIMD's matrix pipe is busy, summed over the SIMDs;
+        # GRBM_GUI_ACTIVE of that pass is summed over the 8 XCDs)
+        mm = {k: counter_mean("mfma", k, kn, g) for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE")}
+        if "mfma" in kn and mm.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None and mm.get("GRBM_GUI_ACTIVE"):
+            cycles = mm["GRBM_GUI_ACTIVE"] / 8.0
+            e["mfma"] = {"SQ_VALU_MFMA_BUSY_CYCLES": mm["SQ_VALU_MFMA_BUSY_CYCLES"], "SQ_INSTS_VALU_MFMA_MOPS_F32": mm["SQ_INSTS_VALU_MFMA_MOPS_F32"],
+                         "SQ_INSTS_MFMA": mm.get("SQ_INSTS_MFMA"), "gpu_cycles": cycles,
+                         "mfma_util": mm["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024.0),
+                         "mfma_flops_per_launch": (mm["SQ_INSTS_VALU_MFMA_MOPS_F32"] or 0.0) * 512.0,
+                         "contraction_flops_per_launch": pairs * 8.0,
+                         "share_of_contraction_on_matrix_pipe": (mm["SQ_INSTS_VALU_MFMA_MOPS_F32"] or 0.0) * 512.0 / (pairs * 8.0),
+                         "note": "mfma_util = busy cycles / (GPU cycles x 1 024 SIMDs); MOPS_F32 counts 512 flops each; the contraction P~ [X|1] is "
+                                 "pairs x 4 multiply-adds = pairs x 8 flops, all of it on the matrix pipe when the MFMA form runs"}
+        entry["kernels"][short(kn)] = e
+    cpd["workloads"][wl] = entry
+# (bench.py's committed_profile() looks a file up by its top-level workload / kernel: the bunny entry is also the file's own)
+cpd["workload"] = CPD_WORKLOADS[0][0]
+cpd["pairs_per_launch"] = cpd["workloads"][CPD_WORKLOADS[0][0]]["pairs_per_launch"]
+cpd["kernels"] = cpd["workloads"][CPD_WORKLOADS[0][0]]["kernels"]
 json.dump(cpd, open(os.path.join(OUT, R + "_cpd_estep_counters.json"), "w"), indent=1)
-print(json.dumps({k: v.get("valu_busy_quadcycles_per_gui_cycle") for k, v in cpd["kernels"].items()}))
+print(json.dumps({wl: {k: {kk: v.get(kk) for kk in ("launches", "launch_ms", "valu_instructions_per_pair", "valu_busy_quadcycles_per_gui_cycle")} for k, v in e["kernels"].items()}
+                  for wl, e in cpd["workloads"].items()}))
+print(json.dumps({"other": cpd["other_dispatches"]}))
