@@ -209,6 +209,54 @@ def cpu_baseline_cpd(np, before, after, sigma2, weight=0.3):
             "ms_per_em_iteration": (t2 - t0) * 1e3}
 
 
+def estep_roofline(workload, pairs):
+    """Roofline of the exact CPD E-step (K7a + K7b: the affinity is evaluated twice, P is never stored) for ONE workload: vector-pipe busy time of its
+    two kernels from the committed counter profile's entry for THAT workload (profiles/*_cpd_estep_counters.json `workloads`: only the dispatches whose
+    grid is the workload's -- VERDICT r05 item 1), over what the same counters read on a saturated pipe (tools/valu_probe)."""
+    prof_c, src, _ = committed_profile("cpd_bunny_14904", "cpd_estep", None, None)
+    cal, cal_src = valu_calibration()
+    if prof_c is None or cal is None:
+        return None
+    entry = prof_c.get("workloads", {}).get(workload)
+    if entry is None and workload == prof_c.get("workload") and "workloads" not in prof_c:
+        entry = prof_c                                   # (a profile of round 5 or earlier: one entry, mixed launches)
+    if entry is None or "kernels" not in entry:
+        return None
+    sat = cal["kernels"]["valu_probe<0>"]["valu_busy_quadcycles_per_gui_cycle"]
+    ceiling = cal.get("valu_busy_ceiling", VALU_BUSY_CEILING)
+    # the kernels of the EXACT mode only: the `<.., true>` instantiations are the hybrid mode's truncated E-step
+    ks = {k: v for k, v in entry["kernels"].items()
+          if v.get("valu_busy_quadcycles_per_gui_cycle") and v.get("launch_ms") and not k.rstrip().endswith("true>") and "cpd_trunc_" not in k}
+    if not ks:
+        return None
+    t_all = sum(v["launch_ms"] for v in ks.values())
+    busy = sum(v["valu_busy_quadcycles_per_gui_cycle"] * v["launch_ms"] for v in ks.values()) / t_all
+    every_pair = cal["kernels"].get("nn_bruteforce_kernel", {}).get("valu_busy_quadcycles_per_gui_cycle")
+    roof = {"bound": "fp32-valu-issue", "achieved": busy, "peak": ceiling, "unit": "vector-pipe busy quad-cycles per GPU cycle",
+            "frac": busy / ceiling, "workload": workload, "pairs_per_launch": pairs,
+            "peak_is": "the counter's ceiling: 1 024 SIMDs / 4 cycles per wave instruction / 8 XCDs summed in GRBM_GUI_ACTIVE",
+            "probe_reads": sat, "every_pair_kernel_reads": every_pair, "frac_of_probe": busy / sat,
+            "calibration_source": cal_src, "source": src,
+            "kernels": {k: {"launch_ms": v["launch_ms"], "launches_in_profile": v.get("launches"), "frac": v["valu_busy_quadcycles_per_gui_cycle"] / ceiling,
+                            "frac_of_probe": v["valu_busy_quadcycles_per_gui_cycle"] / sat,
+                            "valu_instructions_per_pair": v["SQ_INSTS_VALU"] * 64.0 / pairs if v.get("SQ_INSTS_VALU") else None}
+                        for k, v in ks.items()},
+            "note": "time-weighted over the two E-step kernels of the exact mode, dispatches of this workload only; packed instructions count by the time they hold the pipe, "
+                    "not as one; the contraction's 4 FMAs per pair run on the matrix pipe (MFMA 4x4x1) when that form is selected"}
+    mf = [v["mfma"] for k, v in ks.items() if "mfma" in k and v.get("mfma")]
+    if mf:      # north_star: "MFMA utilisation against the chip's peak" -- the contraction kernel's matrix pipe, from its own counter pass
+        m0 = mf[0]
+        roof["mfma_util"] = m0["mfma_util"]
+        roof["mfma"] = {"busy_cycles_per_launch": m0["SQ_VALU_MFMA_BUSY_CYCLES"], "gpu_cycles_per_launch": m0["gpu_cycles"],
+                        "flops_on_matrix_pipe_per_launch": m0["mfma_flops_per_launch"],
+                        "contraction_flops_per_launch": m0["contraction_flops_per_launch"],
+                        "share_of_contraction_on_matrix_pipe": m0["mfma_flops_per_launch"] / m0["contraction_flops_per_launch"],
+                        "source": src,
+                        "note": "fp32 MFMA peak = fp32 vector peak on this chip; a 4-FMA-per-pair contraction beside ~9 vector "
+                                "instructions per pair of affinity arithmetic cannot fill the matrix pipe -- what it buys is those FMAs off the binding pipe"}
+    return roof
+
+
 def cpd_published_size(np, capi, ctx, n=49000, iterations=8):
     """The size the reference publishes CPD times for (N = 49 000: doc/plots/ms-cpd-3.png, BASELINE.md section 1 -- exact P ~15 500 ms per
     iteration on its GPU build, hybrid ~3 000 ms), on the synthetic recipe of the headline: `iterations` EM iterations each (no stop rule),
@@ -226,6 +274,17 @@ def cpd_published_size(np, capi, ctx, n=49000, iterations=8):
             sR, t, scale, it, err = ctx.cpd_register(before, after, p)
             walls.append((time.perf_counter() - t0) * 1e3)
         out[label] = {"iterations": it, "ms_total": min(walls), "ms_per_em_iteration": min(walls) / max(it, 1), "final_sigma2": err}
+    # the kernels' own times at this size (events around every kernel, one more exact run) and the workload's own roofline entry
+    ctx.profile_enable(True)
+    ctx.profile_select(None)
+    ctx.profile_reset()
+    ctx.cpd_register(before, after, capi.cpd_params(max_iterations=iterations, eps=0.0, tolerance=0.0, approximation=capi.CPD_APPROX_NONE))
+    prof = {capi.KERNEL_NAMES[k]: ctx.profile_get(k) for k in range(len(capi.KERNEL_NAMES))}
+    ctx.profile_enable(False)
+    out["exact"]["kernels_ms_per_launch"] = {k: v[0] / v[1] for k, v in prof.items() if v[1] > 0}
+    roof = estep_roofline(out["workload"], float(n) * float(n))
+    if roof is not None:
+        out["exact"]["roofline"] = roof
     return out
 
 
@@ -313,40 +372,10 @@ def cpd_bunny(np, capi, ctx, world):
                 leg["estep_pairs_per_s"] = pairs / world / (den[0] / den[1] * 1e-3)   # K7a: this rank's share of the N*M affinities
             # roofline of the E-step (K7a + K7b: the affinity is evaluated twice, P is never stored): vector-pipe busy time of the two
             # kernels from the committed counter profile, over what the same counters read on a saturated pipe (tools/valu_probe)
-            prof_c, src, _ = committed_profile("cpd_bunny_14904", "cpd_estep", None, None)
-            cal, cal_src = valu_calibration()
-            if prof_c is not None and cal is not None and "kernels" in prof_c and world == 1:
-                sat = cal["kernels"]["valu_probe<0>"]["valu_busy_quadcycles_per_gui_cycle"]
-                ceiling = cal.get("valu_busy_ceiling", VALU_BUSY_CEILING)
-                # the kernels of the EXACT mode only: the `<.., true>` instantiations are the hybrid mode's truncated E-step
-                ks = {k: v for k, v in prof_c["kernels"].items()
-                      if v.get("valu_busy_quadcycles_per_gui_cycle") and v.get("launch_ms") and not k.rstrip().endswith("true>") and "cpd_trunc_" not in k}
-                if ks:
-                    t_all = sum(v["launch_ms"] for v in ks.values())
-                    busy = sum(v["valu_busy_quadcycles_per_gui_cycle"] * v["launch_ms"] for v in ks.values()) / t_all
-                    every_pair = cal["kernels"].get("nn_bruteforce_kernel", {}).get("valu_busy_quadcycles_per_gui_cycle")
-                    leg["roofline"] = {"bound": "fp32-valu-issue", "achieved": busy, "peak": ceiling, "unit": "vector-pipe busy quad-cycles per GPU cycle",
-                                       "frac": busy / ceiling,
-                                       "peak_is": "the counter's ceiling: 1 024 SIMDs / 4 cycles per wave instruction / 8 XCDs summed in GRBM_GUI_ACTIVE",
-                                       "probe_reads": sat, "every_pair_kernel_reads": every_pair, "frac_of_probe": busy / sat,
-                                       "calibration_source": cal_src, "source": src,
-                                       "kernels": {k: {"launch_ms": v["launch_ms"], "frac": v["valu_busy_quadcycles_per_gui_cycle"] / ceiling,
-                                                       "frac_of_probe": v["valu_busy_quadcycles_per_gui_cycle"] / sat,
-                                                       "valu_instructions_per_pair": v["SQ_INSTS_VALU"] * 64.0 / pairs if v.get("SQ_INSTS_VALU") else None}
-                                                   for k, v in ks.items()},
-                                       "note": "time-weighted over the two E-step kernels of the exact mode; packed instructions count by the time they hold the pipe, not as one; "
-                                               "the contraction's 4 FMAs per pair run on the matrix pipe (MFMA 4x4x1) when that form is selected"}
-                    mf = [v["mfma"] for k, v in ks.items() if "mfma" in k and v.get("mfma")]
-                    if mf:      # north_star: "MFMA utilisation against the chip's peak" -- the contraction kernel's matrix pipe, from its own counter pass
-                        m0 = mf[0]
-                        leg["roofline"]["mfma_util"] = m0["mfma_util"]
-                        leg["roofline"]["mfma"] = {"busy_cycles_per_launch": m0["SQ_VALU_MFMA_BUSY_CYCLES"], "gpu_cycles_per_launch": m0["gpu_cycles"],
-                                                   "flops_on_matrix_pipe_per_launch": m0["mfma_flops_per_launch"],
-                                                   "contraction_flops_per_launch": m0["contraction_flops_per_launch"],
-                                                   "share_of_contraction_on_matrix_pipe": m0["mfma_flops_per_launch"] / m0["contraction_flops_per_launch"],
-                                                   "source": src,
-                                                   "note": "fp32 MFMA peak = fp32 vector peak on this chip; a 4-FMA-per-pair contraction beside ~9 vector "
-                                                           "instructions per pair of affinity arithmetic cannot fill the matrix pipe -- what it buys is those FMAs off the binding pipe"}
+            if world == 1:
+                roof = estep_roofline("cpd_bunny_14904", pairs)
+                if roof is not None:
+                    leg["roofline"] = roof
         out[label] = leg
     return out
 

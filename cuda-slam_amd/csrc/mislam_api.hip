@@ -569,11 +569,25 @@ extern "C" int mi_profile_reset(mi_ctx* c)
     return MI_OK;
 }
 
+// The counting build's counters (GRID_STATS_ROWS copies of GRID_STATS_COLS words), summed over the copies ([7] is a maximum)
+static int search_counters(mi_ctx* c, unsigned long long (&sum)[GRID_STATS_COLS])
+{
+    const size_t words = (size_t)GRID_STATS_ROWS * GRID_STATS_COLS;
+    for (int i = 0; i < GRID_STATS_COLS; i++) sum[i] = 0;
+    if (!c->nn_stats_on) return MI_OK;
+    std::vector<unsigned long long> h(words);
+    MI_HIP(hipMemcpyAsync(h.data(), c->nn_stats.p, sizeof(unsigned long long) * words, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP(hipStreamSynchronize(c->stream));
+    for (size_t r = 0; r < (size_t)GRID_STATS_ROWS; r++)
+        for (int i = 0; i < GRID_STATS_COLS; i++) sum[i] = i == 7 ? std::max(sum[i], h[r * GRID_STATS_COLS + i]) : sum[i] + h[r * GRID_STATS_COLS + i];
+    return MI_OK;
+}
+
 extern "C" int mi_profile_search_stats(mi_ctx* c, int enable, unsigned long long out[8])
 {
     if (!c) { set_error("mi_profile_search_stats: null context"); return MI_ERR_INVALID_ARG; }
     MI_ENTER(c);
-    const size_t words = (size_t)GRID_STATS_ROWS * 8;
+    const size_t words = (size_t)GRID_STATS_ROWS * GRID_STATS_COLS;
 #ifdef MISLAM_DEV_WAVE_TIMELINE        // developer build: 4 words per wave of the last search behind the counters, dumped to $MISLAM_DEV_TIMELINE_FILE
     const size_t tl_words = (size_t)16 * (1u << 18);
     MI_TRY(c->nn_stats.reserve(words + tl_words));
@@ -586,17 +600,25 @@ extern "C" int mi_profile_search_stats(mi_ctx* c, int enable, unsigned long long
 #endif
     MI_TRY(c->nn_stats.reserve(words));
     if (out) {
-        for (int i = 0; i < 8; i++) out[i] = 0;
-        if (c->nn_stats_on) {
-            std::vector<unsigned long long> h(words);
-            MI_HIP(hipMemcpyAsync(h.data(), c->nn_stats.p, sizeof(unsigned long long) * words, hipMemcpyDeviceToHost, c->stream));
-            MI_HIP(hipStreamSynchronize(c->stream));
-            for (size_t r = 0; r < (size_t)GRID_STATS_ROWS; r++)
-                for (int i = 0; i < 8; i++) out[i] = i == 7 ? std::max(out[i], h[r * 8 + i]) : out[i] + h[r * 8 + i];   // [7] is a maximum
-        }
+        unsigned long long sum[GRID_STATS_COLS];
+        MI_TRY(search_counters(c, sum));
+        for (int i = 0; i < 8; i++) out[i] = sum[i];
     }
     c->nn_stats_on = enable != 0;
     if (enable) MI_HIP(hipMemsetAsync(c->nn_stats.p, 0, sizeof(unsigned long long) * words, c->stream));
+    return MI_OK;
+}
+
+extern "C" int mi_profile_search_phases(mi_ctx* c, unsigned long long out[20])
+{
+    if (!c || !out) { set_error("mi_profile_search_phases: null argument"); return MI_ERR_INVALID_ARG; }
+    MI_ENTER(c);
+    if (!c->nn_stats_on) { set_error("mi_profile_search_phases: counting is off (mi_profile_search_stats(ctx, 1, NULL) first)"); return MI_ERR_STATE; }
+    unsigned long long sum[GRID_STATS_COLS];
+    MI_TRY(search_counters(c, sum));
+    static_assert(GRID_STATS_COLS >= 8 + 19, "phases: 19 counters behind the 8 of mi_profile_search_stats");
+    for (int i = 0; i < 19; i++) out[i] = sum[8 + i];
+    out[19] = 0;
     return MI_OK;
 }
 

@@ -16,6 +16,7 @@ constexpr float GRID_POINTS_PER_CELL = 1.25f;       // round 3's scan liked 1.5 
 #endif
 constexpr float GRID_DU_MAX = MISLAM_GRID_DU_MAX;        // the grid answers queries whose neighbour lies within this many cells; the others walk the hierarchy
 constexpr int GRID_STATS_ROWS = 1024;         // mi_profile_search_stats: the counters are kept in this many copies
+constexpr int GRID_STATS_COLS = 32;           // counters per copy: [0, 8) mi_profile_search_stats, [8, 27) mi_profile_search_phases (nn_grid.hip)
 #ifndef MISLAM_GRID_FAR_FACTOR
 #define MISLAM_GRID_FAR_FACTOR 2.0f
 #endif

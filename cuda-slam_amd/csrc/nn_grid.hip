@@ -317,6 +317,11 @@ struct GridLane {
     int budget;
     bool alive;
     unsigned int n_rows;                 // (STATS)
+    // (STATS) wave-uniform trip counts of the scan's loops, what tools/isa_budget.py multiplies the kernel's static instruction counts by:
+    // [0] block batches run, [1] of them dealt, [2] deal passes, [3] iterations of the deal's write loop, [4] lockstep trips;
+    // [5] leftover rounds (rows dealt out), [6] of them with their trips dealt, [7] deal passes, [8] write-loop iterations, [9] lockstep trips,
+    // [10] leftover batches of the four-rows-per-lane form, [11] waves that had leftover rows
+    unsigned int ph[12];
 #ifdef MISLAM_DEV_WAVE_TIMELINE
     unsigned long long t_in, t_block;    // developer build: entry of the scan, end of its first batch
     unsigned int trips_block, trips_rest, batches_rest;
@@ -373,11 +378,11 @@ __device__ __forceinline__ void wave_lds_sync()
 // Returns false (nothing done) if dealing does not pay or does not fit; true: kbest / bslot hold the lane's results.
 // `owner_lane`: the lane the trips are tested FOR (the lane itself, or -- leftover rows dealt out -- the lane whose row it scans; then
 // `own_setup` is false: the owners' queries and keys are in LDS already).
-template <bool FMA>
+template <bool FMA, bool COUNT = false>
 __device__ __forceinline__ bool grid_deal_scan(const float4* __restrict__ pts, const float q[3], unsigned int n_trips, unsigned int e1, unsigned int e2,
                                                unsigned int e3, unsigned int b0, unsigned int b1, unsigned int b2, unsigned int b3,
                                                unsigned long long& kbest, unsigned int& bslot, unsigned int& dev_passes,
-                                               unsigned int owner_lane, bool own_setup)
+                                               unsigned int owner_lane, bool own_setup, unsigned int* count = nullptr)
 {
     static_assert(GRID_TRIP == 4, "a dealt trip is four candidates");
     GridWaveLds& L = grid_wave_lds();
@@ -410,6 +415,7 @@ __device__ __forceinline__ bool grid_deal_scan(const float4* __restrict__ pts, c
         deal_key[lane] = kbest;
     }
     const unsigned char mine = (unsigned char)owner_lane;
+    if (COUNT) { count[0] += 1u; count[1] += (total + 63u) >> 6; count[2] += longest; }
     for (unsigned int k = 0; k < longest; k++) {                // (wave-uniform bound: the lane with the most trips)
         if (k < n_trips) {
             const unsigned int t = k * GRID_TRIP;
@@ -528,7 +534,9 @@ __device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, uns
 #ifndef MISLAM_GRID_NO_DEAL
     {
         unsigned int dev_passes = 0u;
-        const bool dealt = grid_deal_scan<FMA>(pts, s.q, e4 / GRID_TRIP, e1, e2, e3, b0, b1, b2, b3, kbest, bslot, dev_passes, (unsigned int)threadIdx.x & 63u, true);
+        if (STATS) s.ph[BLOCK ? 0 : 10] += 1u;
+        const bool dealt = grid_deal_scan<FMA, STATS>(pts, s.q, e4 / GRID_TRIP, e1, e2, e3, b0, b1, b2, b3, kbest, bslot, dev_passes, (unsigned int)threadIdx.x & 63u, true,
+                                                      STATS ? &s.ph[BLOCK ? 1 : 6] : nullptr);
 #ifdef MISLAM_DEV_WAVE_TIMELINE
         if (BLOCK) s.trips_block += dev_passes; else s.trips_rest += dev_passes;
 #endif
@@ -536,6 +544,7 @@ __device__ __forceinline__ void grid_batch(const NnGridView& g, GridLane& s, uns
     }
 #endif
     for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < e4) != 0ull; t += GRID_TRIP) {
+        if (STATS) s.ph[BLOCK ? 4 : 9] += 1u;
 #ifdef MISLAM_DEV_WAVE_TIMELINE
         if (BLOCK) s.trips_block += 1; else s.trips_rest += 1;
 #endif
@@ -611,7 +620,9 @@ __device__ __forceinline__ void grid_rows_dealt(const NnGridView& g, GridLane& s
     L.own_cand[lane] = 0u;
     if (mask != 0u) { L.rec_first[rank] = first | (lane << 16); L.rec_rows[rank] = mask; }
     wave_lds_sync();                                            // (the arrays are one wave's own: orders its LDS traffic)
+    if (STATS) s.ph[11] += 1u;
     for (unsigned int base = 0; base < total; base += 64u) {    // (wave-uniform; one round unless the wave has more than 64 rows left)
+        if (STATS) s.ph[5] += 1u;
         const unsigned int c = base + lane;
         const bool have = c < total;
         unsigned int lo = 0u;                                   // the last record that starts at or before row c
@@ -649,7 +660,7 @@ __device__ __forceinline__ void grid_rows_dealt(const NnGridView& g, GridLane& s
             // the trips of the dealt rows, dealt in turn (3.6 lockstep trips per round without, 1.6 passes + trips with: the rows' runs
             // differ in length); kbest / bslot: the lane's OWN -- the deal ends with every lane collecting what was found for it
             unsigned int dev_passes = 0u;
-            const bool dealt = grid_deal_scan<FMA>(pts, s.q, e / GRID_TRIP, e, e, e, S, S, S, S, s.kbest, s.bslot, dev_passes, owner, false);
+            const bool dealt = grid_deal_scan<FMA, STATS>(pts, s.q, e / GRID_TRIP, e, e, e, S, S, S, S, s.kbest, s.bslot, dev_passes, owner, false, STATS ? &s.ph[6] : nullptr);
 #ifdef MISLAM_DEV_WAVE_TIMELINE
             s.trips_rest += dev_passes;
 #endif
@@ -660,6 +671,7 @@ __device__ __forceinline__ void grid_rows_dealt(const NnGridView& g, GridLane& s
         const unsigned long long kb0 = kb;
         unsigned int slot = 0u;
         for (unsigned int t = 0; __builtin_amdgcn_ballot_w64(t < e) != 0ull; t += GRID_TRIP) {
+            if (STATS) s.ph[9] += 1u;
 #ifdef MISLAM_DEV_WAVE_TIMELINE
             s.trips_rest += 1;
 #endif
@@ -750,7 +762,7 @@ __device__ __forceinline__ float grid_du(const NnGridView& g, float r2, float ot
 // `reach_word` = row_occ of the query's cell: 0 says no cell the scan could visit holds a point, a clear bit that its row holds none.  `lane_on`: the lane has a point.
 template <bool FMA, bool STATS>
 __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3], bool lane_on, unsigned int reach_word, float& best, unsigned int& bidx,
-                                            unsigned int& bslot, unsigned int& n_cand, unsigned int& n_rows, bool deal_rows, bool extend_reach
+                                            unsigned int& bslot, unsigned int& n_cand, unsigned int& n_rows, bool deal_rows, bool extend_reach, unsigned int (&phases)[12]
 #ifdef MISLAM_DEV_WAVE_TIMELINE
                                             , unsigned long long (&dev_tl)[3]
 #endif
@@ -777,6 +789,7 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
     s.bslot = bslot;
     s.budget = GRID_CAND_BUDGET;
     s.n_rows = 0u;
+    if (STATS) for (int k = 0; k < 12; k++) s.ph[k] = 0u;
     const int cx = cell_index(u0, g.nx);
     s.cy = cell_index(u1, g.ny);
     s.cz = cell_index(u2, g.nz);
@@ -844,7 +857,10 @@ __device__ __forceinline__ bool grid_search(const NnGridView& g, const float q[3
     best = __uint_as_float((unsigned int)(s.kbest >> 32));
     bidx = (unsigned int)s.kbest;
     bslot = s.bslot;
-    if (STATS) { n_cand += (unsigned int)(GRID_CAND_BUDGET - s.budget); n_rows += s.n_rows; }
+    if (STATS) {
+        n_cand += (unsigned int)(GRID_CAND_BUDGET - s.budget); n_rows += s.n_rows;
+        for (int k = 0; k < 12; k++) phases[k] = s.ph[k];
+    }
 #ifdef MISLAM_DEV_WAVE_TIMELINE
     dev_tl[0] = s.t_in; dev_tl[1] = s.t_block; dev_tl[2] = s.trips_block | ((unsigned long long)s.trips_rest << 16) | ((unsigned long long)s.batches_rest << 32);
 #endif
@@ -961,6 +977,8 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
     const unsigned int near_word = g.row_occ[cell_of(g, q[0], q[1], q[2])];
     bool hard = false;
     unsigned int n_cand = 0u, n_rows = 0u, n_nodes = 0u, n_leaves = 0u;
+    unsigned int phases[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};      // (STATS: grid_search's loop trip counts, GridLane::ph)
+    bool scanned = false;
     // A chunk most of whose lanes ended beyond the grid's reach last time (they will again: the flags move slowly) skips the scan:
     // all its lanes walk, each from its own starting candidate -- the walk is exact by itself, the few lanes the scan would have
     // served add little to the union the wave visits anyway, and the wave's critical path loses the scan (speed only).
@@ -984,15 +1002,17 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
     if (walk_only) hard = valid && (!halves || (tid >> 5) == helper);
     else if (WAVES == 2 && helper != 0) hard = valid && mine_to_walk;
 #ifdef MISLAM_DEV_WAVE_TIMELINE
-    else hard = grid_search<FMA, STATS>(g, q, valid && !mine_to_walk, near_word, best, bidx, bslot, n_cand, n_rows, a.deal_rows != 0, extend_reach, dev_tl) && valid && !mine_to_walk;
+    else hard = grid_search<FMA, STATS>(g, q, valid && !mine_to_walk, near_word, best, bidx, bslot, n_cand, n_rows, a.deal_rows != 0, extend_reach, phases, dev_tl) && valid && !mine_to_walk;
 #else
-    else hard = grid_search<FMA, STATS>(g, q, valid && !mine_to_walk, near_word, best, bidx, bslot, n_cand, n_rows, a.deal_rows != 0, extend_reach) && valid && !mine_to_walk;   // (all lanes: the loops run in step)
+    else hard = grid_search<FMA, STATS>(g, q, valid && !mine_to_walk, near_word, best, bidx, bslot, n_cand, n_rows, a.deal_rows != 0, extend_reach, phases) && valid && !mine_to_walk;   // (all lanes: the loops run in step)
 #endif
+    if (STATS) scanned = !walk_only && !(WAVES == 2 && helper != 0);
     bool walked = __builtin_amdgcn_ballot_w64(hard) != 0ull;
 #ifdef MISLAM_DEV_WAVE_TIMELINE
     tl_scan = wall_clock64();
 #endif
-    if (hard) tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves, cold);
+    unsigned int walk_counts[4] = {0u, 0u, 0u, 0u};
+    if (hard) tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves, cold, STATS ? walk_counts : nullptr);
     if (WAVES == 2 && (walk_only ? halves : predicted != 0ull)) {       // (workgroup-uniform: both waves are here)
         __shared__ float x_best[64];
         __shared__ unsigned int x_bidx[64];
@@ -1013,7 +1033,7 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
     // using scalar loads for the hierarchy (it can no longer prove those arrays unwritten)
     if (STATS) {
         // spread over GRID_STATS_ROWS rows of 8 counters (64 bytes apart): atomics on one line serialise at ~10 ns each
-        unsigned long long* srow = a.stats + (size_t)(blockIdx.x % GRID_STATS_ROWS) * 8;
+        unsigned long long* srow = a.stats + (size_t)(blockIdx.x % GRID_STATS_ROWS) * GRID_STATS_COLS;
         unsigned int c0 = valid ? n_cand : 0u, c1 = valid ? n_rows : 0u;
         unsigned int v0 = hard ? n_nodes : 0u, v1 = hard ? n_leaves : 0u;
 #pragma unroll
@@ -1024,7 +1044,7 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
         const unsigned long long nh = __builtin_popcountll(__builtin_amdgcn_ballot_w64(hard)), nv = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid));
 #ifdef MISLAM_DEV_WAVE_TIMELINE
         if (tid == 0) {
-            unsigned long long* tl = a.stats + (size_t)GRID_STATS_ROWS * 8 + (size_t)blockIdx.x * 16;
+            unsigned long long* tl = a.stats + (size_t)GRID_STATS_ROWS * GRID_STATS_COLS + (size_t)blockIdx.x * 16;
             tl[8] = tl_p1; tl[9] = tl_p2; tl[10] = tl_p3;
             tl[0] = tl_start; tl[1] = tl_scan; tl[2] = wall_clock64();
             tl[3] = (unsigned long long)(v0 + v1) | (nh << 16) | ((unsigned long long)(walk_only ? 1 : 0) << 32) | ((unsigned long long)chunk << 40);
@@ -1042,6 +1062,28 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
                 atomicAdd(&srow[5], (unsigned long long)v1);
                 atomicAdd(&srow[6], 1ull);
                 atomicMax(&srow[7], (unsigned long long)(v0 + v1));     // the longest walk, in steps
+            }
+            // the loops' trip counts (wave-uniform: lane 0's), mi_profile_search_phases: [8] waves, [9] waves that scanned, [10] walk-only waves, [11 ..] GridLane::ph
+            atomicAdd(&srow[8], 1ull);
+            if (scanned) atomicAdd(&srow[9], 1ull);
+            if (walk_only) atomicAdd(&srow[10], 1ull);
+            if (scanned)
+                for (int k = 0; k < 12; k++)
+                    if (phases[k] != 0u) atomicAdd(&srow[11 + k], (unsigned long long)phases[k]);
+        }
+        {
+            // the walk's other loops (wave-uniform trip counts; the walking lanes agree, the others hold 0): a maximum over the wave, then one atomic each
+            unsigned int w0 = hard ? walk_counts[0] : 0u, w1 = hard ? walk_counts[1] : 0u, w2 = hard ? walk_counts[2] : 0u, w3 = hard ? walk_counts[3] : 0u;
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) {
+                w0 = max(w0, (unsigned int)__shfl_xor(w0, m, 64)); w1 = max(w1, (unsigned int)__shfl_xor(w1, m, 64));
+                w2 = max(w2, (unsigned int)__shfl_xor(w2, m, 64)); w3 = max(w3, (unsigned int)__shfl_xor(w3, m, 64));
+            }
+            if (tid == 0 && walked) {
+                atomicAdd(&srow[23], (unsigned long long)w0);
+                atomicAdd(&srow[24], (unsigned long long)w1);
+                atomicAdd(&srow[25], (unsigned long long)w2);
+                atomicAdd(&srow[26], (unsigned long long)w3);
             }
         }
     }

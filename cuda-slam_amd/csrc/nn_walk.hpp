@@ -106,7 +106,8 @@ __device__ __forceinline__ f32x2 box6_bound2(const float* __restrict__ pr, const
 
 template <bool FMA, bool STATS>
 __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float p[3], float& best, unsigned int& bidx,
-                                               unsigned int& n_nodes, unsigned int& n_leaves, bool nearest_first = false
+                                               unsigned int& n_nodes, unsigned int& n_leaves, bool nearest_first = false,
+                                               unsigned int* walk_counts = nullptr     // (STATS) [0] leaves whose offers ran, [1] leaf children looked at, [2] votes for the nearest child, [3] pops
                                                )
 {
     const float* __restrict__ boxes6 = t.boxes6;
@@ -152,6 +153,7 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
             }
         }
         if (__builtin_amdgcn_ballot_w64(m <= best) == 0ull) return;
+        if (STATS && walk_counts) walk_counts[0] += 1u;
 #pragma unroll
         for (int k = 0; k < TREE_LEAF / 2; k++) {
             offer(d[k].x, slot0 + 2 * k);
@@ -203,6 +205,7 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
 #pragma unroll 1
                 for (unsigned int m = mask; m != 0u; m &= m - 1u) {
                     const int j = __builtin_ctz(m);
+                    if (STATS && walk_counts) walk_counts[1] += 1u;
                     float lbj = lb[0];
 #pragma unroll
                     for (int c = 1; c < 8; c++) lbj = j == c ? lb[c] : lbj;
@@ -213,6 +216,7 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
                 // yet (a good first descent is all its pruning); lanes that came with one prune by it whatever the order
                 int f = __builtin_ctz(mask);
                 if (nearest_first || __builtin_amdgcn_ballot_w64(!(best < inf)) != 0ull) {
+                    if (STATS && walk_counts) walk_counts[2] += 1u;
                     float minb = inf;
 #pragma unroll
                     for (int j = 0; j < 8; j++) minb = ((mask >> j) & 1u) ? fminf(minb, lb[j]) : minb;
@@ -234,6 +238,7 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
                 // next pending child, deepest wide level first
                 have = pend != 0ull;
                 if (have) {
+                    if (STATS && walk_counts) walk_counts[3] += 1u;
                     const int w = (63 - __builtin_clzll(pend)) >> 3;
                     const unsigned int slot = (unsigned int)(pend >> (8 * w)) & 0xffu;
                     const int j = __builtin_ctz(slot);

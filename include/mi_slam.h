@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MI_SLAM_ABI_VERSION 3   /* 3: mi_icp_load_times, mi_cross_moments, mi_icp_auto_batch; 2: mi_cpd_params gained sigma2_mode; mi_dist_info, mi_source_share, mi_cpd_sigma_squared_mode, mi_profile_search_stats, mi_selftest_sort_pairs */
+#define MI_SLAM_ABI_VERSION 4   /* 4: mi_profile_search_phases, mi_runtime_info (additive: no signature of version 3 changed); 3: mi_icp_load_times, mi_cross_moments, mi_icp_auto_batch; 2: mi_cpd_params gained sigma2_mode; mi_dist_info, mi_source_share, mi_cpd_sigma_squared_mode, mi_profile_search_stats, mi_selftest_sort_pairs */
 
 enum {
     MI_OK = 0,
@@ -450,6 +450,14 @@ int mi_icp_load_times(mi_ctx* ctx, double out_ms[MI_LOAD_STAGES]);
  * maximum, not a sum).
  * enable != 0 starts counting (and zeroes the counters), 0 stops; out may be NULL.  Costs four atomics per moving point while on. */
 int mi_profile_search_stats(mi_ctx* ctx, int enable, unsigned long long out[8]);
+/* The same counting build's LOOP TRIP COUNTS since counting was switched on (call it BEFORE mi_profile_search_stats(ctx, 0, ..) switches it off), summed over
+ * waves -- what tools/isa_budget.py multiplies the kernel's static per-phase instruction counts by (the measured instruction budget of DESIGN section 4):
+ * out[0] waves, [1] waves that ran the grid scan, [2] walk-only waves; of the scanning waves: [3] nearest-block batches, [4] of them with their trips dealt
+ * over the wave, [5] deal passes, [6] iterations of the deal's write loop, [7] lockstep trips; [8] rounds of leftover rows dealt out, [9] of them with their
+ * trips dealt, [10] deal passes, [11] write-loop iterations, [12] lockstep trips, [13] leftover batches of the four-rows-per-lane form, [14] waves that had
+ * leftover rows; of the walking waves: [15] leaves whose sequential offers ran, [16] leaf children looked at, [17] votes for the nearest child, [18] pops of a
+ * pending child; [19] reserved (0).  Measurement hook: no reference counterpart. */
+int mi_profile_search_phases(mi_ctx* ctx, unsigned long long out[20]);
 /* Self-test of the library's own device radix sort (the Hilbert ordering of the index build): sorts the n (key, value) pairs in
  * place, stable, ascending by the low `bits` (10, 20 or 30) of the keys.  Host arrays; test use only. */
 int mi_selftest_sort_pairs(mi_ctx* ctx, unsigned int* keys, int* values, int n, int bits);

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(capi):
     missing = [n for n in names if not hasattr(lib, n)]
     assert missing == []
     assert sorted(capi.EXPORTS) == names          # the binding's list is the header's list
-    assert lib.mi_abi_version() == 3
+    assert lib.mi_abi_version() == 4
 
 
 def test_struct_layouts_match_header(capi):

@@ -156,6 +156,8 @@ trace.sort(key=lambda r: int(r["Start_Timestamp"]))
 by_kernel_grid = {}
 for r in trace:
     by_kernel_grid.setdefault((r["Kernel_Name"], grid_of_trace(r)), []).append(r)
+noop_launches = {k: len(rs) - len(live(rs)) for k, rs in by_kernel_grid.items()}
+by_kernel_grid = {k: live(rs) for k, rs in by_kernel_grid.items()}
 # per kernel: its grid sizes in ascending order of work; the workloads in ascending order of pairs -- the k-th largest grid that carries more than a
 # handful of launches belongs to the k-th largest workload (tiny grids: primitives called on small inputs, e.g. a self-test -- listed under "other")
 grids_of = {}
@@ -168,8 +170,31 @@ for kn, gl in grids_of.items():
         assign[(kn, g)] = wl[0]
 
 
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if v else 0
+
+
+def dur(r):
+    return int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+
+
+def live(rs):
+    """Without the NO-OP launches: a registration's iterations are enqueued in batches, and what is still in the queue when the device-side stop rule
+    fires returns at the `done` flag (3-4 us, same grid).  They are launches of the kernel, not E-steps: a dispatch counts if it lasts at least half
+    the median of its (kernel, grid) group."""
+    m = median([dur(r) for r in rs])
+    return [r for r in rs if 2 * dur(r) >= m]
+
+
 def counter_rows_of(d, kn, grid):
-    return [r for r in rows(d, "counter_collection.csv") if r["Kernel_Name"] == kn and int(r["Grid_Size"]) == grid]
+    rs = [r for r in rows(d, "counter_collection.csv") if r["Kernel_Name"] == kn and int(r["Grid_Size"]) == grid]
+    # (one row per counter and dispatch, each with the dispatch's own timestamps under that pass: the same rule, per pass)
+    per_dispatch = {}
+    for r in rs:
+        per_dispatch.setdefault(r["Dispatch_Id"], r)
+    keep = {r["Dispatch_Id"] for r in live(list(per_dispatch.values()))}
+    return [r for r in rs if r["Dispatch_Id"] in keep]
 
 
 def counter_mean(d, counter, kn, grid):
@@ -179,8 +204,8 @@ def counter_mean(d, counter, kn, grid):
 
 cpd = {"kernel": "cpd_estep", "steps": None, "warmup": None, "git_head": head,
        "command": doc["command"].split(";")[0] + " (its cpd_bunny leg: exact P on the bunny clouds and at the reference's published size)",
-       "selection": "per kernel, the dispatches whose grid is the workload's (the grid is a function of (n, m) alone); means over ALL such dispatches of the "
-                    "process; the rows themselves: " + R + "_cpd_estep_timed_dispatches.csv",
+       "selection": "per kernel, the dispatches whose grid is the workload's (the grid is a function of (n, m) alone), without the no-op launches that return at a "
+                    "finished registration's `done` flag (shorter than half the group's median); means over ALL remaining dispatches of the process; the rows themselves: " + R + "_cpd_estep_timed_dispatches.csv",
        "workloads": {}, "other_dispatches": {}}
 with open(os.path.join(OUT, R + "_cpd_estep_timed_dispatches.csv"), "w", newline="") as f:
     w = csv.writer(f)
@@ -202,6 +227,7 @@ for wl, n_, m_ in CPD_WORKLOADS:
         t = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs]
         e["grid_work_items"] = g
         e["launches"] = len(t)
+        e["noop_launches_excluded"] = noop_launches.get((kn, g), 0)      # (returned at the registration's `done` flag: see live())
         e["launch_ms"] = mean(t) * 1e-6
         e["launch_ms_min_max"] = [min(t) * 1e-6, max(t) * 1e-6]
         e["counter_launches"] = len([r for r in counter_rows_of("sq1", kn, g) if r["Counter_Name"] == "SQ_INSTS_VALU"])
