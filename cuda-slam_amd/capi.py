@@ -496,7 +496,7 @@ class Context:
 
     SEARCH_PHASES = ("waves", "scan_waves", "walk_only_waves", "block_batches", "block_dealt", "block_deal_passes", "block_deal_writes", "block_lockstep_trips",
                      "rest_rounds", "rest_dealt", "rest_deal_passes", "rest_deal_writes", "rest_lockstep_trips", "rest_batches4", "rest_waves",
-                     "walk_leaf_offers", "walk_leaf_children", "walk_votes", "walk_pops")
+                     "walk_leaf_hits", "walk_leaf_children", "walk_votes", "walk_pops", "walk_leaf_offers")
 
     def search_phases(self):
         """Loop trip counts of the counting build since search_stats(True), summed over waves (mi_profile_search_phases) -> dict."""

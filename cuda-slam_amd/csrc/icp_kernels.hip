@@ -94,11 +94,10 @@ __global__ __launch_bounds__(256) void pack_keys_kernel(const int* __restrict__ 
 __global__ __launch_bounds__(ICP_ROW_POINTS) void icp_moments_rows_kernel(IcpView v, double* __restrict__ rows)
 {
     if (v.state->done != 0) return;
-    __shared__ double lds[ICP_ROW_WAVES * 16];
-    double mom[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) mom[k] = 0.0;
     const int i = blockIdx.x * ICP_ROW_POINTS + threadIdx.x;
+    bool use = false;
+    float bx = 0.f, by = 0.f, bz = 0.f;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < v.n) {
         const unsigned long long key = v.keys[i];
         const int gidx = (int)(unsigned int)(key & 0xffffffffull);
@@ -106,11 +105,12 @@ __global__ __launch_bounds__(ICP_ROW_POINTS) void icp_moments_rows_kernel(IcpVie
         const bool mine = gidx >= v.shard_lo && gidx < v.shard_hi;
         const bool kept = v.filter_pairs ? (d2 < v.max_distance_squared) : true;
         if (mine && kept) {
-            const float4 a = v.tgt4[gidx - v.shard_lo];
-            pair_moments(mom, v.cx[i], v.cy[i], v.cz[i], a.x, a.y, a.z);
+            a = v.tgt4[gidx - v.shard_lo];
+            bx = v.cx[i]; by = v.cy[i]; bz = v.cz[i];
+            use = true;
         }
     }
-    row_store_moments(mom, rows + (size_t)blockIdx.x * ICP_ROW, lds);
+    row_store_pair_moments(use, bx, by, bz, a.x, a.y, a.z, rows + (size_t)blockIdx.x * ICP_ROW);     // (the one producer of moments rows: icp_rows.hpp)
 }
 
 // rows [first, first + count) of ICP_ROW doubles -> out[blockIdx.x] : workgroup g sums its contiguous slice of rows in index
@@ -285,13 +285,12 @@ __device__ void apply_solve(IcpState* __restrict__ state, const double* mom, int
 __global__ __launch_bounds__(ICP_ROW_POINTS) void icp_transform_error_rows_kernel(IcpView v, double* __restrict__ rows, int rearm)
 {
     if (v.state->done != 0) return;
-    __shared__ double lds[ICP_ROW_WAVES * 2];
     float R[9], t[3];
 #pragma unroll
     for (int i = 0; i < 9; i++) R[i] = v.state->R[i];
 #pragma unroll
     for (int i = 0; i < 3; i++) t[i] = v.state->t[i];
-    double e0 = 0.0, e1 = 0.0;
+    float e0 = 0.f, e1 = 0.f;
     const int i = blockIdx.x * ICP_ROW_POINTS + threadIdx.x;
     if (i < v.n_pad) {
         const float x = v.bx[i], y = v.by[i], z = v.bz[i];
@@ -313,8 +312,8 @@ __global__ __launch_bounds__(ICP_ROW_POINTS) void icp_transform_error_rows_kerne
                 const float dx = a.x - ox, dy = a.y - oy, dz = a.z - oz;
                 const float e = (dx * dx + dy * dy) + dz * dz;       // diff.LengthSquared(), common.cpp:264-265
                 if (kept) {
-                    e0 = (double)e;
-                    e1 = 1.0;
+                    e0 = e;
+                    e1 = 1.f;
                     resid = e;
                 }
                 // The old match under the new transform is a real candidate of the next search, evaluated with the
@@ -327,7 +326,7 @@ __global__ __launch_bounds__(ICP_ROW_POINTS) void icp_transform_error_rows_kerne
             if (v.resid != nullptr) v.resid[i] = resid;
         }
     }
-    row_store_error(e0, e1, rows + (size_t)blockIdx.x * ICP_ROW, lds);
+    row_store_error(e0, e1, rows + (size_t)blockIdx.x * ICP_ROW);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -515,7 +514,7 @@ __global__ __launch_bounds__(256) void icp_schedule_reset_kernel(IcpSchedule sch
 
 hipError_t icp_schedule_reset(const IcpSchedule& sched, int nrows, hipStream_t s)
 {
-    hipLaunchKernelGGL(icp_schedule_reset_kernel, dim3((nrows + 255) / 256), dim3(256), 0, s, sched, nrows);
+    hipLaunchKernelGGL(icp_schedule_reset_kernel, dim3((nrows + 255) / 256 > 0 ? (nrows + 255) / 256 : 1), dim3(256), 0, s, sched, nrows);
     return hipGetLastError();
 }
 

@@ -616,9 +616,8 @@ extern "C" int mi_profile_search_phases(mi_ctx* c, unsigned long long out[20])
     if (!c->nn_stats_on) { set_error("mi_profile_search_phases: counting is off (mi_profile_search_stats(ctx, 1, NULL) first)"); return MI_ERR_STATE; }
     unsigned long long sum[GRID_STATS_COLS];
     MI_TRY(search_counters(c, sum));
-    static_assert(GRID_STATS_COLS >= 8 + 19, "phases: 19 counters behind the 8 of mi_profile_search_stats");
-    for (int i = 0; i < 19; i++) out[i] = sum[8 + i];
-    out[19] = 0;
+    static_assert(GRID_STATS_COLS >= 8 + 20, "phases: 20 counters behind the 8 of mi_profile_search_stats");
+    for (int i = 0; i < 20; i++) out[i] = sum[8 + i];
     return MI_OK;
 }
 

@@ -896,7 +896,7 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
     static_assert(GRID_BLOCK == 64 && ICP_ROW_POINTS == 64, "one wave = one workgroup = one row of partial sums");
     static_assert(WAVES == 1 || (WAVES == 2 && FUSED && !STATS), "the helper wave exists for fused iterations only");
     if (FUSED) {
-        if (a.state->done != 0) return;
+        if (as_constant(&a.state->done)[0] != 0) return;
     } else if (a.done_flag != nullptr && *a.done_flag != 0) return;
     const int tid = (int)threadIdx.x & 63;
     const int helper = WAVES == 2 ? (int)threadIdx.x >> 6 : 0;         // 1: the second wave of the workgroup
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
 #define MI_TL_STAMP(var, dep) do { } while (0)
 #endif
     unsigned int chunk = xcd_chunk(blockIdx.x, gridDim.x, MISLAM_GRID_XCD_RUN);
-    if (FUSED) chunk = (unsigned int)a.order[chunk];          // walking chunks first (IcpSchedule): speed only
+    if (FUSED) chunk = (unsigned int)as_constant(a.order)[chunk];          // walking chunks first (IcpSchedule): speed only (read-only for the launch: a scalar load, nn_walk.hpp as_constant)
     if (WAVES == 2 && helper != 0) {
         // a helper with nothing to help with leaves before it has loaded anything else (three chunks in four, late in a registration)
         const unsigned int fc = a.far[chunk];
@@ -938,9 +938,9 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
     if (FUSED) {
         float R[9], tr[3];
 #pragma unroll
-        for (int k = 0; k < 9; k++) R[k] = a.state->R[k];
+        for (int k = 0; k < 9; k++) R[k] = as_constant(a.state->R)[k];
 #pragma unroll
-        for (int k = 0; k < 3; k++) tr[k] = a.state->t[k];
+        for (int k = 0; k < 3; k++) tr[k] = as_constant(a.state->t)[k];
         bool kept_lane = false;
         if (valid) {
             const float x = a.bx[i], y = a.by[i], z = a.bz[i];
@@ -996,7 +996,7 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
     // the first iterations of a registration move the cloud by many cells: the starting candidates (previous matches) are STALE, and a walk
     // that enters the children in index order meets the true neighbourhood late; there the nearest child goes first (a lane vote per step) -- and
     // the scan reaches farther for queries outside the grid's extent (grid_lane_cap2), as it does for a plain search, which has no candidates at all
-    const bool cold = FUSED && a.state->passes < GRID_COLD_PASSES;
+    const bool cold = FUSED && as_constant(&a.state->passes)[0] < GRID_COLD_PASSES;
     constexpr bool extend_reach = !FUSED || EXTEND;
     const bool halves = WAVES == 2 && a.split_walks != 2;                  // a chunk that walks at once: half the lanes per wave
     if (walk_only) hard = valid && (!halves || (tid >> 5) == helper);
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
 #ifdef MISLAM_DEV_WAVE_TIMELINE
     tl_scan = wall_clock64();
 #endif
-    unsigned int walk_counts[4] = {0u, 0u, 0u, 0u};
+    unsigned int walk_counts[5] = {0u, 0u, 0u, 0u, 0u};
     if (hard) tree_walk_wide<FMA, STATS>(t, q, best, bidx, n_nodes, n_leaves, cold, STATS ? walk_counts : nullptr);
     if (WAVES == 2 && (walk_only ? halves : predicted != 0ull)) {       // (workgroup-uniform: both waves are here)
         __shared__ float x_best[64];
@@ -1073,24 +1073,25 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
         }
         {
             // the walk's other loops (wave-uniform trip counts; the walking lanes agree, the others hold 0): a maximum over the wave, then one atomic each
-            unsigned int w0 = hard ? walk_counts[0] : 0u, w1 = hard ? walk_counts[1] : 0u, w2 = hard ? walk_counts[2] : 0u, w3 = hard ? walk_counts[3] : 0u;
+            unsigned int w0 = hard ? walk_counts[0] : 0u, w1 = hard ? walk_counts[1] : 0u, w2 = hard ? walk_counts[2] : 0u, w3 = hard ? walk_counts[3] : 0u, w4 = hard ? walk_counts[4] : 0u;
 #pragma unroll
             for (int m = 32; m > 0; m >>= 1) {
                 w0 = max(w0, (unsigned int)__shfl_xor(w0, m, 64)); w1 = max(w1, (unsigned int)__shfl_xor(w1, m, 64));
                 w2 = max(w2, (unsigned int)__shfl_xor(w2, m, 64)); w3 = max(w3, (unsigned int)__shfl_xor(w3, m, 64));
+                w4 = max(w4, (unsigned int)__shfl_xor(w4, m, 64));
             }
             if (tid == 0 && walked) {
                 atomicAdd(&srow[23], (unsigned long long)w0);
                 atomicAdd(&srow[24], (unsigned long long)w1);
                 atomicAdd(&srow[25], (unsigned long long)w2);
                 atomicAdd(&srow[26], (unsigned long long)w3);
+                atomicAdd(&srow[27], (unsigned long long)w4);
             }
         }
     }
     if (FUSED) {
-        double mom[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) mom[k] = 0.0;
+        bool use_pair = false;
+        float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid && best < __builtin_inff()) {
             const int gidx = (int)bidx;
             const bool mine = gidx >= a.shard_lo && gidx < a.shard_hi;
@@ -1098,15 +1099,13 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
             if (hard) bslot = g.slot_of[gidx - g.index_base];   // a walk's winner: the hierarchy keeps its own order
             a.match_slot[io] = bslot;
             if (mine && kept) {
-                const float4 p = g.pts[bslot];
-                pair_moments(mom, q[0], q[1], q[2], p.x, p.y, p.z);
+                pm = g.pts[bslot];
+                use_pair = true;
             }
         } else if (valid) a.match_slot[io] = ~0u;
         double* row = a.rows + (size_t)chunk * ICP_ROW;
-        row_store_moments(mom, row, nullptr);
-        float e_row = e_prev;
-        asm("" : "+v"(e_row));                                 // (the conversion HERE: hoisted to the prologue the double would take two registers across the search)
-        row_store_error((double)e_row, ((kept_prev >> tid) & 1ull) != 0ull ? 1.0 : 0.0, row, nullptr);
+        row_store_pair_moments(use_pair, q[0], q[1], q[2], pm.x, pm.y, pm.z, row);      // (four fp64 matrix-pipe products: icp_rows.hpp)
+        row_store_error(e_prev, ((kept_prev >> tid) & 1ull) != 0ull ? 1.f : 0.f, row);      // (fp32 in: the conversions happen inside, next to the products)
         {
             // next iteration's class of this chunk: 0 = no lane walked, 1 = some did, 2 = most lanes lie beyond the grid's reach
             // (this lane's reach under the rule the NEXT search will apply: the class is a prediction for it)
@@ -1114,7 +1113,11 @@ __global__ __launch_bounds__(GRID_BLOCK * WAVES) MI_GRID_OCC void nn_grid_kernel
             // no scalar instruction to compute it -- otherwise sits in a vector register from the scan to here, across the whole search)
             NnGridView ge = g;
             asm("" : "+s"(ge.h_lo));
-            const float cap2 = grid_lane_cap2(ge, q, !FUSED || a.extend_reach_next != 0);
+            // (the next search's rule: with the extended reach a function of the lane's position outside the extent -- some forty instructions --, without it
+            // ONE number for the whole wave; which of the two is a launch argument, so the warm kernel branches around the arithmetic)
+            float cap2;
+            if (!FUSED || a.extend_reach_next != 0) cap2 = grid_lane_cap2(ge, q, true);
+            else { float gs0[3]; cap2 = grid_lane_cap2(ge, 0.f, 0.f, 0.f, gs0, false); }
             const int beyond = (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && !(best <= cap2)));
             if (tid == 0) a.far[chunk] = beyond >= GRID_WALK_ONLY_MIN ? 2 : (walked ? 1 : 0);
             // (the helper wave's share next time: the lanes the scan cannot serve -- NOT "the lanes that walked", which would keep every lane
@@ -1133,9 +1136,10 @@ const char* nn_grid_kernel_name(bool) { return "nn_grid_kernel"; }
 hipError_t nn_grid_query(const NnGridView& g, const NnTreeView& t, const GridSearchArgs& a, int fma, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
     if (a.n <= 0) return hipSuccess;
-    const dim3 grid((a.n + GRID_BLOCK - 1) / GRID_BLOCK), block(GRID_BLOCK);
+    const int n_chunks = (a.n + GRID_BLOCK - 1) / GRID_BLOCK;
     const bool fused = a.state != nullptr;
     const bool helped = fused && a.stats == nullptr && a.split_walks != 0 && a.far_lanes != nullptr;   // two waves per workgroup (nn_grid_kernel<.., 2>)
+    const dim3 grid(n_chunks), block(GRID_BLOCK);
     if (fused && (a.order == nullptr || a.far == nullptr || a.rows == nullptr || a.match_slot == nullptr)) return hipErrorInvalidValue;   // (the fused kernel does not test for them)
     const bool timed = e0 != nullptr && e1 != nullptr;
     const bool ext = !fused || a.extend_reach != 0;

@@ -18,6 +18,16 @@
 
 namespace mislam {
 
+// A pointer into memory this kernel never writes, in the CONSTANT address space: a wave-uniform load through it is a scalar load whatever the compiler can
+// or cannot prove about the kernel's own stores and atomics.  (Round 6: a persistent form of the search that draws its chunks off a global counter was
+// built and measured -- ONE atomic in the kernel made the compiler give up the scalar form of every uniform load behind it, hierarchy boxes, leaf points,
+// the state: 38 of 55; through this address space they stay scalar by construction.  The persistent form itself lost 30 % and is gone, DESIGN section 4
+// K1g; the arrays in question are read-only for the launch, which is all the constant address space asserts, so the walk keeps it.)
+template <class T> using cptr = const T __attribute__((address_space(4)))*;
+template <class T> __device__ __forceinline__ cptr<T> as_constant(const T* p) { return (cptr<T>)(unsigned long long)p; }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 template <bool FMA>
 __device__ __forceinline__ float sq3(float dx, float dy, float dz)
 {
@@ -76,8 +86,8 @@ __device__ __forceinline__ void unpack_start(unsigned long long k0, float& best,
 // unchanged: a lane's true neighbour lies in a child that lane needs at every step, needed children are never dropped, skipped
 // ones have a bound strictly above that lane's best.  Call with any subset of a wave's lanes active.
 // b: the node's lo.x in NnTreeView::boxes6 (siblings interleaved: its other components follow two floats apart)
-template <bool FMA>
-__device__ __forceinline__ float box6_bound(const float* __restrict__ b, const float s[3])
+template <bool FMA, class P>
+__device__ __forceinline__ float box6_bound(P b, const float s[3])
 {
     const float ex = fmaxf(fmaxf(b[0] - s[0], s[0] - b[6]), 0.f);
     const float ey = fmaxf(fmaxf(b[2] - s[1], s[1] - b[8]), 0.f);
@@ -89,8 +99,8 @@ __device__ __forceinline__ float box6_bound(const float* __restrict__ b, const f
 // and the sums as packed fp32 operations (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 -- the same IEEE operations as the single ones, two
 // results per issue slot), the pair's components coming straight out of the scalar loads as register pairs
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <bool FMA>
-__device__ __forceinline__ f32x2 box6_bound2(const float* __restrict__ pr, const float s[3])
+template <bool FMA, class P>
+__device__ __forceinline__ f32x2 box6_bound2(P pr, const float s[3])
 {
     const f32x2 sx = {s[0], s[0]}, sy = {s[1], s[1]}, sz = {s[2], s[2]};
     const f32x2 ax = (f32x2){pr[0], pr[1]} - sx, bx = sx - (f32x2){pr[6], pr[7]};
@@ -107,12 +117,13 @@ __device__ __forceinline__ f32x2 box6_bound2(const float* __restrict__ pr, const
 template <bool FMA, bool STATS>
 __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float p[3], float& best, unsigned int& bidx,
                                                unsigned int& n_nodes, unsigned int& n_leaves, bool nearest_first = false,
-                                               unsigned int* walk_counts = nullptr     // (STATS) [0] leaves whose offers ran, [1] leaf children looked at, [2] votes for the nearest child, [3] pops
+                                               unsigned int* walk_counts = nullptr     // (STATS) [0] leaves with a candidate at or below some lane's best, [1] leaf children looked at, [2] votes for the nearest child, [3] pops, [4] leaves whose sequential offers ran
                                                )
 {
-    const float* __restrict__ boxes6 = t.boxes6;
-    const float4* __restrict__ leaf_soa = t.leaf_soa;
-    const int* __restrict__ leaf_idx = t.leaf_idx;
+    const cptr<float> boxes6 = as_constant(t.boxes6);
+    const cptr<f32x4> leaf_soa = as_constant(reinterpret_cast<const f32x4*>(t.leaf_soa));
+    const int* __restrict__ leaf_idx = t.leaf_idx;               // (per-lane gathers: the offers' tie rule, the winner's index at the end)
+    const cptr<int> leaf_idx_c = as_constant(t.leaf_idx);        // (a leaf's eight indices at once: wave-uniform)
     const int H = t.height, first_leaf = t.n_pad - 1, real_leaves = t.n_leaves;
     const float inf = __builtin_inff();
     int bslot = -1;                                            // >= 0: the winner's sorted slot; < 0: bidx is the winner
@@ -122,7 +133,7 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
         best = lt ? d : best;
         bslot = lt ? s : bslot;
         if (tie) {
-            const unsigned int j = (unsigned int)leaf_idx[s];
+            const unsigned int j = (unsigned int)leaf_idx_c[s];   // (s is wave-uniform: a scalar load)
             const unsigned int jb = bslot >= 0 ? (unsigned int)leaf_idx[bslot] : bidx;
             if (j < jb) bslot = s;
         }
@@ -133,12 +144,12 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
     auto scan_leaf = [&](int leaf) {                            // leaf is wave-uniform: its points arrive through scalar loads
         if (STATS) n_leaves += 1;
         const int slot0 = leaf * TREE_LEAF;
-        const float4* __restrict__ lp = leaf_soa + (size_t)leaf * (3 * TREE_LEAF / 4);
+        const cptr<f32x4> lp = leaf_soa + (size_t)leaf * (3 * TREE_LEAF / 4);
         f32x2 d[TREE_LEAF / 2];
         float m = inf;
 #pragma unroll
         for (int c4 = 0; c4 < TREE_LEAF / 4; c4++) {
-            const float4 X = lp[c4], Y = lp[TREE_LEAF / 4 + c4], Z = lp[2 * (TREE_LEAF / 4) + c4];
+            const f32x4 X = lp[c4], Y = lp[TREE_LEAF / 4 + c4], Z = lp[2 * (TREE_LEAF / 4) + c4];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 f32x2 dx, dy, dz;
@@ -154,6 +165,42 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
         }
         if (__builtin_amdgcn_ballot_w64(m <= best) == 0ull) return;
         if (STATS && walk_counts) walk_counts[0] += 1u;
+        // Round 6: half the leaves a warm walk scans get this far (profiles/r06_search_budget.md), and the sixteen-way select chain of the
+        // sequential offers below was a fifth of a walking wave's instructions.  The offers only matter where an INDEX decides between two
+        // points of THIS walk: a lane that meets its leaf minimum twice, or ties a best it found in an earlier leaf.  Everywhere else the
+        // outcome of the eight offers is "the leaf's minimum, if it is lexicographically smaller than (best, bidx)" -- the one slot that holds
+        // m, its global index from the leaf's eight (a scalar load: the leaf is wave-uniform), whatever the intermediate steps did.  The
+        // commonest tie by far is a lane meeting its own STARTING candidate again (the previous match is a point of this tree): equal
+        // index, nothing changes.
+        {
+            int km = 0;
+            unsigned int cnt = 0u;
+#pragma unroll
+            for (int k = TREE_LEAF - 1; k >= 0; k--) {
+                const float dk = (k & 1) ? d[k >> 1].y : d[k >> 1].x;
+                const bool e = dk == m;
+                km = e ? k : km;
+                cnt += e ? 1u : 0u;
+            }
+            const bool tie = m == best;
+            if (__builtin_amdgcn_ballot_w64(cnt > 1u || (tie && bslot >= 0)) == 0ull) {
+                bool take = m < best;
+                if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {
+                    static_assert(TREE_LEAF == 8, "a leaf's indices are two 16-byte scalar loads");
+                    const cptr<i32x4> ip = (cptr<i32x4>)(leaf_idx_c + slot0);
+                    const i32x4 I0 = ip[0], I1 = ip[1];
+                    const int idx8[8] = {I0.x, I0.y, I0.z, I0.w, I1.x, I1.y, I1.z, I1.w};
+                    int j = idx8[0];
+#pragma unroll
+                    for (int k = 1; k < TREE_LEAF; k++) j = km == k ? idx8[k] : j;
+                    take = take || (tie && (unsigned int)j < bidx);      // (bslot < 0 here: bidx is the running winner's index)
+                }
+                best = take ? m : best;
+                bslot = take ? slot0 + km : bslot;
+                return;
+            }
+        }
+        if (STATS && walk_counts) walk_counts[4] += 1u;
 #pragma unroll
         for (int k = 0; k < TREE_LEAF / 2; k++) {
             offer(d[k].x, slot0 + 2 * k);
@@ -161,7 +208,7 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
         }
     };
     {
-        const float root_lb = box6_bound<FMA>(boxes6 + tree_box_offset(0), p);
+        const float root_lb = box6_bound<FMA, cptr<float>>(boxes6 + tree_box_offset(0), p);
         if (__builtin_amdgcn_ballot_w64(root_lb <= best && root_lb < inf) == 0ull) return;
     }
     if (H == 0) {
@@ -177,13 +224,13 @@ __device__ __forceinline__ void tree_walk_wide(const NnTreeView& t, const float 
             const int base = ((un + 1) << k) - 1;                   // first of the 2^k descendants k levels down
             const int clevel = level + k;
             if (STATS) n_nodes += 1;
-            const float* __restrict__ bp = boxes6 + (size_t)((base + 1) >> 1) * 12;   // base is odd: the first of a pair of siblings
+            const cptr<float> bp = boxes6 + (size_t)((base + 1) >> 1) * 12;   // base is odd: the first of a pair of siblings
             float lb[8];
             unsigned int mask = 0u;
             // (a root step of fewer than three levels reads boxes past its children: masked off below)
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
-                const f32x2 b2 = box6_bound2<FMA>(bp + 6 * j, p);
+                const f32x2 b2 = box6_bound2<FMA, cptr<float>>(bp + 6 * j, p);
                 lb[j] = b2.x;
                 lb[j + 1] = b2.y;
                 if (__builtin_amdgcn_ballot_w64(lb[j] <= best) != 0ull) mask |= 1u << j;

@@ -455,8 +455,8 @@ int mi_profile_search_stats(mi_ctx* ctx, int enable, unsigned long long out[8]);
  * out[0] waves, [1] waves that ran the grid scan, [2] walk-only waves; of the scanning waves: [3] nearest-block batches, [4] of them with their trips dealt
  * over the wave, [5] deal passes, [6] iterations of the deal's write loop, [7] lockstep trips; [8] rounds of leftover rows dealt out, [9] of them with their
  * trips dealt, [10] deal passes, [11] write-loop iterations, [12] lockstep trips, [13] leftover batches of the four-rows-per-lane form, [14] waves that had
- * leftover rows; of the walking waves: [15] leaves whose sequential offers ran, [16] leaf children looked at, [17] votes for the nearest child, [18] pops of a
- * pending child; [19] reserved (0).  Measurement hook: no reference counterpart. */
+ * leftover rows; of the walking waves: [15] leaves that held a candidate at or below some lane's best, [16] leaf children looked at, [17] votes for the nearest
+ * child, [18] pops of a pending child, [19] leaves whose sequential (index-settling) offers ran.  Measurement hook: no reference counterpart. */
 int mi_profile_search_phases(mi_ctx* ctx, unsigned long long out[20]);
 /* Self-test of the library's own device radix sort (the Hilbert ordering of the index build): sorts the n (key, value) pairs in
  * place, stable, ascending by the low `bits` (10, 20 or 30) of the keys.  Host arrays; test use only. */
