@@ -444,7 +444,15 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
     MI_TRY(fgt_side(c, f, &f->y, v.yx, v.yy, v.yz, w->m, K, &cy));
     MI_TRY(fgt_side(c, f, &f->a, v.ax, v.ay, v.az, w->n, K, &ca));
     MI_TRY(f->By.reserve((size_t)K * t.pd)); MI_TRY(f->Ba.reserve(4 * (size_t)K * t.pd));
-    const int Zy = c->tune.fgt_model_splits != 0 ? fgt_model_splits(w->m, K, t.pd) : 1, Za = c->tune.fgt_model_splits != 0 ? fgt_model_splits(w->n, K, t.pd) : 1;       // (big cells: a cell's members over several workgroups)
+    // (big cells: a cell's members over several workgroups -- unless the cloud is one whose cells list their own members, which is one workgroup per cell;
+    // decided from n, K and pd ALONE: ADVICE r05 found the fixed side taking the listing path on a re-clustering E-step and the split path on the others,
+    // two orders of the same sums, for clouds of at most 32 768 points in cells of 1 024 and more)
+    const auto splits = [&](int n_side) {
+        if (c->tune.fgt_model_splits == 0) return 1;
+        if (c->tune.fgt_lists_in_model != 0 && fgt_lists_rule(n_side, K)) return 1;
+        return fgt_model_splits(n_side, K, t.pd);
+    };
+    const int Zy = splits(w->m), Za = splits(w->n);
     if (Zy > 1) MI_TRY(f->By_part.reserve((size_t)Zy * K * t.pd));
     if (Za > 1) MI_TRY(f->Ba_part.reserve(4 * (size_t)Za * K * t.pd));
     const int Sa = fgt_predict_splits(w->n, K), Sy = fgt_predict_splits(w->m, K);

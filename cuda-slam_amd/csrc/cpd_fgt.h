@@ -64,6 +64,10 @@ hipError_t fgt_cluster(const FgtClusters& c, void* sort_temp, size_t sort_temp_b
 // workgroups each, their partial sums added in z order (the means, if asked for, in a launch of their own).
 constexpr int FGT_MODEL_MAX_SPLITS = 16;
 int fgt_model_splits(int n, int K, int pd);
+// whether a cloud of n points in K cells is small enough for the model build to list every cell's members itself (FgtClusters::lists_in_model): a cloud that
+// is takes ONE workgroup per cell on every E-step -- the caller passes Z = 1 for it whether or not this E-step re-clusters (the path, and with it
+// the order of a cell's sums, must follow from n, K and pd alone)
+bool fgt_lists_rule(int n, int K);
 hipError_t fgt_model(const FgtClusters& c, const float4* w4, float sigma, const FgtTables& t, float* B, hipStream_t s, bool centers = false,
                      float* part = nullptr, int Z = 1);
 // v[split][w][i] = sum_{k in split} [ |dy|^2 <= e ] exp(-|dy|^2) sum_alpha B[k][alpha][w] dy^alpha, dy = (q_i - xc_k) / sigma

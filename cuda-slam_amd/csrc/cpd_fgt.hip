@@ -625,9 +625,14 @@ constexpr int FGT_MODEL_GROUPS = 4;
 // by a ballot prefix.  The same off / memb as the three sort launches leave (every workgroup of the cell writes the same words), without the launches.
 constexpr int FGT_LISTS_IN_MODEL_MAX_POINTS = 32768;
 constexpr long long FGT_LISTS_IN_MODEL_MAX_READS = 4ll << 20;    // K workgroups read n labels each: beyond this the counting sort's O(n) wins (bunny: K <= 281)
+// the size rule alone (n and K: what the host needs to keep the build's PATH a function of the problem, not of which E-step it is)
+bool fgt_lists_rule(int n, int K)
+{
+    return n <= FGT_LISTS_IN_MODEL_MAX_POINTS && (long long)K * n <= FGT_LISTS_IN_MODEL_MAX_READS;
+}
 static bool lists_in_model(const FgtClusters& c)
 {
-    return c.lists_in_model && c.centers_in_model && c.n <= FGT_LISTS_IN_MODEL_MAX_POINTS && (long long)c.K * c.n <= FGT_LISTS_IN_MODEL_MAX_READS;
+    return c.lists_in_model && c.centers_in_model && fgt_lists_rule(c.n, c.K);
 }
 template <int W, bool CENTERS, bool LISTS>
 __global__ __launch_bounds__(FGT_TILE * FGT_MODEL_GROUPS) void fgt_model_kernel(FgtClusters c, const float4* __restrict__ w4, float inv_sigma, FgtTables t,

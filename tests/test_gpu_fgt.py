@@ -421,6 +421,24 @@ def _resumed_clustering_changes_nothing(ctx, fresh, capi, golden, bunny):
     assert a[3] == b[3] == 24 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[4] == b[4]
 
 
+def test_few_moving_points_against_many_fixed_ones_resume_changes_no_bit(ctx, capi, monkeypatch):
+    # 24 moving points against 32 768 fixed ones is K <= 24 cells of 1 000+ members on the fixed side -- big enough for the model build's
+    # split over workgroups (Z > 1), small enough for the cells to list their own members (one workgroup per cell).  Which of the two ran used to depend
+    # on whether THAT E-step re-clustered the fixed cloud (two orders of the same sums: bits that moved between iterations and between RESUME on / off);
+    # now it follows from n, K and pd alone.
+    rng = np.random.default_rng(12)
+    a = (rng.normal(size=(32768, 3)) * np.array([1.5, 1.0, 0.6])).astype(np.float32)
+    b = (a[rng.permutation(32768)[:24]] + rng.normal(scale=0.02, size=(24, 3)) + np.array([0.1, -0.05, 0.08])).astype(np.float32)
+    monkeypatch.setenv("MISLAM_FGT_RESUME", "0")       # read at context creation
+    with capi.Context(0) as fresh:
+        for approx in (capi.CPD_APPROX_FULL, capi.CPD_APPROX_HYBRID):
+            p = capi.cpd_params(max_iterations=6, tolerance=0.0, approximation=approx)
+            r1, r2 = ctx.cpd_register(b, a, p), fresh.cpd_register(b, a, p)
+            assert r1[3] == r2[3] and np.array_equal(r1[0], r2[0], equal_nan=True) and np.array_equal(r1[1], r2[1], equal_nan=True), approx
+            r3 = ctx.cpd_register(b, a, p)                      # ... and a second run on the resumed context
+            assert np.array_equal(r1[0], r3[0], equal_nan=True) and np.array_equal(r1[1], r3[1], equal_nan=True)
+
+
 def test_large_cloud_sweep_and_its_resume(ctx, capi, oracle, monkeypatch):
     # above 65 536 points the sweep runs one grid-wide launch per centre; the fixed cloud's sweep is still resumed as K grows
     rng = np.random.default_rng(4)

@@ -92,5 +92,56 @@ def main():
                                                                               ("LOOP->" + back[0]) if back else "", top))
 
 
+def compose(path, spec_path, counts_path, measured_valu_per_wave=None):
+    """The measured budget: static counts of the spec's phases (block index ranges of THIS build) x the counting build's trip counts."""
+    import json
+    spec = json.load(open(spec_path))
+    cnt = json.load(open(counts_path))
+    blocks = parse(path, spec["kernel"])
+    static_total = sum(1 for _, ins in blocks for op, *_ in ins if classify(op) == "valu")
+    if static_total != spec["static_valu_total"]:
+        sys.exit("the spec speaks for a kernel of %d static vector instructions, this one has %d: map its blocks again (--blocks)" % (spec["static_valu_total"], static_total))
+    L = float(cnt["launches"])
+    ph, st = cnt["phases"], cnt["stats"]
+    env = {"W": ph["waves"] / L, "S": ph["scan_waves"] / L, "WW": st["walking_waves"] / L,
+           "Bb": ph["block_batches"] / L, "Bd": ph["block_dealt"] / L, "Bp": ph["block_deal_passes"] / L, "Bw": ph["block_deal_writes"] / L, "Bl": ph["block_lockstep_trips"] / L,
+           "Rw": ph["rest_waves"] / L, "Rr": ph["rest_rounds"] / L, "Rd": ph["rest_dealt"] / L, "Rp": ph["rest_deal_passes"] / L, "Rwr": ph["rest_deal_writes"] / L,
+           "Rl": ph["rest_lockstep_trips"] / L, "st": st["walk_steps"] / L, "lc": ph["walk_leaf_children"] / L, "lv": st["walk_leaves"] / L,
+           "lh": ph["walk_leaf_hits"] / L, "lo": ph["walk_leaf_offers"] / L}
+    per_block = []
+    for label, ins in blocks:
+        c = Counter(classify(op) for op, *_ in ins)
+        per_block.append((c["valu"], c["salu"] + c["sctl"], c["smem"] + c["vmem"] + c["lds"]))
+    rows = []
+    tot_v = tot_s = 0.0
+    for entry in spec["phases"]:
+        name, lo, hi, expr = entry[0], entry[1], entry[2], entry[3]
+        over = entry[4] if len(entry) > 4 else {}
+        mult = [eval(expr, {}, env)] * (hi - lo + 1)
+        for rng, e in over.items():
+            a, _, b = rng.partition("-")
+            for k in range(int(a), int(b or a) + 1):
+                mult[k - lo] = eval(e, {}, env)
+        sv = sum(per_block[k][0] for k in range(lo, hi + 1))
+        dv = sum(per_block[k][0] * max(mult[k - lo], 0.0) for k in range(lo, hi + 1))
+        ds = sum(per_block[k][1] * max(mult[k - lo], 0.0) for k in range(lo, hi + 1))
+        rows.append((name, sv, expr, dv, ds))
+        tot_v += dv
+        tot_s += ds
+    W = env["W"]
+    print("| phase | static VALU | runs per launch | VALU per launch | per wave (of %d) | share | SALU per wave |" % round(W))
+    print("|---|---|---|---|---|---|---|")
+    for name, sv, expr, dv, ds in rows:
+        print("| %s | %d | `%s` | %.3g | %.0f | %.1f %% | %.0f |" % (name, sv, expr, dv, dv / W, 100.0 * dv / tot_v, ds / W))
+    print("| **sum** | %d | | **%.4g** | **%.0f** | | %.0f |" % (static_total, tot_v, tot_v / W, tot_s / W))
+    if measured_valu_per_wave:
+        print("\nmeasured (SQ_INSTS_VALU / SQ_WAVES over the same 20 launches): %.0f per wave; the table's rows sum to %.0f = %.3f of it" % (measured_valu_per_wave, tot_v / W, tot_v / W / measured_valu_per_wave))
+    print("\ntrip counts per launch: " + ", ".join("%s %.0f" % kv for kv in sorted(env.items())))
+
+
 if __name__ == "__main__":
-    main()
+    if "--compose" in sys.argv:
+        k = sys.argv.index("--compose")
+        compose(sys.argv[1], sys.argv[k + 1], sys.argv[k + 2], float(sys.argv[k + 3]) if len(sys.argv) > k + 3 else None)
+    else:
+        main()

@@ -147,6 +147,23 @@ def exact_form(name):            # the `<.., true>` instantiations are the hybri
     return not short(name).rstrip().endswith("true>")
 
 
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if v else 0
+
+
+def dur(r):
+    return int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+
+
+def live(rs):
+    """Without the NO-OP launches: a registration's iterations are enqueued in batches, and what is still in the queue when the device-side stop rule
+    fires returns at the `done` flag (3-4 us, same grid).  They are launches of the kernel, not E-steps: a dispatch counts if it lasts at least half
+    the median of its (kernel, grid) group."""
+    m = median([dur(r) for r in rs])
+    return [r for r in rs if 2 * dur(r) >= m]
+
+
 def grid_of_trace(r):
     return int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
 
@@ -168,23 +185,6 @@ for kn, gl in grids_of.items():
     big = sorted([g for g, cnt in gl if cnt >= 8], reverse=True)[:len(CPD_WORKLOADS)]
     for g, wl in zip(big, sorted(CPD_WORKLOADS, key=lambda w: -w[1] * w[2])):
         assign[(kn, g)] = wl[0]
-
-
-def median(v):
-    v = sorted(v)
-    return v[len(v) // 2] if v else 0
-
-
-def dur(r):
-    return int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-
-
-def live(rs):
-    """Without the NO-OP launches: a registration's iterations are enqueued in batches, and what is still in the queue when the device-side stop rule
-    fires returns at the `done` flag (3-4 us, same grid).  They are launches of the kernel, not E-steps: a dispatch counts if it lasts at least half
-    the median of its (kernel, grid) group."""
-    m = median([dur(r) for r in rs])
-    return [r for r in rs if 2 * dur(r) >= m]
 
 
 def counter_rows_of(d, kn, grid):
