@@ -37,7 +37,7 @@ EXPORTS = [
     "mi_transform_mse", "mi_cpd_params_default", "mi_cpd_register", "mi_cpd_sigma_squared", "mi_cpd_sigma_squared_mode", "mi_cpd_estep",
     "mi_cpd_estep_truncated", "mi_cpd_estep_fgt", "mi_fgt_kcenter", "mi_fgt_kcenter_guided", "mi_fgt_tables", "mi_nicp_params_default", "mi_nicp_register",
     "mi_prepare_params_default", "mi_prepare_cloud",
-    "mi_cpd_mstep", "mi_profile_enable", "mi_profile_select", "mi_profile_reset", "mi_profile_get", "mi_icp_load_times", "mi_profile_search_stats", "mi_profile_search_phases", "mi_selftest_sort_pairs", "mi_nn_kernel_name",
+    "mi_cpd_mstep", "mi_profile_enable", "mi_profile_select", "mi_profile_reset", "mi_profile_get", "mi_icp_load_times", "mi_profile_search_stats", "mi_profile_search_phases", "mi_selftest_sort_pairs", "mi_selftest_fail_loads", "mi_nn_kernel_name",
 ]
 
 
@@ -503,6 +503,10 @@ class Context:
         out = (C.c_ulonglong * 20)()
         _check(lib().mi_profile_search_phases(self._h, out))
         return {k: int(out[i]) for i, k in enumerate(self.SEARCH_PHASES)}
+
+    def selftest_fail_loads(self, n):
+        """Test hook: the next n index builds of this context fail on purpose (mi_selftest_fail_loads)."""
+        _check(lib().mi_selftest_fail_loads(self._h, int(n)))
 
     def selftest_sort_pairs(self, keys, values, bits=30):
         """The library's device radix sort on host arrays: (sorted keys, values carried along), stable."""

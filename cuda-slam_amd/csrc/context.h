@@ -118,7 +118,6 @@ struct mi_ctx {
         int svd_ieee = 0;                                // MISLAM_SVD_IEEE=1: the 3 x 3 SVD of every solve in IEEE divisions and roots (svd3.hpp)
         int icp_fused_solve = 1;                         // MISLAM_ICP_FUSED_SOLVE=0: rows reduce and solve as two launches at every size
         int icp_pipeline = 1;                            // MISLAM_ICP_PIPELINE=0: every host check of mi_icp_run settles the pending iteration and drains the stream
-        int dev_fail_loads = 0;                          // MISLAM_DEV_FAIL_LOADS=N: the context's first N index builds fail on purpose (tests/test_gpu_context.py)
         int fgt_two_streams = 1;                         // MISLAM_FGT_TWO_STREAMS=0: the fixed cloud's clustering of an FGT E-step on the main stream, behind the moving side's
         int fgt_lists_in_model = 1;                      // MISLAM_FGT_LISTS_IN_MODEL=0: the member lists of an FGT E-step by the three-launch counting sort (round 4) instead of inside the model kernel
         int fgt_coop_sweep = 1;                          // MISLAM_FGT_COOP_SWEEP=0: K-centre sweeps of clouds beyond 16 384 points as in rounds 1-4 (one workgroup / two launches per centre); 2: the cooperative kernel for every sweep
@@ -209,6 +208,7 @@ struct mi_ctx {
     // ---- profiling
     mislam::DevBuf<unsigned long long> nn_stats;         // mi_profile_search_stats counters
     bool nn_stats_on = false;
+    int selftest_fail_loads = 0;                         // mi_selftest_fail_loads: the next N index builds fail on purpose (an explicit call of a test, never the environment: ADVICE r05)
     bool profile = false;
     unsigned int prof_mask = 0xffffffffu;                // kernels that get events while profiling (mi_profile_select)
     std::vector<mislam::ProfileSpan> spans;

@@ -238,7 +238,6 @@ static int ctx_create_common(int device, mi_ctx** out)
         c->tune.fgt_lists_in_model = env_i("MISLAM_FGT_LISTS_IN_MODEL", 1);
         c->tune.fgt_coop_sweep = env_i("MISLAM_FGT_COOP_SWEEP", 1);
         c->tune.fgt_model_splits = env_i("MISLAM_FGT_MODEL_SPLITS", 1);
-        c->tune.dev_fail_loads = env_i("MISLAM_DEV_FAIL_LOADS", 0);
         c->tune.grid_deal_rows = env_i("MISLAM_GRID_DEAL_ROWS", -1);
         c->tune.grid_split_walks = env_i("MISLAM_GRID_SPLIT_WALKS", -1);
         c->tune.icp_pipeline = env_i("MISLAM_ICP_PIPELINE", 1);
@@ -621,6 +620,13 @@ extern "C" int mi_profile_search_phases(mi_ctx* c, unsigned long long out[20])
     return MI_OK;
 }
 
+extern "C" int mi_selftest_fail_loads(mi_ctx* c, int n)
+{
+    if (!c || n < 0) { set_error("mi_selftest_fail_loads: bad argument"); return MI_ERR_INVALID_ARG; }
+    c->selftest_fail_loads = n;
+    return MI_OK;
+}
+
 extern "C" int mi_selftest_sort_pairs(mi_ctx* c, unsigned int* keys, int* values, int n, int bits)
 {
     if (!c || n < 0 || (n > 0 && (!keys || !values)) || (bits != 10 && bits != 20 && bits != 30)) {
@@ -757,9 +763,9 @@ static int ensure_tree(mi_ctx* c, int m_local, int index_base)
     int n_pad = 1, height = 0;
     while (n_pad < n_leaves) { n_pad <<= 1; height++; }
     if (height > TREE_MAX_HEIGHT) { set_error("fixed cloud too large for the box hierarchy"); return MI_ERR_INVALID_ARG; }
-    if (c->tune.dev_fail_loads > 0) {      // MISLAM_DEV_FAIL_LOADS=N (tests): the first N index builds of the context fail HERE -- behind the fixed cloud's
-        c->tune.dev_fail_loads -= 1;       // upload, which is already on the auxiliary stream: the early return mi_icp_load's lane guard exists for
-        set_error("index build failed on request (MISLAM_DEV_FAIL_LOADS)");
+    if (c->selftest_fail_loads > 0) {      // mi_selftest_fail_loads (tests): the next N index builds of the context fail HERE -- behind the fixed cloud's
+        c->selftest_fail_loads -= 1;       // upload, which is already on the auxiliary stream: the early return mi_icp_load's lane guard exists for
+        set_error("index build failed on request (mi_selftest_fail_loads)");
         return MI_ERR_INVALID_ARG;
     }
     MI_TRY(c->torder_out.reserve((size_t)m_local));

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MI_SLAM_ABI_VERSION 4   /* 4: mi_profile_search_phases, mi_runtime_info (additive: no signature of version 3 changed); 3: mi_icp_load_times, mi_cross_moments, mi_icp_auto_batch; 2: mi_cpd_params gained sigma2_mode; mi_dist_info, mi_source_share, mi_cpd_sigma_squared_mode, mi_profile_search_stats, mi_selftest_sort_pairs */
+#define MI_SLAM_ABI_VERSION 4   /* 4: mi_profile_search_phases, mi_selftest_fail_loads, mi_runtime_info (additive: no signature of version 3 changed); 3: mi_icp_load_times, mi_cross_moments, mi_icp_auto_batch; 2: mi_cpd_params gained sigma2_mode; mi_dist_info, mi_source_share, mi_cpd_sigma_squared_mode, mi_profile_search_stats, mi_selftest_sort_pairs */
 
 enum {
     MI_OK = 0,
@@ -461,6 +461,10 @@ int mi_profile_search_phases(mi_ctx* ctx, unsigned long long out[20]);
 /* Self-test of the library's own device radix sort (the Hilbert ordering of the index build): sorts the n (key, value) pairs in
  * place, stable, ascending by the low `bits` (10, 20 or 30) of the keys.  Host arrays; test use only. */
 int mi_selftest_sort_pairs(mi_ctx* ctx, unsigned int* keys, int* values, int n, int bits);
+/* Fault injection for the library's own tests: the next n index builds of this context fail with MI_ERR_INVALID_ARG behind the fixed cloud's upload (the
+ * early-return path of mi_icp_load).  Only ever by this explicit call -- round 5 read it from the environment, where a stray variable could have failed
+ * loads in production.  n = 0 disarms. */
+int mi_selftest_fail_loads(mi_ctx* ctx, int n);
 /* Name of the correspondence-search kernel (MI_KERNEL_NN) a search of n_moving points against m_fixed_local fixed points runs
  * with this nn_mode and the current settings -- the name a rocprofv3 kernel trace shows (static string). */
 const char* mi_nn_kernel_name(const mi_ctx* ctx, int n_moving, int m_fixed_local, int nn_mode);

@@ -66,16 +66,15 @@ def test_contexts_in_turn_and_in_threads_with_changing_sizes(capi):
 
 def test_a_failed_load_leaves_the_context_usable(capi, monkeypatch):
     # mi_icp_load puts the fixed cloud's upload and index builds on auxiliary streams and joins them into the main stream at the end --
-    # an early return in between (a refused hierarchy, a failed reserve) used to leave them un-joined.  MISLAM_DEV_FAIL_LOADS=2 makes the context's
+    # an early return in between (a refused hierarchy, a failed reserve) used to leave them un-joined.  mi_selftest_fail_loads(ctx, 2) (an explicit call: ADVICE r05) makes the context's
     # first two index builds fail behind the upload; every exit path now joins the lanes: the failed calls raise, the next one on the SAME context
     # registers the clouds bit for bit as a fresh context does, also at another size (buffers outgrown and retired in between).
     from conftest import synth_cloud
     b1, a1 = synth_cloud(60000, seed=3)[:2]
     b2, a2 = synth_cloud(150000, seed=4)[:2]
     p = capi.icp_params(eps=0.0, max_iterations=6)
-    monkeypatch.setenv("MISLAM_DEV_FAIL_LOADS", "2")
     with capi.Context(0) as bad:
-        monkeypatch.delenv("MISLAM_DEV_FAIL_LOADS")
+        bad.selftest_fail_loads(2)
         with capi.Context(0) as fresh:
             with pytest.raises(capi.MiSlamError):
                 bad.icp_register(b1, a1, p)

@@ -242,7 +242,8 @@ def test_soak_cases_root_caused_in_round_5(ctx, ieee_ctx, capi, oracle, seed, ca
     #    hands a decomposition whose smallest singular value is below 1e-3 of the largest to the IEEE forms (svd3.hpp): 4e-6.
     #  * seed 1 case 333, seed 3 case 337: differences of 5e-2 / 1.5 that the ORACLE shows against itself when the moving cloud is merely
     #    reordered (cpu-slam's sequential fp32 centroid sums round differently): the problem's own conditioning, no kernel's error.  Asserted
-    #    as such: the device is no farther from the oracle than the oracle from itself (x 1.5).
+    #    as such: the device is no farther from the oracle than 2 x the oracle from itself -- the maximum over twelve seeded reorderings, PINNED in
+    #    tests/golden/soak_spread.json (oracle/make_golden_soak_spread.py; round 5 drew the twelve at run time: a noisy bar).
     src, tgt = soak_problem(seed, case)
     Ro, to, ito, eo = oracle.icp(src, tgt, eps=0.0, max_iterations=3)[:4]
     scale = max(1.0, float(np.abs(to).max()))
@@ -254,9 +255,10 @@ def test_soak_cases_root_caused_in_round_5(ctx, ieee_ctx, capi, oracle, seed, ca
     if bar is not None:
         assert d < bar
     else:
-        rng = np.random.default_rng(seed * 1000 + case)
-        # (twelve reorderings: the distribution has a long tail -- three of them showed 9e-4 once where the soak's own three had shown 5.4e-2)
-        own = max(frob(*oracle.icp(src[rng.permutation(len(src))], tgt, eps=0.0, max_iterations=3)[:2], Ro, to) for _ in range(12)) / scale
+        import json, os
+        pinned = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "soak_spread.json")))["cases"]["%d/%d" % (seed, case)]
+        assert abs(pinned["scale"] - scale) < 1e-6 * scale          # (the same problem as the fixture's)
+        own = pinned["spread_max"]
         assert d <= 2.0 * own + 1e-5, (d, own)
 
 
