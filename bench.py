@@ -355,10 +355,10 @@ def cpd_bunny(np, capi, ctx, world):
         ctx.profile_enable(True)                                 # once more with HIP events around every kernel, for the breakdown only
         ctx.profile_select(None)
         ctx.profile_reset()
-        # (capped at the iteration count just measured: the registration's iterations are enqueued in batches, and what is still queued when the
-        # device-side stop rule fires returns at the `done` flag in 3-4 us -- launches of the kernels, not E-steps: ~11 % of the bunny leg's launches, which
-        # diluted every per-launch figure of rounds 1-5 by as much.  With the cap the loop ends where the rule would have ended it: the same result.)
-        p_capped = capi.cpd_params(max_iterations=it, sigma2_init=g["sigma2_init"], approximation=approx)
+        # (ONE iteration per host check, capped at the iteration count just measured: a registration's iterations are otherwise enqueued in batches, and what
+        # is still queued when the device-side stop rule fires returns at the `done` flag in 3-4 us -- launches of the kernels, not E-steps: ~11 % of the
+        # bunny leg's launches, which diluted every per-launch figure of rounds 1-5 by as much.  The kernels' own times do not depend on the host's checks.)
+        p_capped = capi.cpd_params(max_iterations=it, sigma2_init=g["sigma2_init"], approximation=approx, sync_every=1)
         t0 = time.perf_counter()
         ctx.cpd_register(before, after, p_capped)
         wall_profiled = time.perf_counter() - t0

@@ -121,6 +121,7 @@ struct mi_ctx {
         int fgt_two_streams = 1;                         // MISLAM_FGT_TWO_STREAMS=0: the fixed cloud's clustering of an FGT E-step on the main stream, behind the moving side's
         int fgt_lists_in_model = 1;                      // MISLAM_FGT_LISTS_IN_MODEL=0: the member lists of an FGT E-step by the three-launch counting sort (round 4) instead of inside the model kernel
         int fgt_coop_sweep = 1;                          // MISLAM_FGT_COOP_SWEEP=0: K-centre sweeps of clouds beyond 16 384 points as in rounds 1-4 (one workgroup / two launches per centre); 2: the cooperative kernel for every sweep
+        int fgt_shard_queries = 1;                       // MISLAM_FGT_SHARD_QUERIES=0: the FGT / hybrid CPD modes run replicated on a multi-rank context, no collective (rounds 4-5)
         int fgt_model_splits = 1;                        // MISLAM_FGT_MODEL_SPLITS=0: one workgroup per cell in the FGT model build whatever the cells' sizes (rounds 1-4)
         int fgt_replay = 1;                              // MISLAM_FGT_REPLAY=0: sweep the moving cloud step by step every E-step (no guess replayed)
     } tune;

@@ -76,7 +76,12 @@ struct CpdWorkspace {
     int k_chunks = 1, k_chunk_len = 0, x_chunks = 1, x_chunk_len = 0;
     bool sums_fresh = false;                  // the last exact E-step left the M-step's x-sums and k-sums in part_x / part_k
     int sum_rows_x = 0, sum_rows_k = 0;       // ... in this many rows each
-    bool replicated = false;                  // multi-rank context, but this registration runs whole on every rank (the FGT modes): no collective
+    bool replicated = false;                  // multi-rank context, both clouds held WHOLE on every rank (the FGT modes: they cluster whole clouds)
+    // Round 6: ... but the E-step's QUERIES are split over the ranks -- the fixed points the first transform is evaluated at
+    // [a_lo, a_hi), the moving points of the second [m_lo, m_hi) (mi_shard_range), the truncated E-step's fixed-cloud tiles [t_lo, t_hi) -- and the
+    // M-step's 24 sums are all-reduced as in the exact mode.  Clusterings and coefficient tables stay replicated (small, bit-deterministic).
+    bool queries_sharded = false;
+    int a_lo = 0, a_hi = 0, m_lo = 0, m_hi = 0;
     mi_cpd_params params{};
 };
 
@@ -258,11 +263,26 @@ static int cpd_estep_trunc_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
     t.bx = v.bx; t.by = v.by; t.bz = v.bz;
     t.xw4 = w->t_xw4.p; t.xw4_caller = v.xw4; t.pt1 = v.pt1; t.p1 = v.p1; t.px = v.px;
     t.trunc_log = v.trunc_log;
-    const int nxb = std::min(CPD_TRUNC_MAX_BLOCKS, cpd_trunc_tiles(w->n)), nkb = std::min(CPD_TRUNC_MAX_BLOCKS, cpd_trunc_tiles(w->m));
+    // a multi-rank context: this rank's tiles of the FIXED cloud (curve order) for the denominators, its tiles of the MOVING cloud for the contraction, each
+    // against the whole other cloud -- per-point values bit for bit the single-GPU run's; the M-step's sums are added over the ranks
+    t.a_tile_lo = 0; t.a_tile_hi = cpd_trunc_tiles(w->n); t.y_tile_lo = 0; t.y_tile_hi = cpd_trunc_tiles(w->m);
+    if (w->queries_sharded) {
+        (void)mi_shard_range(cpd_trunc_tiles(w->n), c->rank, c->world, &t.a_tile_lo, &t.a_tile_hi);
+        (void)mi_shard_range(cpd_trunc_tiles(w->m), c->rank, c->world, &t.y_tile_lo, &t.y_tile_hi);
+    }
+    const int nxb = std::max(1, std::min(CPD_TRUNC_MAX_BLOCKS, t.a_tile_hi - t.a_tile_lo)), nkb = std::max(1, std::min(CPD_TRUNC_MAX_BLOCKS, t.y_tile_hi - t.y_tile_lo));
     // the moving cloud's current positions in curve order + this E-step's boxes
     MI_HIP(cpd_trunc_gather(v.yx, v.yy, v.yz, w->t_border.p, w->m, w->t_yx.p, w->t_yy.p, w->t_yz.p, w->t_ybox.p,
                             w->t_ybox.p + 6 * (size_t)cpd_trunc_tiles(w->m), v.state, c->stream));
     { ProfScope ps(c, MI_KERNEL_CPD_DENOM); MI_HIP(cpd_trunc_denominators(t, w->part_x.p, nxb, c->stream)); }
+    if (w->queries_sharded) {
+        // the contraction's operand (w x, w y, w z, w per fixed point, curve order): every rank has written its own tiles' points; an unsigned MINIMUM against
+        // all-ones hands every rank all of them, bit for bit (as for the FGT E-step's weights below)
+        const size_t p_lo = (size_t)t.a_tile_lo * CPD_TRUNC_TILE, p_hi = std::min((size_t)t.a_tile_hi * CPD_TRUNC_TILE, (size_t)w->n);
+        if (p_lo > 0) MI_HIP(hipMemsetAsync(w->t_xw4.p, 0xff, sizeof(float4) * p_lo, c->stream));
+        if (p_hi < (size_t)w->n) MI_HIP(hipMemsetAsync(w->t_xw4.p + p_hi, 0xff, sizeof(float4) * ((size_t)w->n - p_hi), c->stream));
+        MI_TRY(allreduce_min_u64(c, reinterpret_cast<unsigned long long*>(w->t_xw4.p), 2 * (size_t)w->n));
+    }
     { ProfScope ps(c, MI_KERNEL_CPD_CONTRACT); MI_HIP(cpd_trunc_contract(t, w->part_k.p, nkb, c->stream)); }
     w->sums_fresh = true;
     w->sum_rows_x = nxb; w->sum_rows_k = nkb;
@@ -278,7 +298,7 @@ static int cpd_mstep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, const
         MI_HIP(cpd_ksums(v, w->part_k.p, nkb, c->stream));
     } else { nxb = w->sum_rows_x; nkb = w->sum_rows_k; }     // (the rows the E-step's own kernels left)
     w->sums_fresh = false;
-    if (!c->distributed() || w->replicated) {
+    if (!c->distributed() || (w->replicated && !w->queries_sharded)) {
         MI_HIP(cpd_solve(w->d_state, w->part_x.p, nxb, w->part_k.p, nkb, rules, update_loop_state, c->stream));
         return MI_OK;
     }
@@ -493,9 +513,23 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
     MI_HIP(fgt_cluster(cy, f->sort_temp.p, temp, c->stream));
     f->y.guess_K = K;
     MI_HIP(fgt_model(cy, nullptr, hsigma, t, f->By.p, c->stream, true, Zy > 1 ? f->By_part.p : nullptr, Zy));
-    MI_HIP(fgt_predict(v.ax, v.ay, v.az, w->n, cy.xc, f->By.p, K, 1, hsigma, ratio_of_far_field, t, Sa, f->kt1.p, c->stream));
-    const int nxb = cpd_standalone_sum_blocks(w->n), nkb = cpd_standalone_sum_blocks(w->m);
-    MI_HIP(fgt_post_kt1(f->kt1.p, Sa, v.ax, v.ay, v.az, w->n, ndi, v.pt1, v.xw4, c->stream, with_sums ? w->part_x.p : nullptr, nxb));
+    // The two evaluation kernels carry the E-step's arithmetic and each query is independent of every other: on a multi-rank
+    // context a rank evaluates ITS queries only -- with the whole cloud's number of cell splits (Sa, Sy), so that a point's partial sums are grouped as on
+    // one GPU and its value is the single-GPU run's to the last bit.
+    const bool sharded = w->queries_sharded && with_sums;
+    const int a0 = sharded ? w->a_lo : 0, an = sharded ? w->a_hi - w->a_lo : w->n;
+    const int m0 = sharded ? w->m_lo : 0, mn = sharded ? w->m_hi - w->m_lo : w->m;
+    MI_HIP(fgt_predict(v.ax + a0, v.ay + a0, v.az + a0, an, cy.xc, f->By.p, K, 1, hsigma, ratio_of_far_field, t, Sa, f->kt1.p, c->stream));
+    const int nxb = cpd_standalone_sum_blocks(an), nkb = cpd_standalone_sum_blocks(mn);
+    MI_HIP(fgt_post_kt1(f->kt1.p, Sa, v.ax + a0, v.ay + a0, v.az + a0, an, ndi, v.pt1 + a0, v.xw4 + a0, c->stream, with_sums ? w->part_x.p : nullptr, nxb));
+    if (sharded) {
+        // The fixed side's model build weighs EVERY fixed point by its 1/den, x/den (xw4): each rank has written its own range; the others' arrive through
+        // the transport.  An element-wise unsigned MINIMUM against all-ones moves any bit pattern unchanged (a sum would not: NaN payloads, -0), so
+        // every rank ends up with the bits the single-GPU run has, and builds the same table from them.
+        if (a0 > 0) MI_HIP(hipMemsetAsync(v.xw4, 0xff, sizeof(float4) * (size_t)a0, c->stream));
+        if (w->a_hi < w->n) MI_HIP(hipMemsetAsync(v.xw4 + w->a_hi, 0xff, sizeof(float4) * (size_t)(w->n - w->a_hi), c->stream));
+        MI_TRY(allreduce_min_u64(c, reinterpret_cast<unsigned long long*>(v.xw4), 2 * (size_t)w->n));
+    }
     // P1 and PX: sources = fixed cloud weighted by 1/den and x/den, queried at the moving cloud   (:54-66; the reference
     // clusters the fixed cloud four times with the same result -- once is enough)
     if (recluster) {
@@ -508,8 +542,8 @@ static int cpd_estep_fgt_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v, f
         f->a.swept_K = K;
     }
     MI_HIP(fgt_model(ca, v.xw4, hsigma, t, f->Ba.p, c->stream, recluster, Za > 1 ? f->Ba_part.p : nullptr, Za));      // (an unchanged clustering keeps its means)
-    MI_HIP(fgt_predict(v.yx, v.yy, v.yz, w->m, ca.xc, f->Ba.p, K, 4, hsigma, ratio_of_far_field, t, Sy, f->v4.p, c->stream));
-    MI_HIP(fgt_post_px(f->v4.p, Sy, w->m, v.p1, v.px, c->stream, with_sums ? w->part_k.p : nullptr, nkb, v.bx, v.by, v.bz));
+    MI_HIP(fgt_predict(v.yx + m0, v.yy + m0, v.yz + m0, mn, ca.xc, f->Ba.p, K, 4, hsigma, ratio_of_far_field, t, Sy, f->v4.p, c->stream));
+    MI_HIP(fgt_post_px(f->v4.p, Sy, mn, v.p1 + m0, v.px + 3 * (size_t)m0, c->stream, with_sums ? w->part_k.p : nullptr, nkb, v.bx + m0, v.by + m0, v.bz + m0));
     if (with_sums) { w->sums_fresh = true; w->sum_rows_x = nxb; w->sum_rows_k = nkb; }
     return MI_OK;
 }
@@ -567,6 +601,11 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
     // no collective at all.  The exact P shards.
     int lo = 0, hi = n_after;
     w->replicated = c->world > 1 && params->approximation != MI_CPD_APPROX_NONE;
+    w->queries_sharded = w->replicated && c->tune.fgt_shard_queries != 0 && cpd_trunc_tiles(m_before) >= c->world && cpd_trunc_tiles(n_after) >= c->world;
+    if (w->queries_sharded) {
+        (void)mi_shard_range(n_after, c->rank, c->world, &w->a_lo, &w->a_hi);
+        (void)mi_shard_range(m_before, c->rank, c->world, &w->m_lo, &w->m_hi);
+    }
     if (c->world > 1 && !w->replicated) (void)mi_shard_range(n_after, c->rank, c->world, &lo, &hi);
     MI_TRY(cpd_load(c, w, before_xyz, m_before, after_xyz + 3 * (size_t)lo, hi - lo));
     w->n_total = n_after;
@@ -614,7 +653,8 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
                     CpdView vt = v;
                     vt.truncate = 1;
                     vt.trunc_log = std::log(1e-3f);                // ComputePMatrix(..., true, 1e-3f), :166 / :182-183
-                    if (c->tune.cpd_trunc_cull != 0) MI_TRY(cpd_estep_trunc_enqueue(c, w, vt));
+                    // (MISLAM_CPD_TRUNC_CULL=0 -- round 4's every-pair truncated kernels -- has no sharded form: a sharded registration takes the culled ones)
+                    if (c->tune.cpd_trunc_cull != 0 || w->queries_sharded) MI_TRY(cpd_estep_trunc_enqueue(c, w, vt));
                     else MI_TRY(cpd_estep_enqueue(c, w, vt));
                 }
             }
@@ -671,6 +711,7 @@ extern "C" int mi_cpd_sigma_squared_mode(mi_ctx* c, const float* before_xyz, int
     CpdWorkspace* w = nullptr;
     MI_TRY(cpd_workspace(c, &w));
     w->replicated = false;
+    w->queries_sharded = false;
     MI_TRY(cpd_load(c, w, before_xyz, m, after_xyz, n));
     const CpdView v = cpd_view(c, w);
     mi_cpd_params p;
@@ -694,6 +735,7 @@ static int estep_primitive(mi_ctx* c, const float* y_xyz, int m, const float* x_
     CpdWorkspace* w = nullptr;
     MI_TRY(cpd_workspace(c, &w));
     w->replicated = false;
+    w->queries_sharded = false;
     MI_TRY(cpd_load(c, w, y_xyz, m, x_xyz, n));
     CpdView v = cpd_view(c, w);
     memset(w->h_state, 0, sizeof(CpdState));
@@ -827,6 +869,7 @@ extern "C" int mi_cpd_mstep(mi_ctx* c, const float* before_xyz, int m, const flo
     CpdWorkspace* w = nullptr;
     MI_TRY(cpd_workspace(c, &w));
     w->replicated = false;
+    w->queries_sharded = false;
     MI_TRY(cpd_load(c, w, before_xyz, m, after_xyz, n));
     CpdView v = cpd_view(c, w);
     v.xw4 = nullptr;   // no E-step ran: skip the log-likelihood term

@@ -85,6 +85,10 @@ struct CpdTruncView {
     float4* xw4_caller;                   // the same records in the caller's order (CpdView::xw4)
     float *pt1, *p1, *px;                 // caller's order, as CpdView
     float trunc_log;
+    // Round 6, multi-rank contexts (the whole clouds: 0 .. tiles): the denominators kernel works on the FIXED cloud's tiles [a_tile_lo, a_tile_hi) of this rank, the
+    // contraction on the MOVING cloud's tiles [y_tile_lo, y_tile_hi) -- each against the whole other cloud, so every per-point value is the single-GPU run's to the
+    // bit; between the two the ranks exchange xw4 (cpd_api.hip)
+    int a_tile_lo, a_tile_hi, y_tile_lo, y_tile_hi;
 };
 // out = in[order] (padded to whole tiles with copies of the last point) and the tiles' boxes; state != null: nothing once it says done
 hipError_t cpd_trunc_gather(const float* x, const float* y, const float* z, const int* order, int n, float* ox, float* oy, float* oz,

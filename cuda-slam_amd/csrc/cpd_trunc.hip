@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * CPD_TRUNC_WAVES) void cpd_trunc_den_kernel(Cpd
     const int n_groups_y = (v.m + CPD_TRUNC_TILE - 1) / CPD_TRUNC_TILE * CPD_TRUNC_PER_LOAD;
     const float far = __builtin_inff();
     double acc[CPD_XSUMS] = {0};
-    for (int tile = blockIdx.x; tile < n_tiles_a; tile += gridDim.x) {
+    for (int tile = v.a_tile_lo + (int)blockIdx.x; tile < v.a_tile_hi; tile += gridDim.x) {      // (this rank's tiles: all of them on one GPU)
         const int i = tile * CPD_TRUNC_TILE + lane;
         const float ax = v.ax[i], ay = v.ay[i], az = v.az[i];                   // (padded to whole tiles)
         float mine[6];
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64 * CPD_TRUNC_WAVES) void cpd_trunc_contract_kerne
     const int n_groups_a = (v.n + CPD_TRUNC_TILE - 1) / CPD_TRUNC_TILE * CPD_TRUNC_PER_LOAD;
     const float far = __builtin_inff();
     double acc[CPD_KSUMS] = {0};
-    for (int tile = blockIdx.x; tile < n_tiles_y; tile += gridDim.x) {
+    for (int tile = v.y_tile_lo + (int)blockIdx.x; tile < v.y_tile_hi; tile += gridDim.x) {      // (this rank's tiles of the moving cloud: all of them on one GPU)
         const int k = tile * CPD_TRUNC_TILE + lane;
         const float yx = v.yx[k], yy = v.yy[k], yz = v.yz[k];
         float mine[6];

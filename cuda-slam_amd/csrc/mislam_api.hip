@@ -238,6 +238,7 @@ static int ctx_create_common(int device, mi_ctx** out)
         c->tune.fgt_lists_in_model = env_i("MISLAM_FGT_LISTS_IN_MODEL", 1);
         c->tune.fgt_coop_sweep = env_i("MISLAM_FGT_COOP_SWEEP", 1);
         c->tune.fgt_model_splits = env_i("MISLAM_FGT_MODEL_SPLITS", 1);
+        c->tune.fgt_shard_queries = env_i("MISLAM_FGT_SHARD_QUERIES", 1);
         c->tune.grid_deal_rows = env_i("MISLAM_GRID_DEAL_ROWS", -1);
         c->tune.grid_split_walks = env_i("MISLAM_GRID_SPLIT_WALKS", -1);
         c->tune.icp_pipeline = env_i("MISLAM_ICP_PIPELINE", 1);

@@ -103,17 +103,28 @@ def main():
             assert ca[3] == cb[3], (kw, ca[3], cb[3])
             assert frob(ca[0], ca[1], cb[0], cb[1]) < 1e-4 and abs(ca[2] - cb[2]) < 1e-5, kw
         assert calls[capi.EXCHANGE_SUM_F64] > 50
-        # the Fast Gauss Transform modes (hybrid is the reference parser's default, configparser.cpp:217) run REPLICATED on a
-        # multi-rank context: whole clouds on every rank, no collective, the single-GPU run's bits
-        n_sum = calls[capi.EXCHANGE_SUM_F64]
+        # The Fast Gauss Transform modes (hybrid is the reference parser's default, configparser.cpp:217).  Rounds 4-5 ran them REPLICATED on a multi-rank
+        # context; round 6 splits the E-step's QUERIES over the ranks -- the fixed points of the first transform, the moving points of
+        # the second, the truncated E-step's fixed-cloud tiles -- with clusterings and coefficient tables replicated: every per-point value is the
+        # single-GPU run's to the bit (the weights travel through an unsigned-minimum all-reduce against all-ones), only the M-step's 24 sums are added in
+        # another grouping.  Same iteration counts, R|t within 1e-6.
+        n_sum, n_min = calls[capi.EXCHANGE_SUM_F64], calls[capi.EXCHANGE_MIN_U64]
         for approx, kw in ((capi.CPD_APPROX_HYBRID, dict(max_iterations=50)), (capi.CPD_APPROX_FULL, dict(max_iterations=5)),
+                           (capi.CPD_APPROX_FULL, dict(max_iterations=17)),
                            (capi.CPD_APPROX_HYBRID, dict(max_iterations=50, sigma2_mode=capi.SIGMA2_CPU_SEQUENTIAL))):
             cp = capi.cpd_params(approximation=approx, **kw)
             ca = dctx.cpd_register(before, after, cp)
             cb = sctx.cpd_register(before, after, cp)
-            assert ca[3] == cb[3] and ca[2] == cb[2] and ca[4] == cb[4], (approx, kw, ca[3], cb[3])
-            assert np.array_equal(np.asarray(ca[0]), np.asarray(cb[0])) and np.array_equal(np.asarray(ca[1]), np.asarray(cb[1])), (approx, kw)
-        assert calls[capi.EXCHANGE_SUM_F64] == n_sum, "a replicated registration must not call the transport"
+            assert ca[3] == cb[3], (approx, kw, ca[3], cb[3])
+            d = frob(ca[0], ca[1], cb[0], cb[1])
+            assert d < 1e-6 and abs(ca[2] - cb[2]) < 1e-6 and abs(ca[4] - cb[4]) <= 1e-6 * max(1.0, abs(cb[4])), (approx, kw, d, ca[2], cb[2], ca[4], cb[4])
+        assert calls[capi.EXCHANGE_SUM_F64] > n_sum and calls[capi.EXCHANGE_MIN_U64] > n_min, "the sharded E-step combines its sums and its weights through the transport"
+        # ragged shares: sizes the rank count does not divide, fewer fixed-cloud tiles than a whole number per rank
+        rb_, ra_ = synth_cloud(5003, m=4099, seed=5)[:2]
+        for approx, kw in ((capi.CPD_APPROX_HYBRID, dict(max_iterations=30)), (capi.CPD_APPROX_FULL, dict(max_iterations=6))):
+            cp = capi.cpd_params(approximation=approx, **kw)
+            ca, cb = dctx.cpd_register(rb_, ra_, cp), sctx.cpd_register(rb_, ra_, cp)
+            assert ca[3] == cb[3] and frob(ca[0], ca[1], cb[0], cb[1]) < 1e-6, (approx, kw, ca[3], cb[3], frob(ca[0], ca[1], cb[0], cb[1]))
 
     dist.barrier()
     dist.destroy_process_group()

@@ -59,3 +59,82 @@ def test_profile_speaks_for_the_committed_search_kernel():
     # a stale profile fails the suite: the counters bench.py attaches to its roofline must have been taken on the code it runs
     assert c.get("source_hash") == search_source_hash(), ("the committed counter profile was taken on other search-kernel code: run "
                                                           "tools/gpu_profiles.sh again and commit its summaries with the kernel change")
+
+
+# ---- the CPD leg: one profile entry per workload, each recomputable from the committed rows --------------------------------
+def _load_cpd():
+    import glob
+    files = sorted(glob.glob(os.path.join(PROF, "r*_cpd_estep_counters.json")))
+    c = json.load(open(files[-1]))
+    tag = os.path.basename(files[-1]).split("_")[0]
+    if "workloads" not in c:
+        pytest.skip("the latest CPD profile predates the per-workload form")
+    rows = list(csv.DictReader(open(os.path.join(PROF, tag + "_cpd_estep_timed_dispatches.csv"))))
+    return tag, c, rows
+
+
+def _bench_lines(tag):
+    path = os.path.join(PROF, tag + "_bench_default.log")
+    if not os.path.exists(path):
+        pytest.skip("no committed default bench log for " + tag)
+    return [json.loads(ln) for ln in open(path) if ln.lstrip().startswith("{") and '"metric"' in ln]
+
+
+CPD_WORKLOADS = {"cpd_bunny_14904": 14904.0 * 14904.0, "cpd_synthetic_uniform_n49000": 49000.0 * 49000.0}
+# vector instructions per pair of the two exact E-step kernels (denominators, contraction) -- the per-workload profile must say the same
+DESIGN_VALU_PER_PAIR = {"cpd_denominator_kernel": 9.5, "cpd_contract_mfma_kernel": 9.9}
+
+
+def test_cpd_profile_has_one_entry_per_workload_recomputable_from_the_committed_rows():
+    tag, c, rows = _load_cpd()
+    assert set(c["workloads"]) == set(CPD_WORKLOADS)
+    for wl, pairs in CPD_WORKLOADS.items():
+        e = c["workloads"][wl]
+        assert e["pairs_per_launch"] == pairs
+        assert len(e["kernels"]) == 2                                       # the exact mode's two kernels, nothing of the hybrid mode's truncated ones
+        for kn, k in e["kernels"].items():
+            mine = [r for r in rows if r["workload"] == wl and r["kernel"].strip() == kn.strip()]
+            assert len(mine) == k["launches"] > 0
+            mean_ms = sum(int(r["duration_ns"]) for r in mine) / len(mine) * 1e-6
+            assert abs(mean_ms - k["launch_ms"]) < 1e-9 + 1e-9 * mean_ms
+            assert len({r["grid_work_items"] for r in mine}) == 1           # one grid per (kernel, workload): what the selection rests on
+            # no no-op launch among them (a launch that returns at a finished registration's `done` flag lasts 3-4 us)
+            assert min(int(r["duration_ns"]) for r in mine) * 2 >= sorted(int(r["duration_ns"]) for r in mine)[len(mine) // 2]
+            assert k["counter_launches"] == k["launches"]                   # the counter passes saw the same dispatches
+            name = "cpd_denominator_kernel" if "denominator" in kn else "cpd_contract_mfma_kernel"
+            assert abs(k["valu_instructions_per_pair"] - DESIGN_VALU_PER_PAIR[name]) <= 0.1 * DESIGN_VALU_PER_PAIR[name], (wl, kn, k["valu_instructions_per_pair"])
+            assert abs(k["SQ_INSTS_VALU"] * 64.0 / pairs - k["valu_instructions_per_pair"]) < 1e-9 * k["valu_instructions_per_pair"]
+
+
+def test_cpd_profile_matrix_pipe_carries_the_contraction_once():
+    _, c, _ = _load_cpd()
+    for wl, e in c["workloads"].items():
+        mf = [k["mfma"] for kn, k in e["kernels"].items() if "mfma" in kn]
+        assert len(mf) == 1
+        share = mf[0]["share_of_contraction_on_matrix_pipe"]
+        assert 0.9 <= share <= 1.1, (wl, share)                             # round 5's mixed average read 2.23
+        assert abs(mf[0]["contraction_flops_per_launch"] - 8.0 * e["pairs_per_launch"]) < 1.0
+        assert 0.05 < mf[0]["mfma_util"] < 0.5
+
+
+def test_cpd_profile_agrees_with_the_bench_lines_live_kernel_times():
+    tag, c, _ = _load_cpd()
+    lines = _bench_lines(tag)
+    assert lines
+    for d in lines:
+        live = d["cpd_bunny"]["exact"]["kernels_ms_per_launch"]
+        prof = c["workloads"]["cpd_bunny_14904"]["kernels"]
+        for live_name, key in (("cpd_denom", "denominator"), ("cpd_contract", "contract")):
+            p = [k["launch_ms"] for kn, k in prof.items() if key in kn][0]
+            assert abs(p - live[live_name]) <= 0.1 * live[live_name], (live_name, p, live[live_name])
+        # ... and the roofline in the line is the bunny entry's, recomputable by hand: time-weighted busy ratio over the counter's ceiling
+        roof = d["cpd_bunny"]["exact"]["roofline"]
+        ks = list(prof.values())
+        busy = sum(k["valu_busy_quadcycles_per_gui_cycle"] * k["launch_ms"] for k in ks) / sum(k["launch_ms"] for k in ks)
+        assert roof["workload"] == "cpd_bunny_14904" and abs(roof["achieved"] - busy) < 1e-6 * busy and abs(roof["frac"] - busy / 32.0) < 1e-6
+        pub = d["cpd_bunny"]["published_size"]["exact"]
+        assert pub["roofline"]["workload"] == "cpd_synthetic_uniform_n49000"
+        prof49 = c["workloads"]["cpd_synthetic_uniform_n49000"]["kernels"]
+        for live_name, key in (("cpd_denom", "denominator"), ("cpd_contract", "contract")):
+            p = [k["launch_ms"] for kn, k in prof49.items() if key in kn][0]
+            assert abs(p - pub["kernels_ms_per_launch"][live_name]) <= 0.1 * pub["kernels_ms_per_launch"][live_name]
