@@ -19,6 +19,7 @@ NN_AUTO, NN_BRUTEFORCE, NN_TREE, NN_GRID = 0, 1, 2, 3
 SHARD_AUTO, SHARD_TARGET, SHARD_SOURCE = 0, 1, 2
 SUM_EXACT, SUM_CPU_SEQUENTIAL = 0, 1
 SIGMA2_EXACT, SIGMA2_CPU_SEQUENTIAL = 0, 1
+ESTEP_DEFAULT, ESTEP_CPU_SEQUENTIAL = 0, 1
 NN_INDEX_MIN_POINTS = 10000         # MI_NN_AUTO switches to the cell grid at this many fixed points (mi_slam.h MI_NN_INDEX_MIN_POINTS)
 STOP_RUNNING, STOP_CONVERGED, STOP_MAX_ITERATIONS, STOP_NO_PAIRS, STOP_ERROR_INCREASED, STOP_TOLERANCE, STOP_SIGMA = range(7)
 (KERNEL_NN, KERNEL_MOMENTS, KERNEL_SOLVE, KERNEL_TRANSFORM, KERNEL_FINALIZE, KERNEL_ALLREDUCE, KERNEL_CPD_DENOM,
@@ -52,7 +53,7 @@ class CpdParams(C.Structure):
     _fields_ = [("eps", C.c_float), ("weight", C.c_float), ("const_scale", C.c_int), ("max_iterations", C.c_int),
                 ("tolerance", C.c_float), ("sigma2_init", C.c_float), ("sync_every", C.c_int), ("verbose", C.c_int),
                 ("approximation", C.c_int), ("fgt_ratio_of_far_field", C.c_float), ("fgt_order_of_truncation", C.c_int),
-                ("sigma2_mode", C.c_int), ("reserved", C.c_int * 4)]
+                ("sigma2_mode", C.c_int), ("estep_mode", C.c_int), ("reserved", C.c_int * 3)]
 
 
 class NicpParams(C.Structure):

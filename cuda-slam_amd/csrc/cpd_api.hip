@@ -206,6 +206,12 @@ static int use_mfma_contraction(const mi_ctx* c) { return c->tune.cpd_mfma; }   
 
 static int cpd_estep_enqueue(mi_ctx* c, CpdWorkspace* w, const CpdView& v)
 {
+    if (w->params.estep_mode == MI_ESTEP_CPU_SEQUENTIAL && !v.truncate) {
+        // parity mode: cpu-slam's summation order (cpd_kernels.hip); the M-step's sums then come from the stand-alone kernels (sums_fresh = false)
+        { ProfScope ps(c, MI_KERNEL_CPD_DENOM); MI_HIP(cpd_estep_sequential(v, c->stream)); }
+        w->sums_fresh = false;
+        return MI_OK;
+    }
     // the two post kernels also accumulate the M-step's moments of what they have just produced (two launches less per EM iteration)
     const int nxb = cpd_sum_blocks(w->n), nkb = cpd_sum_blocks(w->m);
     { ProfScope ps(c, MI_KERNEL_CPD_DENOM); MI_HIP(cpd_denominators(v, c->stream)); }
@@ -588,6 +594,11 @@ extern "C" int mi_cpd_register(mi_ctx* c, const float* before_xyz, int m_before,
     if (params->approximation != MI_CPD_APPROX_NONE &&
         (params->fgt_order_of_truncation < 1 || params->fgt_order_of_truncation > FGT_MAX_ORDER || m_before < 2 || n_after < 2)) {
         set_error("mi_cpd_register: the FGT modes need 1 <= order of truncation <= %d and >= 2 points per cloud", FGT_MAX_ORDER);
+        return MI_ERR_INVALID_ARG;
+    }
+    if (params->estep_mode != MI_ESTEP_DEFAULT && params->estep_mode != MI_ESTEP_CPU_SEQUENTIAL) { set_error("mi_cpd_register: bad estep_mode %d", params->estep_mode); return MI_ERR_INVALID_ARG; }
+    if (params->estep_mode == MI_ESTEP_CPU_SEQUENTIAL && (c->world > 1 || params->approximation != MI_CPD_APPROX_NONE)) {
+        set_error("mi_cpd_register: MI_ESTEP_CPU_SEQUENTIAL is a single-GPU parity mode of the exact E-step");
         return MI_ERR_INVALID_ARG;
     }
     MI_ENTER(c);

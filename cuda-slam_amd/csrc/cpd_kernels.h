@@ -96,6 +96,8 @@ hipError_t cpd_trunc_gather(const float* x, const float* y, const float* z, cons
 hipError_t cpd_trunc_denominators(const CpdTruncView& v, double* xpartials, int nblocks, hipStream_t s);   // den, Pt1, xw4 + the M-step's x-sums
 hipError_t cpd_trunc_contract(const CpdTruncView& v, double* kpartials, int nblocks, hipStream_t s);       // P1, PX + the M-step's k-sums
 
+// MI_ESTEP_CPU_SEQUENTIAL: den (into den_part[0 .. n)), Pt1, xw4, then P1 / PX, every sum in cpu-slam's index order (parity mode; cpd_kernels.hip)
+hipError_t cpd_estep_sequential(const CpdView& v, hipStream_t s);
 hipError_t cpd_init_sums(const CpdView& v, double* partials, int nblocks, hipStream_t s);
 // sigma2_override > 0: use it; sigma2_from_state: use the value cpd_sigma2_sequential left in state->sigma2_init; else the exact
 // closed form from the sums

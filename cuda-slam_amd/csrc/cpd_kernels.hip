@@ -756,6 +756,63 @@ hipError_t cpd_post_contract(const CpdView& v, hipStream_t s, double* kpartials,
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// MI_ESTEP_CPU_SEQUENTIAL (round 6): the E-step in cpu-slam's own SUMMATION ORDER -- a parity mode, like MI_SUM_CPU_SEQUENTIAL for ICP.
+// cpu-slam adds a fixed point's m affinities one by one into one fp32 running sum, and every moving point's P1 / PX one fixed point at a time
+// (coherentpointdrift.cpp:186-213); a running sum of ~1e2 drops every term below half its ulp whole -- a ONE-SIDED error the default kernels' chunked sums do
+// not make, 2.5e-5 of sigma^2 per EM iteration, which `cpd-const-scale: true` amplifies to 1.1e-3 of s R|t on the bunny clouds.  Here: one
+// lane per fixed point adds its terms in index order (kernel 1), one lane per moving point divides by the denominator as the reference does -- value =
+// p / den, not p * (1 / den) -- and adds value, x * value in index order (kernel 2).  What cannot be retraced is the exponential itself (glibc's expf against
+// the 2-ulp routine above): unbiased rounding noise, no drift.  Cost irrelevant: ~2 x 0.5 ms per E-step on the bunny clouds.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void cpd_estep_seq_den_kernel(CpdView v)
+{
+    if (v.state->done != 0) return;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int ic = min(i, v.n - 1);
+    const float mult = -0.5f / v.state->sigma2;          // coherentpointdrift.cpp:176
+    const float c = v.state->constant;
+    const float ax = v.ax[ic], ay = v.ay[ic], az = v.az[ic];
+    float den = 0.f;
+    for (int k = 0; k < v.m; k++) {                        // (wave-uniform k: the moving cloud arrives through scalar loads)
+        const float value = affinity<false>(mult * sq_dist(ax, ay, az, v.yx[k], v.yy[k], v.yz[k]), 0.f);
+        den += value;                                      // :199  one running sum, index order
+    }
+    den += c;                                              // :202
+    if (i >= v.n) return;
+    const float w = 1.0f / den;
+    v.den_part[i] = den;                                   // kernel 2 divides by it
+    v.pt1[i] = 1.0f - c / den;                             // :204
+    v.xw4[i] = make_float4(ax * w, ay * w, az * w, w);     // (what the stand-alone x-sums read: log den through .w)
+}
+
+__global__ __launch_bounds__(64) void cpd_estep_seq_contract_kernel(CpdView v)
+{
+    if (v.state->done != 0) return;
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    const int kc = min(k, v.m - 1);
+    const float mult = -0.5f / v.state->sigma2;
+    const float yx = v.yx[kc], yy = v.yy[kc], yz = v.yz[kc];
+    float p1 = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+    for (int x = 0; x < v.n; x++) {                        // (wave-uniform x: scalar loads)
+        const float ax = v.ax[x], ay = v.ay[x], az = v.az[x];
+        const float p = affinity<false>(mult * sq_dist(ax, ay, az, yx, yy, yz), 0.f);    // the same operations as kernel 1's: the same value
+        const float value = p / v.den_part[x];             // :209  float value = p(k) / denominator
+        p1 += value;                                       // :210
+        px += ax * value; py += ay * value; pz += az * value;   // :211  px.row(k) += x * value  (a term of exactly 0 -- the reference's `if (p != 0)` -- adds nothing)
+    }
+    if (k >= v.m) return;
+    v.p1[k] = p1;
+    v.px[3 * (size_t)k] = px; v.px[3 * (size_t)k + 1] = py; v.px[3 * (size_t)k + 2] = pz;
+}
+
+hipError_t cpd_estep_sequential(const CpdView& v, hipStream_t s)
+{
+    hipLaunchKernelGGL(cpd_estep_seq_den_kernel, dim3((v.n + 63) / 64), dim3(64), 0, s, v);
+    hipLaunchKernelGGL(cpd_estep_seq_contract_kernel, dim3((v.m + 63) / 64), dim3(64), 0, s, v);
+    return hipGetLastError();
+}
+
 hipError_t cpd_xsums(const CpdView& v, double* partials, int nblocks, hipStream_t s)
 {
     hipLaunchKernelGGL(cpd_xsums_kernel, dim3(nblocks), dim3(256), 0, s, v, partials, v.xw4 != nullptr ? 1 : 0);

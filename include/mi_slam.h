@@ -270,8 +270,17 @@ typedef struct {
     float fgt_ratio_of_far_field;    /* "fgt-ratio-of-far-field" e (default 10): cells farther than sqrt(e)*sigma are skipped */
     int   fgt_order_of_truncation;   /* "fgt-order-of-truncation" p (default 8): monomials of total degree < p, 1..16 */
     int   sigma2_mode;               /* MI_SIGMA2_*: how the initial sigma^2 is computed when sigma2_init <= 0 */
-    int   reserved[4];
+    int   estep_mode;                /* MI_ESTEP_*: the order the exact E-step's sums are added in (round 6; took one of the reserved words: same size) */
+    int   reserved[3];
 } mi_cpd_params;
+
+/* The exact E-step's summation order.
+ *   DEFAULT:        chunked partial sums over the whole chip (K7a / K7b).
+ *   CPU_SEQUENTIAL: cpu-slam's own order -- each fixed point's affinities added one by one into one fp32 running sum, each moving point's P1 / PX one
+ *                   fixed point at a time, value = p / denominator (coherentpointdrift.cpp:186-213).  A parity mode, ~5 x the default's time: cpu-slam's
+ *                   running sums drop small terms whole, a one-sided error of ~2.5e-5 of sigma^2 per EM iteration that the default does not make and that
+ *                   `cpd-const-scale: true` amplifies; with this mode the device retraces the CPU restatement through it.  Single-GPU contexts, exact P only. */
+enum { MI_ESTEP_DEFAULT = 0, MI_ESTEP_CPU_SEQUENTIAL = 1 };
 
 /* The initial sigma^2 = sum_ij |b_i - a_j|^2 / (3MN) (CalculateSigmaSquared, coherentpointdrift.cpp:126-139 / cpdcuda.cu:65-78).
  *   EXACT:          closed form from the clouds' sums, fp64 (what cuda-slam's thrust reduction approximates).
@@ -296,9 +305,10 @@ void mi_cpd_params_default(mi_cpd_params* p);
 /* out_sR_t: column-major 4x4 holding scale*R (cpdcuda.cu:360) and t; out_scale may be NULL.
  * On a multi-GPU context (mi_ctx_create_dist) every rank passes both clouds whole and keeps fixed points mi_shard_range(n_after);
  * one all-reduce of 24 doubles per EM iteration merges the M-step moments, every rank returns the same result.  The FGT modes
- * (approximation != MI_CPD_APPROX_NONE; hybrid is the reference parser's default, configparser.cpp:217) run REPLICATED there:
- * every rank keeps both clouds whole and does the same arithmetic (their E-step is O((N + M) K)), no collective, the single-GPU
- * run's bits on every rank.
+ * (approximation != MI_CPD_APPROX_NONE; hybrid is the reference parser's default, configparser.cpp:217) keep both clouds whole on every
+ * rank -- they cluster whole clouds -- and split the E-step's QUERIES (round 6): the fixed points the first transform is evaluated at, the
+ * moving points of the second, the truncated E-step's tiles; the per-point weights travel through an unsigned-minimum all-reduce (bit for
+ * bit), the M-step's sums through the 24-double one: the single-GPU run's iteration counts, s R|t within 1e-6 of it.
  * Synchronous: when it returns, the context's stream is drained (round 5; the host checks inside only peek at the state, so up to one
  * iteration's worth of no-op launches or a prelaunched K-centre replay trails the copy that said "done" -- it is waited for here). */
 int mi_cpd_register(mi_ctx* ctx, const float* before_xyz, int m_before, const float* after_xyz, int n_after,

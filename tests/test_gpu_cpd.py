@@ -178,6 +178,37 @@ def test_bunny_cpd_const_scale(ctx, capi, golden, bunny):
     check_measured("bunny_cpd_const_scale_vs_cpu_slam", frob(sR, t, g["final_const_scale"]["sR"], g["final_const_scale"]["t"]), 0.1, factor=1.5)
 
 
+def test_bunny_cpd_const_scale_in_cpu_slams_summation_order(ctx, capi, golden, bunny):
+    # Round 6: MI_ESTEP_CPU_SEQUENTIAL -- the E-step's sums in cpu-slam's own order (one running fp32 sum per fixed point over the moving
+    # points in index order; P1 / PX one fixed point at a time; value = p / denominator).  The default kernels' chunked sums do not make the running sum's
+    # one-sided error, which is what separated the device from the CPU restatement on `cpd-const-scale: true` (1.1e-3, the test above); with the order
+    # retraced only the exponential's rounding is left (glibc's expf against the device's 2-ulp routine): the bar is 1e-5 per EM iteration.
+    before, after = bunny
+    g = golden.json("bunny_cpd.json")
+    o = golden.json("bunny_cpd_oracle.json")["final_const_scale"]
+    p = capi.cpd_params(max_iterations=50, const_scale=1, sigma2_init=g["sigma2_init"], estep_mode=capi.ESTEP_CPU_SEQUENTIAL)
+    sR, t, scale, it, err = ctx.cpd_register(before, after, p)
+    assert it == o["iterations"] == g["final_const_scale"]["iterations"]
+    d = frob(sR, t, o["sR"], o["t"])
+    d_ref = frob(sR, t, g["final_const_scale"]["sR"], g["final_const_scale"]["t"])
+    print("bunny CPD const-scale, cpu-slam's summation order: |d(sR|t)|_F vs oracle = %.3e (default order: 1.1e-3), vs cpu-slam = %.3e (default: 4.3e-2)" % (d, d_ref))
+    check_measured("bunny_cpd_const_scale_seq_vs_oracle", d, 1e-5 * it)
+    check_measured("bunny_cpd_const_scale_seq_vs_cpu_slam", d_ref, 0.1, factor=1.5)
+    # the scale-free run (cfg 4) in the same order: still cpu-slam's 27 iterations, and closer to the restatement than the default order is
+    o4 = golden.json("bunny_cpd_oracle.json")
+    p4 = capi.cpd_params(max_iterations=50, const_scale=0, sigma2_init=g["sigma2_init"], estep_mode=capi.ESTEP_CPU_SEQUENTIAL)
+    r4 = ctx.cpd_register(before, after, p4)
+    f = g["final_scale_free"]
+    assert r4[3] == f["iterations"]
+    print("bunny CPD scale-free, cpu-slam's summation order: vs cpu-slam %.3e" % frob(r4[0], r4[1], f["sR"], f["t"]))
+    assert frob(r4[0], r4[1], f["sR"], f["t"]) < 1e-4
+    # argument checks: a single-GPU parity mode of the exact E-step
+    with pytest.raises(capi.MiSlamError):
+        ctx.cpd_register(before, after, capi.cpd_params(max_iterations=3, approximation=capi.CPD_APPROX_HYBRID, estep_mode=capi.ESTEP_CPU_SEQUENTIAL))
+    with pytest.raises(capi.MiSlamError):
+        ctx.cpd_register(before, after, capi.cpd_params(max_iterations=3, estep_mode=7))
+
+
 def test_bunny_cpd_with_device_sigma(ctx, capi, bunny):
     # the library's own (exact) sigma^2 start: converges to the known transform of config/default.json
     before, after = bunny
