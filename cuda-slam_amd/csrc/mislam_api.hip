@@ -246,9 +246,13 @@ static int ctx_create_common(int device, mi_ctx** out)
         c->tune.svd_ieee = env_i("MISLAM_SVD_IEEE", 0);
         if (const char* ppc = getenv("MISLAM_GRID_PPC")) { const float f = (float)atof(ppc); if (f >= 0.25f && f <= 64.f) c->tune.grid_points_per_cell = f; }
         if (env_i("MISLAM_PRELOAD", 0) == 1) MI_TRY(mi_ctx_preload(c));       // =1: mi_ctx_preload as part of every context creation
-        // pinned upload staging: a ring of 16 pieces of 1 MB, pinned here, once per context (pinning costs ~0.25 ms per MB on this
-        // machine); MISLAM_PIN=0 uses the runtime's pageable-copy path instead
-        if (env_i("MISLAM_PIN", 1) != 0) {
+        // Host clouds go up through the runtime's own pageable-copy path (round 6).  Rounds 3-5 staged them through an own pinned ring of 16 x 1 MB, built
+        // against 20-50 ms stalls that round 3 pinned on the runtime's path -- and that were the process's CPU quota being throttled by idle BLAS pools
+        // (profiles/r03_stall_hunt.log: gone with the pools quiet, for either path).  Measured side by side, 20 calls each (profiles/r06_upload_paths.log):
+        // a load of two 12 MB clouds 1.35 -> 1.01 ms (the ring's one host thread copies every byte itself, 37 us per MB; the runtime pipelines larger pieces
+        // over its own staging buffers), 120 MB clouds 13.3 -> 7.8 ms, the whole 50-iteration registration at 1e6 points 6.43 -> 6.04 ms; outliers as
+        // rare on one as on the other.  MISLAM_PIN=1 brings the ring back (4 ms of pinning per context).
+        if (env_i("MISLAM_PIN", 0) != 0) {
             MI_HIP(hipHostMalloc((void**)&c->pin, mi_ctx::PIN_PIECE * mi_ctx::PIN_SLOTS, hipHostMallocDefault));
             for (hipEvent_t& e : c->pin_event) MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
