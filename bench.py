@@ -17,7 +17,7 @@ Rank 0 prints one JSON line.
                   average launch; `issue` beside it is the vector pipe's share of that kernel, from the committed counter profile of
                   this command, CALIBRATED by the same counters read off a kernel of known instruction count (tools/valu_probe)
   whole_call      one registration as the reference times it (host buffers in, allocation / upload / index builds / 50 iterations /
-                  result included: testrunner.cpp:54-56) at 1e5 and 1e6 points, with the load split into its stages
+                  result included: testrunner.cpp:54-56) at 1e5 and 1e6 points and on the bunny clouds (cfg 1), with the load split into its stages
   late_iterations the same number of steps LATE in the same registration (the headline's window is a transient: the search gets cheaper as the clouds close in)
   sizes           the same measurement at N = M = 1e4, 1e5, 1e7 (BASELINE.json: "N = 10^4 ... 10^7"), a few steps each
   bruteforce_nn   the every-pair kernel on the same clouds with `valu`, its launch against the fp32 vector-issue rate
@@ -288,13 +288,13 @@ def cpd_published_size(np, capi, ctx, n=49000, iterations=8):
     return out
 
 
-def whole_call(np, capi, ctx, n, repeats=3):
+def whole_call(np, capi, ctx, n, repeats=3, clouds=None, params=None):
     """One registration as the reference times it (testrunner.cpp:54-56, doc/documentation.tex:397): mi_icp_register on HOST buffers,
     upload / index builds / 50 iterations / result included, GPU-reference driver rules and sweep settings (testset.cpp:82-117).
     `ms` = best of `repeats` calls on a context that has seen the size (the first call of a size also pays its device allocations:
     `first_call_ms`); `breakdown` = one more call split into load stages (stream drained after each, so they add up) + iterations."""
-    before, after = synth_cloud(np, n)
-    p = capi.icp_params(cuda_slam=True, max_iterations=50, eps=1e-3, max_distance_squared=10000.0)
+    before, after = clouds if clouds is not None else synth_cloud(np, n)
+    p = params if params is not None else capi.icp_params(cuda_slam=True, max_iterations=50, eps=1e-3, max_distance_squared=10000.0)
     t0 = time.perf_counter()
     R, t, it, err = ctx.icp_register(before, after, p)
     first = (time.perf_counter() - t0) * 1e3
@@ -916,6 +916,12 @@ def main():
     whole = None
     if world == 1 and not args.no_whole_call:
         whole = {str(wn): whole_call(np, capi, ctx, wn) for wn in (100000, 1000000)}
+        # cfg 1 the same way: the bunny clouds with config/default.json's rules (cpu-slam's 39 iterations), host buffers in, result out
+        gold = os.path.join(ROOT, "tests", "golden")
+        bz = np.load(os.path.join(gold, "bunny_clouds.npz"))
+        bp = json.load(open(os.path.join(gold, "bunny_icp.json")))["params"]
+        whole["bunny_14904"] = whole_call(np, capi, ctx, 14904, clouds=(bz["before"], bz["after"]),
+                                          params=capi.icp_params(eps=bp["eps"], max_iterations=bp["max_iterations"], max_distance_squared=bp["max_distance_squared"]))
 
     # The floor of the headline path's collective: the 64 x 18-double sum of one iteration through a ONE-rank RCCL communicator, event-timed
     # (what ncclAllReduce costs on this stream before a single byte crosses xGMI).  N = 1 only, outside the timed region, never fatal.
