@@ -532,7 +532,7 @@ def test_multiplication_known_answer(ctx, capi):
 
 
 def test_upload_and_allocation_fallbacks_do_not_change_the_registration(ctx, capi, monkeypatch):
-    # MISLAM_PIN=0 (the runtime's pageable upload path instead of the context's pinned ring; read at context creation) in this process,
+    # MISLAM_PIN=1 (the context's pinned ring of rounds 3-5 instead of the runtime's pageable upload path, the default since round 6; read at context creation) in this process,
     # MISLAM_POOL=0 (plain hipMalloc / hipFree instead of the stream-ordered pool; decided once per process) in a child process: how the
     # bytes get there and where the buffers come from must not show in a single bit of the result
     import hashlib
@@ -540,7 +540,7 @@ def test_upload_and_allocation_fallbacks_do_not_change_the_registration(ctx, cap
     import subprocess
     import sys
     rng = np.random.default_rng(77)
-    before = rng.uniform(-5, 5, (60000, 3)).astype(np.float32)                  # 720 KB per cloud: through the ring
+    before = rng.uniform(-5, 5, (60000, 3)).astype(np.float32)                  # 720 KB per cloud: through the ring when it is on
     c, s = np.cos(0.1), np.sin(0.1)
     after = (before[rng.permutation(len(before))].astype(np.float64) @ np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]]).T + 0.3).astype(np.float32)
     p = capi.icp_params(max_iterations=12)
@@ -549,7 +549,7 @@ def test_upload_and_allocation_fallbacks_do_not_change_the_registration(ctx, cap
     def digest(r):
         return hashlib.sha256(np.asarray(r[0], np.float32).tobytes() + np.asarray(r[1], np.float32).tobytes() + np.int32(r[2]).tobytes() + np.float32(r[3]).tobytes()).hexdigest()
 
-    monkeypatch.setenv("MISLAM_PIN", "0")
+    monkeypatch.setenv("MISLAM_PIN", "1")
     with capi.Context(0) as c2:
         assert digest(c2.icp_register(before, after, p)) == digest(base)
     monkeypatch.delenv("MISLAM_PIN")
@@ -570,3 +570,33 @@ def test_upload_and_allocation_fallbacks_do_not_change_the_registration(ctx, cap
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert ("DIGEST " + digest(base)) in out.stdout
+
+
+def test_search_phase_counters_of_the_counting_build(ctx, capi):
+    # Round 6: mi_profile_search_phases -- the loop trip counts the measured instruction budget of the search kernel is built from
+    # (profiles/r06_search_budget.md).  The counting build runs the same control flow: its registration is the product build's bit for bit, and the
+    # counters obey the kernel's own structure.
+    from conftest import synth_cloud
+    before, after = synth_cloud(200000, seed=9)[:2]
+    p = capi.icp_params(eps=0.0, max_iterations=-1, sync_every=4)
+    ctx.icp_load(before, after, p)
+    ctx.icp_run(4)
+    ctx.search_stats(True)
+    ctx.icp_run(4)
+    ph = ctx.search_phases()
+    cand, rows, hard, pts, nodes, leaves, wwaves, longest = ctx.search_stats(False)
+    with pytest.raises(capi.MiSlamError):
+        ctx.search_phases()                                   # counting is off again
+    ctx.icp_run(4)
+    counted = ctx.icp_result()
+    ctx.icp_load(before, after, p)
+    ctx.icp_run(12)
+    plain = ctx.icp_result()
+    assert np.array_equal(counted[0], plain[0]) and np.array_equal(counted[1], plain[1]) and counted[3] == plain[3]
+    waves_per_launch = (len(before) + 63) // 64
+    assert ph["waves"] == 4 * waves_per_launch and pts == 4 * len(before)
+    assert ph["scan_waves"] + ph["walk_only_waves"] == ph["waves"] and ph["block_batches"] == ph["scan_waves"]
+    assert 0 < ph["block_dealt"] <= ph["block_batches"] and ph["block_deal_passes"] >= ph["block_dealt"] and ph["block_deal_writes"] >= ph["block_dealt"]
+    assert ph["rest_dealt"] <= ph["rest_rounds"] and ph["rest_waves"] <= ph["scan_waves"]
+    assert ph["walk_leaf_offers"] <= ph["walk_leaf_hits"] <= leaves <= ph["walk_leaf_children"] and ph["walk_only_waves"] <= wwaves <= ph["waves"]
+    assert nodes >= wwaves > 0 and cand > 0 and rows > 0 and longest > 0

@@ -138,3 +138,34 @@ def test_cpd_profile_agrees_with_the_bench_lines_live_kernel_times():
         for live_name, key in (("cpd_denom", "denominator"), ("cpd_contract", "contract")):
             p = [k["launch_ms"] for kn, k in prof49.items() if key in kn][0]
             assert abs(p - pub["kernels_ms_per_launch"][live_name]) <= 0.1 * pub["kernels_ms_per_launch"][live_name]
+
+
+# ---- the search kernel's measured instruction budget speaks for the committed kernel ---------------------------------------
+def test_search_budget_is_recomputable_and_current(tmp_path):
+    """profiles/r06_search_budget.md = static instruction counts of the warm kernel's ISA per phase (profiles/r06_search_budget_spec.json) x the counting
+    build's trip counts (profiles/r06_phase_counts.json), against SQ_INSTS_VALU / SQ_WAVES of the same launches.  Recomputed here from the sources (hipcc
+    cross-compiles without a GPU): a kernel change that moves the block layout makes the composer refuse the spec, and the rows must still add up to the
+    counter within the model's stated error."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "isa_dump.sh"), "nn_grid"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    isa = r.stdout.strip().splitlines()[-1]
+    c, _, _ = _load()
+    per_wave = c["valu_instructions_per_wave"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_budget.py"), isa, "x", "--compose", os.path.join(PROF, "r06_search_budget_spec.json"),
+                        os.path.join(PROF, "r06_phase_counts.json"), "%.1f" % per_wave], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    import re
+    m = re.search(r"rows sum to (\d+) = ([0-9.]+) of it", r.stdout)
+    assert m, r.stdout[-800:]
+    assert 0.95 <= float(m.group(2)) <= 1.15            # (conditional code inside a block is counted as always run: the model errs high)
+    counts = json.load(open(os.path.join(PROF, "r06_phase_counts.json")))
+    ph = counts["phases"]
+    L = counts["launches"]
+    assert ph["waves"] == L * ((counts["points"] + 63) // 64)                      # one wave per 64 moving points
+    assert ph["scan_waves"] + ph["walk_only_waves"] == ph["waves"] and ph["block_batches"] == ph["scan_waves"]
+    assert ph["block_dealt"] <= ph["block_batches"] and ph["rest_dealt"] <= ph["rest_rounds"] and ph["walk_leaf_offers"] <= ph["walk_leaf_hits"] <= counts["stats"]["walk_leaves"]
