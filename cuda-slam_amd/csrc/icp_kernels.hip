@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64) void icp_rows_to_state_kernel(IcpState* __restr
 // seq_b / seq_a (MI_SUM_CPU_SEQUENTIAL, else null): cpu-slam's sequential fp32 running sums of the kept pairs; its centroids
 // are those sums divided by (float)count (common.cpp:283), and t inherits their rounding.  The cross-covariance keeps the
 // fp64 form: replacing the exact centroids by the rounded ones changes H by n*da*db^T, ~1e-9 relative.
-__device__ void solve_from_moments(const double* mom, const float* seq_b, const float* seq_a, float Ri[9], float ti[3], bool svd_ieee)
+__device__ void solve_from_moments(const double* mom, const float* seq_b, const float* seq_a, float Ri[9], float ti[3], bool svd_ieee, const float* seq_H = nullptr)
 {
     const double n = mom[0];
     const double inv_n = 1.0 / n;            // (n is a count: one fp64 division instead of six on the one-lane chain)
@@ -221,6 +221,14 @@ __device__ void solve_from_moments(const double* mom, const float* seq_b, const 
     Mat3 H;
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) H.a[r][c] = (float)(mom[7 + 3 * r + c] - n * ca[r] * cb[c]);
+    // MI_SUM_CPU_SEQUENTIAL (round 6): cpu-slam's OWN matrix -- the points centred in fp32 with its sequential-sum centroids (icp_seq_cross_kernel).  For a
+    // well-conditioned H the two differ by ~1e-7 and R by as little; for a RANK-DEFICIENT one -- the first iteration of a registration whose clouds start
+    // 20-30 units apart: 20 000 moving points matched to TWO fixed points, singular values 23 064 / 0 / 0 -- the true H leaves R undetermined and what cpu-slam
+    // returns is decided by the rounding of its centring (singular values 23 064 / 1.3e-3 / 0 there); the exact matrix above then lands in another basin
+    // (the reference's convergence set, rot 0.6 / trans 30: cpu-slam 47 iterations, the exact matrix 100 iterations and 23 away).  A parity mode retraces it.
+    if (seq_H != nullptr)
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) H.a[r][c] = seq_H[3 * r + c];
     const Kabsch3 k = kabsch_rotation<true>(H, svd_ieee);     // (svd3.hpp SvdMath: hardware reciprocals and roots for the rotation parameters)
     // column-major like glm::mat3 (ConvertRotationMatrix, common.cpp:335-346)
     for (int c = 0; c < 3; c++)
@@ -256,7 +264,9 @@ __device__ void apply_solve(IcpState* __restrict__ state, const double* mom, int
     float Ri[9], ti[3];
     float seq_b[3], seq_a[3];
     for (int d = 0; d < 3; d++) { seq_b[d] = state->seq_sum_b[d]; seq_a[d] = state->seq_sum_a[d]; }
-    solve_from_moments(mom, seq_sums ? seq_b : nullptr, seq_sums ? seq_a : nullptr, Ri, ti, svd_ieee != 0);
+    float seq_H[9];
+    for (int i = 0; i < 9; i++) seq_H[i] = state->seq_H[i];
+    solve_from_moments(mom, seq_sums ? seq_b : nullptr, seq_sums ? seq_a : nullptr, Ri, ti, svd_ieee != 0, seq_sums ? seq_H : nullptr);
     for (int i = 0; i < 9; i++) state->Ri[i] = Ri[i];
     for (int i = 0; i < 3; i++) state->ti[i] = ti[i];
     float R[9], t[3];
@@ -677,9 +687,57 @@ hipError_t invert_order(const int* order, int n, int* inv, hipStream_t s)
     return hipGetLastError();
 }
 
+// cpu-slam's cross-covariance (LeastSquaresSVD, common.cpp:525-530): the kept pairs centred with ITS centroids -- the sequential sums just taken, divided
+// by (float)count -- in fp32, as GetAlignedCloud does, then alignedAfter * alignedBefore^T.  The products are summed in fp64 like the restatement's
+// (oracle/slam_oracle.c oracle_least_squares_svd: Eigen's fp32 GEMM blocking is machine-dependent), thread t taking pairs t, t + 1024, ... and the threads'
+// sums added in one fixed tree: another grouping of the same doubles than the restatement's index order -- 1e-16 relative, below the fp32 cast.  One
+// workgroup: the mode's cost is irrelevant.
+__global__ __launch_bounds__(1024) void icp_seq_cross_kernel(IcpView v)
+{
+    if (v.state->done != 0) return;
+    __shared__ double part[1024];
+    __shared__ int s_count;
+    // the count of kept pairs (the centroids' divisor): counted here in the same pass order
+    int kept_n = 0;
+    for (int i = threadIdx.x; i < v.n; i += 1024) {
+        const float d2 = __uint_as_float((unsigned int)(v.keys[i] >> 32));
+        kept_n += (v.filter_pairs ? (d2 < v.max_distance_squared) : true) ? 1 : 0;
+    }
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    atomicAdd(&s_count, kept_n);
+    __syncthreads();
+    const float fn = (float)s_count;
+    float cb[3], ca[3];
+    for (int d = 0; d < 3; d++) { cb[d] = v.state->seq_sum_b[d] / fn; ca[d] = v.state->seq_sum_a[d] / fn; }     // common.cpp:283
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < v.n; i += 1024) {
+        const unsigned long long key = v.keys[i];
+        const float d2 = __uint_as_float((unsigned int)(key >> 32));
+        if (!(v.filter_pairs ? (d2 < v.max_distance_squared) : true)) continue;
+        const int gidx = (int)(unsigned int)(key & 0xffffffffull);
+        const float4 a = v.tgt4[gidx - v.shard_lo];
+        const float ab[3] = {v.cx[i] - cb[0], v.cy[i] - cb[1], v.cz[i] - cb[2]};        // GetAlignedCloud: point - center, fp32
+        const float aa[3] = {a.x - ca[0], a.y - ca[1], a.z - ca[2]};
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) acc[3 * r + c] += (double)aa[r] * (double)ab[c];
+    }
+    for (int q = 0; q < 9; q++) {
+        part[threadIdx.x] = acc[q];
+        __syncthreads();
+        for (int w = 512; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) v.state->seq_H[q] = (float)part[0];
+        __syncthreads();
+    }
+}
+
 hipError_t icp_seq_centroids(const IcpView& v, hipStream_t s)
 {
     hipLaunchKernelGGL(icp_seq_centroid_kernel, dim3(1), dim3(384), 0, s, v);
+    hipLaunchKernelGGL(icp_seq_cross_kernel, dim3(1), dim3(1024), 0, s, v);      // (reads the sums the kernel before it left in the state)
     return hipGetLastError();
 }
 

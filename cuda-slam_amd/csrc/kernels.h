@@ -60,7 +60,7 @@ struct IcpState {
     float seq_sum_b[3];      // sum of the moving points        (GetCenterOfMass, common.cpp:281-284)
     float seq_sum_a[3];      // sum of their matched fixed points
     float seq_sum_err;       // sum of squared residuals         (GetMeanSquaredError, common.cpp:259-268)
-    float pad2_;
+    float seq_H[9];          // cpu-slam's cross-covariance of the kept pairs: sum fl32(a - ca) fl32(b - cb)^T with ITS centroids (round 6, icp_seq_cross_kernel)
 };
 
 struct IcpView {
