@@ -79,8 +79,13 @@ enum {
  *                   pairs in the caller's point order (GetCenterOfMass common.cpp:281-284, GetMeanSquaredError :259-268).
  *                   That sum is 1.3e-4 off the exact mean at 2e4 points and worse beyond, and it feeds both the translation
  *                   and the stop rule -- choose this mode to retrace cpu-slam's trajectory at sizes where its own summation
- *                   noise exceeds the 1e-4 parity budget.  Single-GPU contexts only; costs ~3.3 ms per million points per
- *                   iteration (a sequential fp32 sum cannot be re-associated). */
+ *                   noise exceeds the 1e-4 parity budget.  Round 6: the mode also takes cpu-slam's own CROSS-COVARIANCE -- the kept pairs centred
+ *                   in fp32 with those centroids (GetAlignedCloud, common.cpp:525-530) -- instead of the exact one: the two differ by ~1e-7, which
+ *                   is nothing unless the matrix is rank-deficient (a first iteration that matches every moving point to the same two fixed points:
+ *                   the exact matrix leaves R undetermined, cpu-slam's R is decided by that centring's rounding).  With it -- and the 3 x 3 SVD in IEEE
+ *                   arithmetic, developer switch MISLAM_SVD_IEEE=1 -- the device retraces the CPU restatement of cpu-slam bit for bit on the
+ *                   reference's convergence and sizes sets (tests/test_gpu_convergence_set.py).  Single-GPU contexts only; costs ~3.3 ms per million
+ *                   points per iteration (a sequential fp32 sum cannot be re-associated). */
 enum {
     MI_SUM_EXACT = 0,
     MI_SUM_CPU_SEQUENTIAL = 1
