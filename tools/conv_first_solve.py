@@ -1,3 +1,6 @@
+"""Developer tool (round 6): the FIRST Kabsch solve of one configuration of the reference's convergence set -- how many distinct fixed points the moving cloud is
+matched to, the cross-covariance and its singular values, the device's R against the restatement's (seed 1208, two distinct targets, rank 1).
+    python tools/conv_first_solve.py SEED ROTATION TRANSLATION"""
 import os, sys, json
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)

@@ -1,3 +1,6 @@
+"""Developer tool (round 6): one configuration of the reference's convergence set (20 000 points of bird.obj, spread 10) capped at 1 .. 60 iterations -- the CPU
+restatement against the device in MI_SUM_CPU_SEQUENTIAL (fast and IEEE K3) and with the default fp64 sums: where a trajectory parts from cpu-slam's.
+    python tools/conv_retrace.py SEED ROTATION TRANSLATION        (e.g. 1208 0.6 30: the rank-1 first iteration of DESIGN section 2)"""
 import os, sys, json
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
