@@ -1048,6 +1048,9 @@ def main():
         destroy = getattr(dist, "destroy_process_group", None)
         if destroy:
             destroy()
+        if rank == 0 and _STAGE["dir"] and os.environ.get("MISLAM_BENCH_PARENT") != "1":     # (a launcher of someone else's: nobody above us removes the stage files)
+            import shutil
+            shutil.rmtree(_STAGE["dir"], ignore_errors=True)
 
 
 if __name__ == "__main__":
