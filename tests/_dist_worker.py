@@ -154,6 +154,49 @@ def main():
     exact = ((b64[:, None, :] - A64[None, :, :]) ** 2).sum()
     assert abs(total - exact) < 1e-9 * exact
 
+    # C3 (round 6) -- the FGT / hybrid CPD modes with their E-step's QUERIES sharded (cpd_api.hip cpd_estep_fgt_enqueue): both clouds whole on every rank, the
+    # coefficient tables replicated; rank r evaluates the first transform at fixed points mi_shard_range(n), writes THEIR weights (1/den, x/den: a float4 per point),
+    # fills the rest with all-ones and the ranks take an element-wise UNSIGNED minimum -- which must hand every rank every weight bit for bit, whatever the
+    # pattern (NaN payloads, -0, denormals, infinities: a sum with zeros would not) -- then evaluates the second transform at moving points mi_shard_range(m);
+    # the M-step's sums of the shares add up to the unsharded ones.  Per-shard compute is the oracle's FGT E-step (test infrastructure): a query's value does
+    # not depend on which other queries are evaluated with it.
+    wts = rng.uniform(-3, 3, (m, 4)).astype(np.float32)
+    wbits = wts.view(np.uint32)
+    wbits[5] = [0x7fc00001, 0xffc12345, 0x7f800000, 0xff800000]         # NaNs with payloads, +-inf
+    wbits[6] = [0x80000000, 0x00000001, 0x807fffff, 0x00000000]         # -0, denormals, +0
+    wbits[m - 1] = [0xffffffff, 0xfffffffe, 0x7fffffff, 0x80000001]     # a NaN that IS the fill pattern, and its neighbours
+    mine = np.full((m, 4), 0xffffffff, np.uint32)
+    mine[lo:hi] = wbits[lo:hi]
+    sign = np.uint64(1) << np.uint64(63)
+    packed = mine.reshape(-1).view(np.uint64) ^ sign                     # gloo has no unsigned MIN: flip the top bit, take the signed one (bench.py does the same)
+    tw = torch.from_numpy(packed.view(np.int64).copy())
+    dist.all_reduce(tw, op=dist.ReduceOp.MIN)
+    got = (tw.numpy().view(np.uint64) ^ sign).view(np.uint32).reshape(m, 4)
+    assert np.array_equal(got, wbits), "the unsigned-minimum exchange did not reproduce every rank's bit patterns"
+    # (ranges: every fixed point, every moving point and every tile of the truncated E-step belongs to exactly one rank)
+    for count in (m, n, (m + 63) // 64, (n + 63) // 64):
+        cover = np.zeros(count, np.int32)
+        for r in range(world):
+            rl, rh = capi.shard_range(count, r, world)
+            cover[rl:rh] += 1
+        assert np.all(cover == 1)
+    # (the shares are cut from the whole run's arrays, as the device cuts them: tables replicated, queries split -- an oracle E-step on a SLICE of the fixed
+    # cloud would cluster another cloud)
+    f1, ft1, fx, fL = O.cpd_estep_fgt(y, tgt, weight, sigma2, 4.0)
+    mlo, mhi = capi.shard_range(n, rank, world)
+    a64 = tgt.astype(np.float64)
+    xs = np.zeros(8); ks = np.zeros(16)
+    xs[1:4] = (a64[lo:hi] * ft1[lo:hi, None]).sum(0); xs[4] = ((a64[lo:hi] ** 2) * ft1[lo:hi, None]).sum()
+    ks[0] = f1[mlo:mhi].astype(np.float64).sum(); ks[1:4] = (b64[mlo:mhi] * f1[mlo:mhi, None]).sum(0)
+    ks[4:13] = (b64[mlo:mhi, :, None] * fx[mlo:mhi].astype(np.float64)[:, None, :]).sum(0).reshape(9); ks[13] = ((b64[mlo:mhi] ** 2) * f1[mlo:mhi, None]).sum()
+    tf = torch.from_numpy(np.concatenate([xs, ks]))
+    dist.all_reduce(tf, op=dist.ReduceOp.SUM)
+    wantf = np.zeros(24)
+    wantf[1:4] = (a64 * ft1[:, None]).sum(0); wantf[4] = ((a64 ** 2) * ft1[:, None]).sum()
+    wantf[8] = f1.astype(np.float64).sum(); wantf[9:12] = (b64 * f1[:, None]).sum(0)
+    wantf[12:21] = (b64[:, :, None] * fx.astype(np.float64)[:, None, :]).sum(0).reshape(9); wantf[21] = ((b64 ** 2) * f1[:, None]).sum()
+    assert np.allclose(tf.numpy(), wantf, rtol=1e-12, atol=1e-9), "the shares' M-step sums do not add up to the whole run's"
+
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
